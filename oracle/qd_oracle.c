@@ -1,0 +1,540 @@
+/* qd_oracle.c -- CPU restatement of the BP-OSD inner decoder and the sliding-window loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under quits_amd/ may import, link or call this file; only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and there only as the checker / the reported
+ * CPU baseline.  The product path is the HIP library (quits_amd/csrc) and fails loudly without it.
+ *
+ * PARITY STATUS: **parity unpinned** for the BP-OSD arithmetic.  The reference (mkangquantum/quits 1.1.0) does
+ * this arithmetic in a third-party dependency, `ldpc>=2.1.2` (pyproject.toml:35; no exact pin, no lock file),
+ * class `ldpc.bposd_decoder.BpOsdDecoder`, which is neither vendored under /root/reference nor installable
+ * here (no network).  The reference's own tests hold no golden vectors for it (only 50-shot statistical
+ * thresholds, tests/test_sliding_window.py:102-103).  What follows restates ldpc 2.x's published algorithm
+ * (src_cpp/bp.hpp, osd.hpp, rref.hpp; Python wrapper bposd_decoder.pyx) anchored on the reference's call sites:
+ *   construction  quits/decoder/sliding_window.py:61,69,149,152   (pcm, bp_method, max_iter, schedule,
+ *                                                                  osd_method, osd_order, error_rate|channel_probs)
+ *   decode        quits/decoder/sliding_window.py:85,95,171,182
+ * The orchestration around it (window bookkeeping, syndrome hand-off) IS pinned: it is checked bit for bit
+ * against the reference's own Python loop run with a deterministic plug-in decoder (tests/golden/, G5).
+ *
+ * Where ldpc leaves behaviour unspecified this file makes it deterministic and says so:
+ *   - OSD column order: ldpc uses std::sort on the posterior LLRs (ties unspecified); here ties break by
+ *     ascending column index (stable).
+ *   - OSD pivot row: ldpc's RowReduce picks the lightest candidate row (a sparsity heuristic); the OSD-0
+ *     solution does not depend on that choice whenever the syndrome lies in the column space.  Here the pivot
+ *     is the lowest-index candidate row; for syndromes outside the column space the result is therefore
+ *     defined by this file, not by ldpc.
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define OQ_PRODUCT_SUM 0
+#define OQ_MINIMUM_SUM 1
+#define OQ_PARALLEL 0
+#define OQ_SERIAL 1
+#define OQ_OSD_OFF 0
+#define OQ_OSD_0 1
+#define OQ_OSD_E 2
+#define OQ_OSD_CS 3
+#define OQ_FORM_LDPC_F64 0      /* per-edge messages, double, ldpc's update order              */
+#define OQ_FORM_COMPRESSED_F32 1 /* compressed min-sum state, float: bit-exact mirror of the HIP kernel */
+#define OQ_FORM_COMPRESSED_F64 2
+#define OQ_FORM_LDPC_F32 3
+#define OQ_MAX_COL_DEG 64
+
+typedef struct {
+    int bp_method;           /* OQ_PRODUCT_SUM | OQ_MINIMUM_SUM                                   */
+    int schedule;            /* OQ_PARALLEL | OQ_SERIAL                                           */
+    int max_iter;            /* 0 -> n (ldpc convention)                                          */
+    int osd_method;          /* OQ_OSD_*                                                          */
+    int osd_order;
+    int form;                /* OQ_FORM_*                                                         */
+    double ms_scaling_factor;/* ldpc default 1.0; 0 -> 1 - 2^-it                                  */
+} oq_params;
+
+typedef struct {
+    int m, n, nnz;
+    int *rp, *ci;            /* CSR, columns ascending in a row   */
+    int *cp, *ri;            /* CSC, rows ascending in a column   */
+    int *csc2csr;            /* CSC edge -> CSR edge              */
+    int *csr_pos;            /* CSC edge -> position of that edge inside its row */
+    double *prior;
+    double *llr0;            /* log((1-p)/p) in double; cast to float by the f32 forms */
+    int rank;                /* -1 until computed */
+} oq_graph;
+
+/* ---------------------------------------------------------------------------------------------------------- */
+oq_graph *oq_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *priors)
+{
+    oq_graph *g = (oq_graph *)calloc(1, sizeof(oq_graph));
+    int nnz = row_ptr[m];
+    g->m = m; g->n = n; g->nnz = nnz; g->rank = -1;
+    g->rp = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    g->ci = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    g->cp = (int *)calloc((size_t)(n + 1), sizeof(int));
+    g->ri = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    g->csc2csr = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    g->csr_pos = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    g->prior = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    g->llr0 = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    memcpy(g->rp, row_ptr, sizeof(int) * (size_t)(m + 1));
+    memcpy(g->ci, col_idx, sizeof(int) * (size_t)nnz);
+    for (int e = 0; e < nnz; e++) {
+        if (col_idx[e] < 0 || col_idx[e] >= n) { free(g); return NULL; }
+        g->cp[col_idx[e] + 1]++;
+    }
+    for (int j = 0; j < n; j++) g->cp[j + 1] += g->cp[j];
+    int *fill = (int *)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
+    for (int i = 0; i < m; i++)
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; e++) {
+            int j = col_idx[e], dst = g->cp[j] + fill[j]++;
+            g->ri[dst] = i; g->csc2csr[dst] = e; g->csr_pos[dst] = e - row_ptr[i];
+        }
+    free(fill);
+    for (int j = 0; j < n; j++) {
+        if (g->cp[j + 1] - g->cp[j] > OQ_MAX_COL_DEG) { free(g); return NULL; }
+        g->prior[j] = priors[j];
+        g->llr0[j] = log((1.0 - priors[j]) / priors[j]);
+    }
+    return g;
+}
+
+void oq_graph_destroy(oq_graph *g)
+{
+    if (!g) return;
+    free(g->rp); free(g->ci); free(g->cp); free(g->ri); free(g->csc2csr); free(g->csr_pos);
+    free(g->prior); free(g->llr0); free(g);
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+#define REAL double
+#define SFX _f64
+#define REAL_MAX DBL_MAX
+#define REAL_ABS fabs
+#define REAL_TANH tanh
+#define REAL_LOG log
+#include "bp_core.inc"
+#undef REAL
+#undef SFX
+#undef REAL_MAX
+#undef REAL_ABS
+#undef REAL_TANH
+#undef REAL_LOG
+
+#define REAL float
+#define SFX _f32
+#define REAL_MAX FLT_MAX
+#define REAL_ABS fabsf
+#define REAL_TANH tanhf
+#define REAL_LOG logf
+#include "bp_core.inc"
+#undef REAL
+#undef SFX
+#undef REAL_MAX
+#undef REAL_ABS
+#undef REAL_TANH
+#undef REAL_LOG
+
+/* BP only.  llr_out receives the posterior LLRs as double (exact widening for the float forms).
+ * Returns 1 if converged.  ldpc's BpOsdDecoder.decode short-circuits the all-zero syndrome
+ * (bposd_decoder.pyx: returns zeros, converge=True); mirrored here with iters = 0. */
+int oq_bp_decode(const oq_graph *g, const oq_params *prm_in, const uint8_t *synd,
+                 uint8_t *dec, double *llr_out, int *iters)
+{
+    oq_params prm = *prm_in;
+    if (prm.max_iter <= 0) prm.max_iter = g->n;
+    int zero = 1;
+    for (int i = 0; i < g->m; i++) if (synd[i]) { zero = 0; break; }
+    if (zero) {
+        memset(dec, 0, (size_t)g->n);
+        for (int j = 0; j < g->n; j++) llr_out[j] = g->llr0[j];
+        *iters = 0;
+        return 1;
+    }
+    int conv;
+    int use_f32 = (prm.form == OQ_FORM_COMPRESSED_F32 || prm.form == OQ_FORM_LDPC_F32);
+    int compressed = (prm.form == OQ_FORM_COMPRESSED_F32 || prm.form == OQ_FORM_COMPRESSED_F64);
+    if (compressed && (prm.bp_method != OQ_MINIMUM_SUM || prm.schedule != OQ_PARALLEL)) return -1;
+    if (use_f32) {
+        float *l = (float *)malloc(sizeof(float) * (size_t)g->n);
+        if (compressed) conv = bp_minsum_compressed_f32(g, &prm, synd, dec, l, iters);
+        else if (prm.schedule == OQ_SERIAL) conv = bp_serial_edge_f32(g, &prm, synd, dec, l, iters);
+        else conv = bp_parallel_edge_f32(g, &prm, synd, dec, l, iters);
+        for (int j = 0; j < g->n; j++) llr_out[j] = (double)l[j];
+        free(l);
+    } else {
+        if (compressed) conv = bp_minsum_compressed_f64(g, &prm, synd, dec, llr_out, iters);
+        else if (prm.schedule == OQ_SERIAL) conv = bp_serial_edge_f64(g, &prm, synd, dec, llr_out, iters);
+        else conv = bp_parallel_edge_f64(g, &prm, synd, dec, llr_out, iters);
+    }
+    return conv;
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* OSD (ldpc osd.hpp: OsdDecoder::decode).
+ *
+ * Column order: ascending posterior LLR (ldpc `soft_decision_col_sort`), ties by ascending index.
+ * Elimination: columns are taken in that order; a column whose reduced image has a 1 on a not-yet-pivoted
+ * row becomes a pivot column (so the pivot set S is the lexicographically first independent set, exactly what
+ * ldpc's `rref(false, true, column_ordering)` finds); OSD-0 solution: e_S = H_S^-1 s, e elsewhere 0.
+ *
+ * Bookkeeping ("T-form"): rows are only ever modified by adding a pivot row, so the accumulated row
+ * transformation T (m x m) is the identity plus columns belonging to pivot rows.  Q[r] holds those bits indexed
+ * by pivot ORDER k (bit k <=> T[r][p_k], r != p_k).  (T c)[r] = [r in c] xor parity(Q[r] & {k : p_k in c}).
+ * The HIP kernel (quits_amd/csrc/osd_kernels.hip) uses the same bookkeeping.
+ *
+ * Early stop: once the transformed syndrome is zero on every non-pivot row, s lies in the span of the pivot
+ * columns found so far, and because S is an independent set the solution restricted to them is already the
+ * final OSD-0 solution (later pivots get coefficient 0).  `stop_early` = 0 disables it (full rank is then
+ * reached, as ldpc does); the result is identical, which tests/ verify.
+ */
+typedef struct { double key; int idx; } oq_sortrec;
+
+static int cmp_sortrec(const void *a, const void *b)
+{
+    const oq_sortrec *x = (const oq_sortrec *)a, *y = (const oq_sortrec *)b;
+    if (x->key < y->key) return -1;
+    if (x->key > y->key) return 1;
+    return (x->idx > y->idx) - (x->idx < y->idx);
+}
+
+void oq_osd_column_order(int n, const double *llr, int32_t *order)
+{
+    oq_sortrec *r = (oq_sortrec *)malloc(sizeof(oq_sortrec) * (size_t)(n > 0 ? n : 1));
+    for (int j = 0; j < n; j++) { r[j].key = llr[j]; r[j].idx = j; }
+    qsort(r, (size_t)n, sizeof(oq_sortrec), cmp_sortrec);
+    for (int j = 0; j < n; j++) order[j] = r[j].idx;
+    free(r);
+}
+
+typedef struct {
+    int mw;                 /* words per Q row = ceil(m/64) (rank <= m) */
+    uint64_t *Q;            /* m x mw                                    */
+    uint8_t *sp;            /* transformed syndrome, per row             */
+    int *rowpiv;            /* row -> pivot order or -1                  */
+    int *prow, *pcol;       /* pivot order -> row / column               */
+    int npiv;
+    int ncols_examined;
+} oq_elim;
+
+static void elim_free(oq_elim *E) { free(E->Q); free(E->sp); free(E->rowpiv); free(E->prow); free(E->pcol); }
+
+/* Eliminates in `order`; stops at rank `max_rank` (or when columns run out), or early when the residual syndrome
+ * vanishes (stop_early).  Gauss-Jordan: every row, pivoted or not, is updated, so on exit e[pcol[k]] = sp[prow[k]]. */
+static void elim_run(const oq_graph *g, const int32_t *order, const uint8_t *synd, int stop_early, int max_rank,
+                     oq_elim *E)
+{
+    const int m = g->m, n = g->n;
+    const int mw = (m + 63) / 64;
+    E->mw = mw;
+    E->Q = (uint64_t *)calloc((size_t)m * (size_t)mw + 1, sizeof(uint64_t));
+    E->sp = (uint8_t *)malloc((size_t)m + 1);
+    E->rowpiv = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    E->prow = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    E->pcol = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    E->npiv = 0; E->ncols_examined = 0;
+    uint8_t *t = (uint8_t *)malloc((size_t)m + 1);
+    int resid = 0;
+    for (int r = 0; r < m; r++) { E->sp[r] = synd[r] & 1; E->rowpiv[r] = -1; resid += E->sp[r]; }
+    for (int c = 0; c < n; c++) {
+        if (E->npiv >= max_rank) break;
+        if (stop_early && resid == 0) break;
+        int col = order[c];
+        E->ncols_examined = c + 1;
+        /* t = T * column */
+        memset(t, 0, (size_t)m);
+        int nmask = 0, maskk[OQ_MAX_COL_DEG];
+        for (int e = g->cp[col]; e < g->cp[col + 1]; e++) {
+            int r = g->ri[e];
+            t[r] ^= 1;
+            if (E->rowpiv[r] >= 0) maskk[nmask++] = E->rowpiv[r];
+        }
+        if (nmask)
+            for (int r = 0; r < m; r++) {
+                const uint64_t *q = E->Q + (size_t)r * mw;
+                int b = 0;
+                for (int x = 0; x < nmask; x++) b ^= (int)((q[maskk[x] >> 6] >> (maskk[x] & 63)) & 1);
+                t[r] ^= (uint8_t)b;
+            }
+        int p = -1;
+        for (int r = 0; r < m; r++) if (t[r] && E->rowpiv[r] < 0) { p = r; break; }
+        if (p < 0) continue;                       /* dependent on earlier pivot columns */
+        int k = E->npiv++;
+        const uint64_t *qp = E->Q + (size_t)p * mw;
+        int kw = k >> 6; uint64_t kb = 1ull << (k & 63);
+        int nw = kw + 1;                           /* words that can be non-zero so far */
+        for (int r = 0; r < m; r++) {
+            if (!t[r] || r == p) continue;
+            uint64_t *q = E->Q + (size_t)r * mw;
+            for (int w = 0; w < nw; w++) q[w] ^= qp[w];
+            q[kw] ^= kb;
+            if (E->sp[p]) {
+                if (E->rowpiv[r] < 0) resid += E->sp[r] ? -1 : 1;
+                E->sp[r] ^= 1;
+            }
+        }
+        if (E->sp[p]) resid -= 1;                  /* p leaves the non-pivot set */
+        E->rowpiv[p] = k; E->prow[k] = p; E->pcol[k] = col;
+    }
+    free(t);
+}
+
+int oq_gf2_rank(oq_graph *g)
+{
+    if (g->rank >= 0) return g->rank;
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->n > 0 ? g->n : 1));
+    uint8_t *z = (uint8_t *)calloc((size_t)g->m + 1, 1);
+    for (int j = 0; j < g->n; j++) order[j] = j;
+    oq_elim E;
+    elim_run(g, order, z, 0, g->m, &E);
+    g->rank = E.npiv;
+    elim_free(&E); free(order); free(z);
+    return g->rank;
+}
+
+/* OSD-0.  stats (optional, int[4]): pivots used, columns examined, residual-nonzero flag (syndrome not in the
+ * column space), 0. */
+int oq_osd0(oq_graph *g, const uint8_t *synd, const double *llr, int stop_early, uint8_t *err, int32_t *stats)
+{
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->n > 0 ? g->n : 1));
+    oq_osd_column_order(g->n, llr, order);
+    oq_elim E;
+    elim_run(g, order, synd, stop_early, stop_early ? g->m : oq_gf2_rank(g), &E);
+    memset(err, 0, (size_t)g->n);
+    for (int k = 0; k < E.npiv; k++) err[E.pcol[k]] = E.sp[E.prow[k]];
+    int inconsistent = 0;
+    for (int r = 0; r < g->m; r++) if (E.rowpiv[r] < 0 && E.sp[r]) inconsistent = 1;
+    if (stats) { stats[0] = E.npiv; stats[1] = E.ncols_examined; stats[2] = inconsistent; stats[3] = 0; }
+    elim_free(&E); free(order);
+    return 0;
+}
+
+/* OSD-CS / OSD-E of order `osd_order` (osd.hpp: osd_setup + decode).  Candidate strings live on the k = n - rank
+ * non-pivot columns taken in the sorted order; cost of a candidate = sum over its 1s of log(1/p_j) (channel
+ * probabilities, not Hamming weight); strict '<' keeps the earliest minimum, OSD-0 first. */
+int oq_osd_w(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method, int osd_order, uint8_t *err)
+{
+    const int m = g->m, n = g->n;
+    int rank = oq_gf2_rank(g);
+    int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    oq_osd_column_order(n, llr, order);
+    oq_elim E;
+    elim_run(g, order, synd, 0, rank, &E);
+    memset(err, 0, (size_t)n);
+    for (int k = 0; k < E.npiv; k++) err[E.pcol[k]] = E.sp[E.prow[k]];
+    if (osd_order <= 0 || osd_method == OQ_OSD_0 || osd_method == OQ_OSD_OFF) { elim_free(&E); free(order); return 0; }
+    /* non-pivot columns in sorted order */
+    uint8_t *ispiv = (uint8_t *)calloc((size_t)n + 1, 1);
+    for (int k = 0; k < E.npiv; k++) ispiv[E.pcol[k]] = 1;
+    int kk = n - E.npiv;
+    int *npc = (int *)malloc(sizeof(int) * (size_t)(kk > 0 ? kk : 1));
+    for (int c = 0, q = 0; c < n; c++) if (!ispiv[order[c]]) npc[q++] = order[c];
+    /* (T c)[pivot rows] for a non-pivot column c, via the final Q: flipping column c on changes the pivot
+     * coefficients by exactly that vector. */
+    double best = 0;
+    for (int j = 0; j < n; j++) if (err[j]) best += log(1.0 / g->prior[j]);
+    uint8_t *cand = (uint8_t *)malloc((size_t)n + 1);
+    uint8_t *tc = (uint8_t *)malloc((size_t)m + 1);
+    uint8_t *base = (uint8_t *)malloc((size_t)n + 1);
+    memcpy(base, err, (size_t)n);
+    long ncand;
+    int w = osd_order > kk ? kk : osd_order;
+    if (osd_method == OQ_OSD_E) ncand = (1L << w) - 1;
+    else ncand = (long)kk + (long)w * (w - 1) / 2;
+    for (long ic = 0; ic < ncand; ic++) {
+        int sel[64], nsel = 0;
+        if (osd_method == OQ_OSD_E) {
+            long pat = ic + 1;
+            for (int b = 0; b < w; b++) if ((pat >> b) & 1) sel[nsel++] = b;
+        } else if (ic < kk) {
+            sel[nsel++] = (int)ic;
+        } else {
+            long q = ic - kk; int a = 0;
+            while (q >= w - 1 - a) { q -= w - 1 - a; a++; }
+            sel[0] = a; sel[1] = a + 1 + (int)q; nsel = 2;
+        }
+        memcpy(cand, base, (size_t)n);
+        for (int s = 0; s < nsel; s++) {
+            int col = npc[sel[s]];
+            memset(tc, 0, (size_t)m);
+            int nmask = 0, maskk[OQ_MAX_COL_DEG];
+            for (int e = g->cp[col]; e < g->cp[col + 1]; e++) {
+                int r = g->ri[e];
+                tc[r] ^= 1;
+                if (E.rowpiv[r] >= 0) maskk[nmask++] = E.rowpiv[r];
+            }
+            for (int k = 0; k < E.npiv; k++) {
+                int r = E.prow[k];
+                const uint64_t *q = E.Q + (size_t)r * E.mw;
+                int b = tc[r];
+                for (int x = 0; x < nmask; x++) b ^= (int)((q[maskk[x] >> 6] >> (maskk[x] & 63)) & 1);
+                if (b) cand[E.pcol[k]] ^= 1;
+            }
+            cand[col] = 1;
+        }
+        double wgt = 0;
+        for (int j = 0; j < n; j++) if (cand[j]) wgt += log(1.0 / g->prior[j]);
+        if (wgt < best) { best = wgt; memcpy(err, cand, (size_t)n); }
+    }
+    free(cand); free(tc); free(base); free(npc); free(ispiv); elim_free(&E); free(order);
+    return 0;
+}
+
+/* BpOsdDecoder.decode (bposd_decoder.pyx): BP; if converged return the BP decision, else OSD on the posteriors.
+ * flags_out (optional, int[4]): converged, iterations, osd pivots, osd inconsistent. */
+int oq_bposd_decode(oq_graph *g, const oq_params *prm, const uint8_t *synd, uint8_t *err, int32_t *flags_out)
+{
+    double *llr = (double *)malloc(sizeof(double) * (size_t)(g->n > 0 ? g->n : 1));
+    int iters = 0;
+    int32_t st[4] = {0, 0, 0, 0};
+    int conv = oq_bp_decode(g, prm, synd, err, llr, &iters);
+    if (conv < 0) { free(llr); return -1; }
+    if (!conv && prm->osd_method != OQ_OSD_OFF) {
+        if (prm->osd_method == OQ_OSD_0 || prm->osd_order == 0) oq_osd0(g, synd, llr, 1, err, st);
+        else oq_osd_w(g, synd, llr, prm->osd_method, prm->osd_order, err);
+    }
+    if (flags_out) { flags_out[0] = conv; flags_out[1] = iters; flags_out[2] = st[0]; flags_out[3] = st[2]; }
+    free(llr);
+    return 0;
+}
+
+int oq_bposd_decode_batch(oq_graph *g, const oq_params *prm, const uint8_t *synd, int64_t B, uint8_t *err,
+                          int32_t *flags /* B x 4 or NULL */)
+{
+    for (int64_t b = 0; b < B; b++) {
+        int rc = oq_bposd_decode(g, prm, synd + b * g->m, err + b * g->n, flags ? flags + 4 * b : NULL);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* Sliding-window loop, circuit-level (quits/decoder/sliding_window.py:162-186), for a batch of shots.
+ * windows[k] decodes rows [row0[k], row0[k] + g_k->m) of the detector record; L[k] / U[k] are CSR matrices over
+ * the first ncommit[k] columns of window k (window_observable_set / window_update, base.py:170,177).
+ */
+typedef struct {
+    int nrows, ncols;
+    int *rp, *ci;
+} oq_csr;
+
+oq_csr *oq_csr_create(int nrows, int ncols, const int32_t *rp, const int32_t *ci)
+{
+    oq_csr *c = (oq_csr *)malloc(sizeof(oq_csr));
+    c->nrows = nrows; c->ncols = ncols;
+    c->rp = (int *)malloc(sizeof(int) * (size_t)(nrows + 1));
+    c->ci = (int *)malloc(sizeof(int) * (size_t)(rp[nrows] > 0 ? rp[nrows] : 1));
+    memcpy(c->rp, rp, sizeof(int) * (size_t)(nrows + 1));
+    memcpy(c->ci, ci, sizeof(int) * (size_t)rp[nrows]);
+    return c;
+}
+void oq_csr_destroy(oq_csr *c) { if (c) { free(c->rp); free(c->ci); free(c); } }
+
+int oq_sliding_window_decode(int nwin, oq_graph **gs, oq_csr **Ls, oq_csr **Us, const int32_t *row0,
+                             int nz, int ndet, int nobs, const oq_params *prm,
+                             const uint8_t *samples /* B x ndet */, int64_t B,
+                             uint8_t *pred /* B x nobs */, int64_t *counters /* [4]: bp-converged windows, osd windows, total iters, inconsistent */)
+{
+    int maxm = 0, maxn = 0;
+    for (int k = 0; k < nwin; k++) { if (gs[k]->m > maxm) maxm = gs[k]->m; if (gs[k]->n > maxn) maxn = gs[k]->n; }
+    uint8_t *s = (uint8_t *)malloc((size_t)maxm + 1), *e = (uint8_t *)malloc((size_t)maxn + 1);
+    uint8_t *upd = (uint8_t *)malloc((size_t)nz + 1);
+    int32_t fl[4];
+    if (counters) memset(counters, 0, sizeof(int64_t) * 4);
+    for (int64_t b = 0; b < B; b++) {
+        const uint8_t *row = samples + b * ndet;
+        uint8_t *acc = pred + b * nobs;
+        memset(acc, 0, (size_t)nobs);
+        memset(upd, 0, (size_t)nz);
+        for (int k = 0; k < nwin; k++) {
+            oq_graph *g = gs[k];
+            for (int i = 0; i < g->m; i++) s[i] = row[row0[k] + i] & 1;
+            for (int i = 0; i < nz && i < g->m; i++) s[i] ^= upd[i];
+            if (oq_bposd_decode(g, prm, s, e, fl)) { free(s); free(e); free(upd); return -1; }
+            if (counters) { counters[0] += fl[0]; counters[1] += !fl[0]; counters[2] += fl[1]; counters[3] += fl[3]; }
+            const oq_csr *L = Ls[k];
+            for (int o = 0; o < L->nrows; o++) {
+                int p = 0;
+                for (int x = L->rp[o]; x < L->rp[o + 1]; x++) p ^= e[L->ci[x]];
+                acc[o] ^= (uint8_t)p;
+            }
+            if (k + 1 < nwin) {
+                const oq_csr *U = Us[k];
+                for (int o = 0; o < U->nrows; o++) {
+                    int p = 0;
+                    for (int x = U->rp[o]; x < U->rp[o + 1]; x++) p ^= e[U->ci[x]];
+                    upd[o] = (uint8_t)p;
+                }
+            }
+        }
+    }
+    free(s); free(e); free(upd);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------- */
+/* DEM sampler: stands in for stim's detector sampler (quits/simulation.py:23-27), which is absent here.
+ * e_j ~ Bernoulli(p_j) independently, s = H e, o = L e  (mod 2).  Randomness: Philox4x32-10, key = (seed lo, hi),
+ * counter = (shot lo, shot hi, j / 4, 0); word (j & 3) of the output decides fault j:  fires iff word < thr_j,
+ * thr_j = floor(p_j * 2^32).  Pure integer work, so the HIP sampler (quits_amd/csrc/sampler.hip) is bit-exact. */
+static inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                 uint32_t out[4])
+{
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void oq_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+}
+
+uint32_t oq_prob_threshold(double p)
+{
+    double t = floor(p * 4294967296.0);
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+/* H given in CSC (cp, ri) over n faults; Lobs in CSC too (lcp, lri).  Outputs are byte arrays. */
+int oq_sample_dem(int m, int n, int nobs, const int32_t *cp, const int32_t *ri, const int32_t *lcp,
+                  const int32_t *lri, const double *priors, uint64_t seed, int64_t shot0, int64_t B,
+                  uint8_t *synd /* B x m */, uint8_t *obs /* B x nobs */, int32_t *nfaults /* B or NULL */)
+{
+    uint32_t *thr = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n > 0 ? n : 1));
+    for (int j = 0; j < n; j++) thr[j] = oq_prob_threshold(priors[j]);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    for (int64_t b = 0; b < B; b++) {
+        uint64_t shot = (uint64_t)(shot0 + b);
+        uint8_t *s = synd + b * m, *o = obs + b * nobs;
+        memset(s, 0, (size_t)m); memset(o, 0, (size_t)nobs);
+        int cnt = 0;
+        for (int j4 = 0; j4 < n; j4 += 4) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)shot, (uint32_t)(shot >> 32), (uint32_t)(j4 >> 2), 0u, k0, k1, r);
+            for (int x = 0; x < 4 && j4 + x < n; x++) {
+                int j = j4 + x;
+                if (r[x] < thr[j]) {
+                    cnt++;
+                    for (int e = cp[j]; e < cp[j + 1]; e++) s[ri[e]] ^= 1;
+                    for (int e = lcp[j]; e < lcp[j + 1]; e++) o[lri[e]] ^= 1;
+                }
+            }
+        }
+        if (nfaults) nfaults[b] = cnt;
+    }
+    free(thr);
+    return 0;
+}
+
+int oq_version(void) { return 1; }

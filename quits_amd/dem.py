@@ -1,0 +1,225 @@
+"""Circuit -> detector error model, without Stim.
+
+Stands in for `circuit.detector_error_model(decompose_errors=False)` at the reference call site
+`/root/reference/src/quits/decoder/base.py:151` (Stim is an external C++ wheel that is absent from
+the build image).  Semantics restated from Stim's error analyser:
+
+* backward pass keeping, per qubit, the set of detectors/observables an X (resp. Z) error inserted
+  at that point would flip;
+* X_ERROR/Z_ERROR(p): one mechanism;  DEPOLARIZE1(p): X, Y, Z components, each with the
+  independent-equivalent probability  q = 1/2 - 1/2*sqrt(1 - 4p/3);  DEPOLARIZE2(p): 15 components
+  with  q = 1/2 - 1/2*(1 - 16p/15)**(1/8);
+* mechanisms with identical (detectors, observables) symptom combine  p <- p(1-q) + q(1-p);
+  empty symptoms are dropped;
+* errors are emitted sorted lexicographically by target list, detectors before observables.  That is
+  Stim's order inside one flush block; SURVEY.md App. C shows `spacetime()` cuts identical windows
+  for this order and for Stim's block-by-block order.
+
+The objects returned duck-type exactly the attributes `detector_error_model_to_matrix`
+(`decoder/base.py:101-125`) touches, so the *reference* function can consume them unchanged (used to
+generate tests/golden fixtures) and so can this package's restatement.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+from .stim_text import Op, flatten
+
+
+class DemTarget:
+    __slots__ = ("val", "_obs")
+
+    def __init__(self, val: int, is_observable: bool):
+        self.val = val
+        self._obs = is_observable
+
+    def is_relative_detector_id(self) -> bool:
+        return not self._obs
+
+    def is_logical_observable_id(self) -> bool:
+        return self._obs
+
+    def __repr__(self):
+        return ("L%d" if self._obs else "D%d") % self.val
+
+
+class DemInstruction:
+    __slots__ = ("type", "_p", "_dets", "_obs")
+
+    def __init__(self, p: float, dets: Tuple[int, ...], obs: Tuple[int, ...]):
+        self.type = "error"
+        self._p = p
+        self._dets = dets
+        self._obs = obs
+
+    def args_copy(self) -> List[float]:
+        return [self._p]
+
+    def targets_copy(self) -> List[DemTarget]:
+        return [DemTarget(d, False) for d in self._dets] + [DemTarget(o, True) for o in self._obs]
+
+    def __repr__(self):
+        t = " ".join(["D%d" % d for d in self._dets] + ["L%d" % o for o in self._obs])
+        return "error(%.17g) %s" % (self._p, t)
+
+
+class DetectorErrorModel:
+    """Flat list of independent error mechanisms (already 'flattened': no repeat/shift)."""
+
+    def __init__(self, errors: List[Tuple[float, Tuple[int, ...], Tuple[int, ...]]],
+                 num_detectors: int, num_observables: int):
+        self.errors = errors
+        self.num_detectors = num_detectors
+        self.num_observables = num_observables
+
+    def flattened(self):
+        return [DemInstruction(p, d, o) for (p, d, o) in self.errors]
+
+    @property
+    def num_errors(self) -> int:
+        return len(self.errors)
+
+    def __str__(self):
+        return "\n".join(repr(i) for i in self.flattened())
+
+
+def _bits(x: int) -> List[int]:
+    out = []
+    while x:
+        low = x & -x
+        out.append(low.bit_length() - 1)
+        x ^= low
+    return out
+
+
+def circuit_to_dem(text: str) -> DetectorErrorModel:
+    """Backward Pauli-sensitivity analysis of a QUITS-dialect Stim circuit."""
+    ops, num_meas, num_det, num_obs = flatten(text)
+    # symptom bitmask layout: bit d for detector d, bit num_det + o for observable o
+    meas_sens = [0] * num_meas            # which detectors/observables include measurement k
+    nq = 1 + max((max(op.targets) for op in ops if op.name not in ("DETECTOR", "OBSERVABLE_INCLUDE")
+                  and op.targets), default=0)
+    xs = [0] * nq                          # flipped by an X error on q inserted *here*
+    zs = [0] * nq
+    probs: Dict[int, float] = {}
+
+    def add(sym: int, q: float):
+        if sym == 0 or q == 0.0:
+            return
+        p = probs.get(sym)
+        probs[sym] = q if p is None else p * (1.0 - q) + q * (1.0 - p)
+
+    m = num_meas                           # running "measurements before this point" counter
+    for op in reversed(ops):
+        name = op.name
+        t = op.targets
+        if name == "DETECTOR":
+            bit = 1 << int(op.arg)
+            for k in t:
+                meas_sens[k] ^= bit
+        elif name == "OBSERVABLE_INCLUDE":
+            bit = 1 << (num_det + int(op.arg))
+            for k in t:
+                meas_sens[k] ^= bit
+        elif name == "CX":
+            # forward: X_c -> X_c X_t ; Z_t -> Z_c Z_t  (pairs are applied in order; undo in reverse)
+            for i in range(len(t) - 2, -1, -2):
+                c, tg = t[i], t[i + 1]
+                xs[c] ^= xs[tg]
+                zs[tg] ^= zs[c]
+        elif name == "H":
+            for q in t:
+                xs[q], zs[q] = zs[q], xs[q]
+        elif name == "M":
+            for q in reversed(t):
+                m -= 1
+                xs[q] ^= meas_sens[m]
+        elif name == "MX":
+            for q in reversed(t):
+                m -= 1
+                zs[q] ^= meas_sens[m]
+        elif name == "MR":
+            for q in reversed(t):
+                m -= 1
+                xs[q] = meas_sens[m]       # reset erases later sensitivity, then the Z-measurement
+                zs[q] = 0
+        elif name in ("R", "RX"):
+            for q in t:
+                xs[q] = 0
+                zs[q] = 0
+        elif name == "X_ERROR":
+            for q in t:
+                add(xs[q], op.arg)
+        elif name == "Z_ERROR":
+            for q in t:
+                add(zs[q], op.arg)
+        elif name == "DEPOLARIZE1":
+            if op.arg > 0.75:
+                raise ValueError("DEPOLARIZE1 probability above 3/4")
+            q1 = 0.5 - 0.5 * math.sqrt(1.0 - 4.0 * op.arg / 3.0)
+            for q in t:
+                x, z = xs[q], zs[q]
+                add(x, q1)
+                add(z, q1)
+                add(x ^ z, q1)
+        elif name == "DEPOLARIZE2":
+            if op.arg > 15.0 / 16.0:
+                raise ValueError("DEPOLARIZE2 probability above 15/16")
+            q2 = 0.5 - 0.5 * (1.0 - 16.0 * op.arg / 15.0) ** 0.125
+            for i in range(0, len(t), 2):
+                a, b = t[i], t[i + 1]
+                pa = (0, xs[a], xs[a] ^ zs[a], zs[a])
+                pb = (0, xs[b], xs[b] ^ zs[b], zs[b])
+                for ia in range(4):
+                    for ib in range(4):
+                        if ia or ib:
+                            add(pa[ia] ^ pb[ib], q2)
+        else:  # pragma: no cover - flatten() only emits the names above
+            raise AssertionError(name)
+    if m != 0:
+        raise AssertionError("measurement bookkeeping is inconsistent")
+
+    det_mask = (1 << num_det) - 1
+    rows = []
+    for sym, p in probs.items():
+        dets = tuple(_bits(sym & det_mask))
+        obs = tuple(_bits(sym >> num_det))
+        rows.append((dets, obs, p))
+    # Stim orders DemTargets with detectors before observables; compare target lists lexicographically
+    rows.sort(key=lambda r: tuple(r[0]) + tuple(num_det + o for o in r[1]))
+    errors = [(p, d, o) for (d, o, p) in rows]
+    return DetectorErrorModel(errors, num_det, num_obs)
+
+
+class Circuit(str):
+    """Circuit text with the one Stim method the decoder path calls (`decoder/base.py:151`)."""
+
+    _dem_cache = None
+
+    def detector_error_model(self, decompose_errors: bool = False, **_ignored) -> DetectorErrorModel:
+        if decompose_errors:
+            raise NotImplementedError("decompose_errors=True is not used by the QUITS decoder path")
+        if self._dem_cache is None:
+            self._dem_cache = circuit_to_dem(str(self))
+        return self._dem_cache
+
+    @property
+    def num_detectors(self) -> int:
+        return self.detector_error_model().num_detectors
+
+    @property
+    def num_observables(self) -> int:
+        return self.detector_error_model().num_observables
+
+
+def as_dem(circuit) -> DetectorErrorModel:
+    """Accept a stim.Circuit (if Stim is installed), circuit text, a Circuit or a DEM-like object."""
+    if hasattr(circuit, "flattened") and hasattr(circuit, "num_detectors") and not isinstance(circuit, str):
+        return circuit
+    if isinstance(circuit, str):
+        return Circuit(circuit).detector_error_model() if not isinstance(circuit, Circuit) \
+            else circuit.detector_error_model()
+    if hasattr(circuit, "detector_error_model"):
+        return circuit.detector_error_model(decompose_errors=False)
+    raise TypeError("circuit must be a stim.Circuit, circuit text, quits_amd.dem.Circuit or a DEM")
