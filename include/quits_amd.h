@@ -1,0 +1,137 @@
+/* quits_amd.h -- C ABI of libquits_amd.so, the MI355X (gfx950) sliding-window BP-OSD decoder.
+ *
+ * This is the drop-in boundary for the decoding hot path of mkangquantum/quits.  Every entry point names the
+ * reference interface it stands in for (paths relative to /root/reference/src/quits/).  The reference reaches its
+ * inner decoder through the Python extension `ldpc.bposd_decoder.BpOsdDecoder`; a maintainer would bind this
+ * library with ctypes exactly as quits_amd/_lib.py does (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary; return 0 on success, a negative QD_E* code on error,
+ *     with a thread-local message behind qd_last_error();
+ *   - pointers named d_* are DEVICE pointers owned by the caller (e.g. torch tensors' data_ptr()); the library
+ *     allocates only its own graph and workspace memory and frees it in *_destroy;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); NULL = default stream;
+ *   - all launches are asynchronous; nothing here synchronises the device unless it says so;
+ *   - one process per GPU; distinct decoders are independent, one decoder must not be used concurrently.
+ */
+#ifndef QUITS_AMD_H
+#define QUITS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_OK 0
+#define QD_EINVAL (-1)      /* bad argument                                             */
+#define QD_EUNSUPPORTED (-2)/* legal for ldpc, not implemented on the device path      */
+#define QD_EHIP (-3)        /* HIP runtime error                                        */
+#define QD_ECAPACITY (-4)   /* graph does not fit the kernels' on-chip layout          */
+
+/* bp_method / schedule / osd_method: the string options of quits/decoder/bposd.py:27-29 as integers */
+#define QD_BP_PRODUCT_SUM 0
+#define QD_BP_MINIMUM_SUM 1
+#define QD_SCHEDULE_PARALLEL 0
+#define QD_SCHEDULE_SERIAL 1
+#define QD_OSD_OFF 0
+#define QD_OSD_0 1
+#define QD_OSD_E 2
+#define QD_OSD_CS 3
+
+/* status word written per shot by qd_decode_batch */
+#define QD_STATUS_ITER_MASK 0xFFFF      /* BP iterations used                                         */
+#define QD_STATUS_CONVERGED (1 << 16)   /* BP reproduced the syndrome                                 */
+#define QD_STATUS_OSD (1 << 17)         /* OSD post-processing produced the output                    */
+#define QD_STATUS_INCONSISTENT (1 << 18)/* OSD: syndrome outside the column space of the window matrix */
+#define QD_STATUS_ZERO (1 << 19)        /* all-zero syndrome short-circuit                            */
+
+typedef struct qd_graph qd_graph;       /* one window's Tanner graph + priors, resident on one device */
+typedef struct qd_decoder qd_decoder;   /* graph + parameters + device workspace                      */
+typedef struct qd_spmat qd_spmat;       /* sparse GF(2) matrix on the device (L_k, U_k, H for sampling) */
+
+/* Keyword arguments the reference hands to BpOsdDecoder (decoder/bposd.py:38-49,74-83). */
+typedef struct qd_params {
+    int32_t bp_method;          /* QD_BP_*        ; device path: MINIMUM_SUM                     */
+    int32_t schedule;           /* QD_SCHEDULE_*  ; device path: PARALLEL (flooding)             */
+    int32_t max_iter;           /* 0 -> number of faults n (ldpc convention)                     */
+    int32_t osd_method;         /* QD_OSD_*       ; device path: OFF, 0 (and CS/E with order 0)  */
+    int32_t osd_order;
+    int32_t reserved;
+    double ms_scaling_factor;   /* not exposed by the reference wrapper -> ldpc default 1.0; 0 = 1-2^-it */
+} qd_params;
+
+int qd_version(void);
+const char *qd_last_error(void);
+/* Number of visible HIP devices (0 if none): lets a host fail loudly before building anything. */
+int qd_device_count(void);
+
+/* ---- graph: replaces the sparse-matrix half of BpOsdDecoder.__init__ (call sites
+ *      decoder/sliding_window.py:61,69,149,152).  CSR of the window check matrix (m detectors x n faults, column
+ *      indices ascending in each row) and the n channel probabilities (`channel_probs`, sliding_window.py:148,151;
+ *      pass n copies of `error_rate` for the phenomenological variant, bposd.py:43,49). */
+int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, const int32_t *col_idx, const double *priors,
+                    int32_t device, qd_graph **out);
+void qd_graph_destroy(qd_graph *g);
+/* info[0..9] = m, n, nnz, max row weight, max column weight, BP block threads, BP LDS bytes, OSD block threads,
+ *              OSD LDS bytes, GF(2) rank of the matrix */
+int qd_graph_info(const qd_graph *g, int32_t *info);
+
+/* ---- decoder: replaces BpOsdDecoder.__init__'s parameter half. */
+int qd_decoder_create(const qd_graph *g, const qd_params *params, qd_decoder **out);
+void qd_decoder_destroy(qd_decoder *d);
+/* Pre-size the device workspace for batches of up to max_batch shots (otherwise grown on demand, which
+ * synchronises). */
+int qd_decoder_reserve(qd_decoder *d, int64_t max_batch);
+
+/* ---- decode: replaces the per-shot `decoder.decode(syndrome)` calls (sliding_window.py:85,95,171,182) for a
+ *      whole batch of shots, including the syndrome preparation in front of them (:168-169,179-180):
+ *        syndrome[b][i] = d_det[b * det_stride + det_offset + i]  (i < m)   XOR   d_upd[b * upd_stride + i] (i < upd_rows)
+ *      d_det: one byte per detector (0/1), i.e. the `zcheck_samples` array; d_upd may be NULL.
+ *      Outputs: d_err_bits[b][w], w < ceil(n/32): bit (j & 31) of word (j >> 5) = decoded fault j;
+ *               d_status[b]: QD_STATUS_* flags | iterations. */
+int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset,
+                    const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
+                    uint32_t *d_err_bits, int32_t *d_status, void *stream);
+
+/* Posterior LLRs of the last qd_decode_batch call for shots whose BP did not converge are kept in the decoder's
+ * workspace; this copies shot b's (float[n], fault order) to d_out, or returns QD_EINVAL if b converged.
+ * Synchronises.  Test/diagnostic hook (ldpc exposes `log_prob_ratios` the same way). */
+int qd_decoder_failed_llr(qd_decoder *d, int64_t b, float *d_out, void *stream);
+
+/* Per-kernel device time of this decoder accumulated between calls (milliseconds, HIP events on `stream`):
+ * out[0] BP kernel, out[1] OSD kernel, out[2] number of BP launches, out[3] number of OSD launches.
+ * enable != 0 turns event recording on.  qd_decoder_profile synchronises on the recorded events. */
+int qd_decoder_set_profiling(qd_decoder *d, int32_t enable);
+int qd_decoder_profile(qd_decoder *d, double *out, int32_t reset);
+
+/* ---- GF(2) sparse matrices and the window hand-off: replace `window_observable_set[k] @ e % 2` and
+ *      `window_update[k] @ e % 2` (sliding_window.py:172,174,183).  CSR, nrows x ncols. */
+int qd_spmat_create(int32_t nrows, int32_t ncols, const int32_t *row_ptr, const int32_t *col_idx, int32_t device,
+                    qd_spmat **out);
+void qd_spmat_destroy(qd_spmat *s);
+/* d_out[b * out_stride + r] (one byte per row) = (accumulate ? old : 0) XOR parity(row r of A AND e_b),
+ * where e_b are the packed error bits of shot b (err_stride_words words per shot). */
+int qd_gf2_spmv_batch(const qd_spmat *A, const uint32_t *d_err_bits, int64_t err_stride_words, int64_t B,
+                      uint8_t *d_out, int64_t out_stride, int32_t accumulate, void *stream);
+
+/* Packed error bits -> one byte per fault (the array ldpc's decode() returns; class-level plug-in). */
+int qd_unpack_bits(const uint32_t *d_bits, int64_t stride_words, int32_t nbits, int64_t B, uint8_t *d_out,
+                   int64_t out_stride, void *stream);
+
+/* Number of shots whose prediction differs from the observable flips on any of k bits: the `pL` numerator of
+ * tests/test_sliding_window.py:83.  d_count (int64 on device) is incremented. */
+int qd_count_mismatch(const uint8_t *d_pred, const uint8_t *d_obs, int32_t k, int64_t B, int64_t *d_count,
+                      void *stream);
+
+/* ---- synthetic input: stands in for stim's detector sampler (simulation.py:23-27), absent here.
+ *      e_j ~ Bernoulli(priors_j) (Philox4x32-10, key = seed, counter = (shot0 + b, j / 4)), s = H e, o = L e.
+ *      Ht / Lt are the TRANSPOSES as CSR (row j = fault j -> detectors / observables it flips).
+ *      d_det: B x det_stride bytes (first m columns written), d_obs: B x obs_stride bytes. */
+int qd_sample_dem(const qd_spmat *Ht, const qd_spmat *Lt, const double *priors, uint64_t seed, int64_t shot0,
+                  int64_t B, uint8_t *d_det, int64_t det_stride, uint8_t *d_obs, int64_t obs_stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUITS_AMD_H */

@@ -1,0 +1,524 @@
+// qd_api.hip -- host side of libquits_amd.so: the extern "C" entry points declared in include/quits_amd.h.
+#include "../../include/quits_amd.h"
+#include "qd_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
+hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t cap, hipStream_t s);
+hipError_t qd_launch_spmv(const SpmatDev &A, const uint32_t *err, int64_t err_stride, int64_t B, uint8_t *out,
+                          int64_t out_stride, int accumulate, hipStream_t s);
+hipError_t qd_launch_unpack(const uint32_t *bits, int64_t stride_words, int nbits, int64_t B, uint8_t *out,
+                            int64_t out_stride, hipStream_t s);
+hipError_t qd_launch_count(const uint8_t *pred, const uint8_t *obs, int k, int64_t B, int64_t *count, hipStream_t s);
+hipError_t qd_launch_sample(const SpmatDev &Ht, const SpmatDev &Lt, const uint32_t *thr, uint64_t seed, int64_t shot0,
+                            int64_t B, int m, int nobs, uint8_t *det, int64_t det_stride, uint8_t *obs,
+                            int64_t obs_stride, hipStream_t s);
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(QD_EHIP, "%s: %s", #expr, hipGetErrorString(e_));              \
+    } while (0)
+
+struct DevAllocs {
+    std::vector<void *> ptrs;
+    template <class Tp> int upload(const std::vector<Tp> &h, const Tp **out)
+    {
+        void *d = nullptr;
+        size_t bytes = std::max<size_t>(h.size() * sizeof(Tp), 16);
+        if (hipMalloc(&d, bytes) != hipSuccess) return -1;
+        ptrs.push_back(d);
+        if (!h.empty() && hipMemcpy(d, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice) != hipSuccess) return -1;
+        *out = reinterpret_cast<const Tp *>(d);
+        return 0;
+    }
+    void release()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+        ptrs.clear();
+    }
+};
+
+struct qd_graph {
+    int device = 0;
+    int m = 0, n = 0, nnz = 0, max_rdeg = 0, max_cdeg = 0, rank = -1;
+    BpGraphDev bp{};
+    OsdGraphDev osd{};
+    DevAllocs mem;
+    std::vector<int32_t> h_cp, h_ri;   // host CSC, for the rank
+};
+
+struct qd_decoder {
+    const qd_graph *g = nullptr;
+    qd_params prm{};
+    int64_t cap = 0;
+    int osd_blocks = 0;
+    float *llr_ws = nullptr;
+    int32_t *fail_list = nullptr, *fail_count = nullptr;
+    uint16_t *order_ws = nullptr;
+    uint64_t *q_spill = nullptr;
+    int profiling = 0;
+    std::vector<hipEvent_t> ev;        // triples (bp start, bp end / osd start, osd end)
+    double acc_ms[4] = {0, 0, 0, 0};
+};
+
+struct qd_spmat {
+    int device = 0;
+    SpmatDev d{};
+    DevAllocs mem;
+};
+
+static inline int align16(int x) { return (x + 15) & ~15; }
+static inline int pad64(int x) { return (x + 63) & ~63; }
+
+extern "C" int qd_version(void) { return 100; }
+extern "C" const char *qd_last_error(void) { return g_err; }
+extern "C" int qd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, const int32_t *col_idx,
+                               const double *priors, int32_t device, qd_graph **out)
+{
+    if (!out) return fail(QD_EINVAL, "out is null");
+    *out = nullptr;
+    if (m <= 0 || n <= 0 || !row_ptr || !col_idx || !priors) return fail(QD_EINVAL, "empty or null graph");
+    if (m > 32767) return fail(QD_ECAPACITY, "m = %d detectors per window exceeds 32767", m);
+    if (n > 65535) return fail(QD_ECAPACITY, "n = %d faults per window exceeds 65535", n);
+    const int nnz = row_ptr[m];
+    if (row_ptr[0] != 0 || nnz < 0) return fail(QD_EINVAL, "bad row_ptr");
+    std::vector<int> rdeg(m), cdeg(n, 0);
+    for (int i = 0; i < m; ++i) {
+        rdeg[i] = row_ptr[i + 1] - row_ptr[i];
+        if (rdeg[i] < 0) return fail(QD_EINVAL, "row_ptr not monotone");
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+            if (col_idx[e] < 0 || col_idx[e] >= n) return fail(QD_EINVAL, "column index out of range");
+            if (e > row_ptr[i] && col_idx[e] <= col_idx[e - 1]) return fail(QD_EINVAL, "columns must ascend in a row");
+            cdeg[col_idx[e]]++;
+        }
+    }
+    for (int j = 0; j < n; ++j)
+        if (!(priors[j] > 0.0 && priors[j] < 1.0)) return fail(QD_EINVAL, "prior %d = %g outside (0,1)", j, priors[j]);
+    const int max_rdeg = *std::max_element(rdeg.begin(), rdeg.end());
+    const int max_cdeg = *std::max_element(cdeg.begin(), cdeg.end());
+    if (max_rdeg > QD_MAX_ROW_DEG || max_rdeg < 1)
+        return fail(QD_ECAPACITY, "row weight %d outside 1..%d", max_rdeg, QD_MAX_ROW_DEG);
+    if (max_cdeg > QD_MAX_COL_DEG || max_cdeg < 1)
+        return fail(QD_ECAPACITY, "column weight %d outside 1..%d", max_cdeg, QD_MAX_COL_DEG);
+
+    qd_graph *g = new qd_graph();
+    g->device = device; g->m = m; g->n = n; g->nnz = nnz; g->max_rdeg = max_rdeg; g->max_cdeg = max_cdeg;
+    if (hipSetDevice(device) != hipSuccess) { delete g; return fail(QD_EHIP, "hipSetDevice(%d) failed", device); }
+
+    // slots: degree-descending, stable
+    std::vector<int> chk_slot_of(m), chk_orig(m), bit_slot_of(n), bit_orig(n);
+    std::iota(chk_orig.begin(), chk_orig.end(), 0);
+    std::stable_sort(chk_orig.begin(), chk_orig.end(), [&](int a, int b) { return rdeg[a] > rdeg[b]; });
+    for (int s = 0; s < m; ++s) chk_slot_of[chk_orig[s]] = s;
+    std::iota(bit_orig.begin(), bit_orig.end(), 0);
+    std::stable_sort(bit_orig.begin(), bit_orig.end(), [&](int a, int b) { return cdeg[a] > cdeg[b]; });
+    for (int s = 0; s < n; ++s) bit_slot_of[bit_orig[s]] = s;
+
+    const int m_pad = pad64(m), n_pad = pad64(n);
+    std::vector<uint16_t> chk_adj((size_t)max_rdeg * m_pad, 0);
+    std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0);
+    std::vector<uint32_t> chk_orig_u(m_pad, 0), bit_orig_u(n_pad, 0), bit_adj((size_t)max_cdeg * n_pad, 0);
+    std::vector<float> llr0(n_pad, 1.0f);
+    // CSC with the edge's position inside its row
+    std::vector<int32_t> cp(n + 1, 0), ri(nnz), pos(nnz);
+    for (int j = 0; j < n; ++j) cp[j + 1] = cp[j] + cdeg[j];
+    {
+        std::vector<int> fill(n, 0);
+        for (int i = 0; i < m; ++i)
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+                const int j = col_idx[e], dst = cp[j] + fill[j]++;
+                ri[dst] = i; pos[dst] = e - row_ptr[i];
+            }
+    }
+    for (int s = 0; s < m; ++s) {
+        const int i = chk_orig[s];
+        chk_deg[s] = (uint8_t)rdeg[i];
+        chk_orig_u[s] = (uint32_t)i;
+        for (int k = 0; k < rdeg[i]; ++k) chk_adj[(size_t)k * m_pad + s] = (uint16_t)bit_slot_of[col_idx[row_ptr[i] + k]];
+    }
+    for (int s = 0; s < n; ++s) {
+        const int j = bit_orig[s];
+        bit_deg[s] = (uint8_t)cdeg[j];
+        bit_orig_u[s] = (uint32_t)j;
+        llr0[s] = (float)std::log((1.0 - priors[j]) / priors[j]);
+        for (int q = 0; q < cdeg[j]; ++q)
+            bit_adj[(size_t)q * n_pad + s] = (uint32_t)chk_slot_of[ri[cp[j] + q]] | ((uint32_t)pos[cp[j] + q] << 16);
+    }
+    g->h_cp = cp; g->h_ri = ri;
+
+    BpGraphDev &bp = g->bp;
+    bp.m = m; bp.n = n; bp.m_pad = m_pad; bp.n_pad = n_pad; bp.max_rdeg = max_rdeg; bp.max_cdeg = max_cdeg;
+    bp.neg_words = (max_rdeg + 31) / 32; bp.out_words = (n + 31) / 32;
+    int rc = 0;
+    rc |= g->mem.upload(chk_adj, &bp.chk_adj);
+    rc |= g->mem.upload(chk_deg, &bp.chk_deg);
+    rc |= g->mem.upload(chk_orig_u, &bp.chk_orig);
+    rc |= g->mem.upload(bit_adj, &bp.bit_adj);
+    rc |= g->mem.upload(bit_deg, &bp.bit_deg);
+    rc |= g->mem.upload(llr0, &bp.bit_llr0);
+    rc |= g->mem.upload(bit_orig_u, &bp.bit_orig);
+    // LDS carve-up for BP
+    int off = 0;
+    bp.off_chk = off; off += m_pad * 16;
+    bp.off_cneg = off; off += align16((bp.neg_words - 1) * m_pad * 4);
+    bp.off_llr = off; off += align16(n_pad * 4);
+    bp.off_bneg = off; off += align16(n_pad * 2);
+    bp.off_out = off; off += align16(bp.out_words * 4);
+    bp.off_misc = off; off += 256;
+    bp.lds_bytes = off;
+    const int need = std::max(m, (n + 9) / 10);
+    bp.threads = need <= 256 ? 256 : (need <= 512 ? 512 : 1024);
+
+    // OSD view
+    OsdGraphDev &od = g->osd;
+    od.m = m; od.n = n; od.m_pad = m_pad; od.max_cdeg = max_cdeg; od.mw = (m + 63) / 64;
+    int np2 = 64;
+    while (np2 < n) np2 <<= 1;
+    od.npow2 = np2;
+    std::vector<uint32_t> csc_ptr(cp.begin(), cp.end());
+    std::vector<uint16_t> csc_row(ri.begin(), ri.end());
+    rc |= g->mem.upload(csc_ptr, &od.csc_ptr);
+    rc |= g->mem.upload(csc_row, &od.csc_row);
+    if (rc) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation/upload failed"); }
+    const int small = align16(m_pad * 8) /*tb*/ + align16(m_pad) /*sp*/ + align16(m_pad * 2) * 2 /*rowpiv,prow*/ +
+                      align16(m_pad * 4) /*pcol*/ + align16(64 * max_cdeg * 4) /*pairs*/ + 256 /*cols*/ + 512 /*red*/ +
+                      align16(bp.out_words * 4);
+    const int q_budget = QD_LDS_BYTES - small - 64;
+    const int sort_bytes = np2 * 8;
+    if (sort_bytes > q_budget) {
+        // BP still runs; OSD needs the sort buffer in LDS
+        od.lds_bytes = 0; od.kw_lds = 0; od.threads = 0;
+    } else {
+        od.kw_lds = std::min(od.mw, q_budget / (m_pad * 8));
+        const int qbytes = std::max(sort_bytes, od.kw_lds * m_pad * 8);
+        off = 0;
+        od.off_q = off; off += align16(qbytes);
+        od.off_tb = off; off += align16(m_pad * 8);
+        od.off_sp = off; off += align16(m_pad);
+        od.off_rowpiv = off; off += align16(m_pad * 2);
+        od.off_prow = off; off += align16(m_pad * 2);
+        od.off_pcol = off; off += align16(m_pad * 4);
+        od.off_pairs = off; off += align16(64 * max_cdeg * 4);
+        od.off_cols = off; off += 256;
+        od.off_red = off; off += 512;
+        od.off_out = off; off += align16(bp.out_words * 4);
+        od.lds_bytes = off;
+        od.threads = m <= 256 ? 256 : (m <= 512 ? 512 : 1024);
+    }
+    if (bp.lds_bytes > QD_LDS_BYTES) {
+        g->mem.release();
+        const int need_lds = bp.lds_bytes;
+        delete g;
+        return fail(QD_ECAPACITY, "window needs %d bytes of LDS for BP state; the CU has %d", need_lds, QD_LDS_BYTES);
+    }
+    *out = g;
+    return QD_OK;
+}
+
+extern "C" void qd_graph_destroy(qd_graph *g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    g->mem.release();
+    delete g;
+}
+
+static int host_rank(qd_graph *g)
+{
+    if (g->rank >= 0) return g->rank;
+    const int m = g->m, n = g->n, mw = (m + 63) / 64;
+    // column-incremental elimination on m-bit columns
+    std::vector<std::vector<uint64_t>> basis;   // reduced columns with distinct leading rows
+    std::vector<int> lead_of(m, -1);
+    int rank = 0;
+    std::vector<uint64_t> v(mw);
+    for (int j = 0; j < n && rank < m; ++j) {
+        std::fill(v.begin(), v.end(), 0ull);
+        for (int e = g->h_cp[j]; e < g->h_cp[j + 1]; ++e) v[g->h_ri[e] >> 6] ^= 1ull << (g->h_ri[e] & 63);
+        for (;;) {
+            int lead = -1;
+            for (int w = 0; w < mw; ++w)
+                if (v[w]) { lead = w * 64 + __builtin_ctzll(v[w]); break; }
+            if (lead < 0) break;
+            if (lead_of[lead] < 0) { lead_of[lead] = (int)basis.size(); basis.push_back(v); ++rank; break; }
+            const std::vector<uint64_t> &b = basis[lead_of[lead]];
+            for (int w = 0; w < mw; ++w) v[w] ^= b[w];
+        }
+    }
+    g->rank = rank;
+    return rank;
+}
+
+extern "C" int qd_graph_info(const qd_graph *g, int32_t *info)
+{
+    if (!g || !info) return fail(QD_EINVAL, "null argument");
+    info[0] = g->m; info[1] = g->n; info[2] = g->nnz; info[3] = g->max_rdeg; info[4] = g->max_cdeg;
+    info[5] = g->bp.threads; info[6] = g->bp.lds_bytes; info[7] = g->osd.threads; info[8] = g->osd.lds_bytes;
+    info[9] = host_rank(const_cast<qd_graph *>(g));
+    return QD_OK;
+}
+
+extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decoder **out)
+{
+    if (!g || !p || !out) return fail(QD_EINVAL, "null argument");
+    *out = nullptr;
+    if (p->bp_method != QD_BP_MINIMUM_SUM)
+        return fail(QD_EUNSUPPORTED, "bp_method: only 'minimum_sum' runs on the device path (got %d); product_sum is not implemented", p->bp_method);
+    if (p->schedule != QD_SCHEDULE_PARALLEL)
+        return fail(QD_EUNSUPPORTED, "schedule: only 'parallel' (flooding) runs on the device path; 'serial' is sequential over bits");
+    const bool osd0 = p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
+    if (p->osd_method != QD_OSD_OFF && !osd0)
+        return fail(QD_EUNSUPPORTED, "osd_method %d with osd_order %d: only OSD-0 (osd_0, or osd_cs/osd_e with order 0) is implemented on the device path", p->osd_method, p->osd_order);
+    if (p->osd_method != QD_OSD_OFF && g->osd.lds_bytes == 0)
+        return fail(QD_ECAPACITY, "n = %d faults: the OSD column sort needs %d bytes of LDS", g->n, g->osd.npow2 * 8);
+    if (p->max_iter < 0 || p->ms_scaling_factor < 0) return fail(QD_EINVAL, "negative max_iter / ms_scaling_factor");
+    qd_decoder *d = new qd_decoder();
+    d->g = g; d->prm = *p;
+    if (d->prm.max_iter == 0) d->prm.max_iter = g->n;       // ldpc: max_iter = 0 -> number of bits
+    if (d->prm.max_iter > 0xFFFF) d->prm.max_iter = 0xFFFF;
+    *out = d;
+    return QD_OK;
+}
+
+static void free_ws(qd_decoder *d)
+{
+    if (d->llr_ws) (void)hipFree(d->llr_ws);
+    if (d->fail_list) (void)hipFree(d->fail_list);
+    if (d->fail_count) (void)hipFree(d->fail_count);
+    if (d->order_ws) (void)hipFree(d->order_ws);
+    if (d->q_spill) (void)hipFree(d->q_spill);
+    d->llr_ws = nullptr; d->fail_list = nullptr; d->fail_count = nullptr; d->order_ws = nullptr; d->q_spill = nullptr;
+    d->cap = 0;
+}
+
+extern "C" void qd_decoder_destroy(qd_decoder *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->g->device);
+    free_ws(d);
+    for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    delete d;
+}
+
+extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
+{
+    if (!d || max_batch <= 0) return fail(QD_EINVAL, "bad reserve request");
+    if (max_batch <= d->cap) return QD_OK;
+    HIP_TRY(hipSetDevice(d->g->device));
+    HIP_TRY(hipDeviceSynchronize());
+    free_ws(d);
+    const qd_graph *g = d->g;
+    const bool osd = d->prm.osd_method != QD_OSD_OFF;
+    HIP_TRY(hipMalloc((void **)&d->fail_count, 64));
+    HIP_TRY(hipMemset(d->fail_count, 0, 64));
+    if (osd) {
+        int ncu = 256;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
+        const int per_cu = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.lds_bytes));
+        d->osd_blocks = ncu * std::min(per_cu, 2048 / g->osd.threads);
+        HIP_TRY(hipMalloc((void **)&d->llr_ws, sizeof(float) * (size_t)max_batch * g->bp.n_pad));
+        HIP_TRY(hipMalloc((void **)&d->fail_list, sizeof(int32_t) * (size_t)max_batch));
+        HIP_TRY(hipMalloc((void **)&d->order_ws, sizeof(uint16_t) * (size_t)d->osd_blocks * g->n));
+        const int spill_planes = g->osd.mw - g->osd.kw_lds;
+        if (spill_planes > 0)
+            HIP_TRY(hipMalloc((void **)&d->q_spill, sizeof(uint64_t) * (size_t)d->osd_blocks * spill_planes * g->osd.m_pad));
+    }
+    d->cap = max_batch;
+    return QD_OK;
+}
+
+extern "C" int qd_decoder_set_profiling(qd_decoder *d, int32_t enable)
+{
+    if (!d) return fail(QD_EINVAL, "null decoder");
+    d->profiling = enable ? 1 : 0;
+    return QD_OK;
+}
+
+extern "C" int qd_decoder_profile(qd_decoder *d, double *out, int32_t reset)
+{
+    if (!d || !out) return fail(QD_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(d->g->device));
+    for (size_t i = 0; i + 2 < d->ev.size(); i += 3) {
+        HIP_TRY(hipEventSynchronize(d->ev[i + 2]));
+        float a = 0.f, b = 0.f;
+        HIP_TRY(hipEventElapsedTime(&a, d->ev[i], d->ev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, d->ev[i + 1], d->ev[i + 2]));
+        d->acc_ms[0] += a; d->acc_ms[1] += b; d->acc_ms[2] += 1; d->acc_ms[3] += (d->prm.osd_method != QD_OSD_OFF);
+    }
+    for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    d->ev.clear();
+    for (int i = 0; i < 4; ++i) out[i] = d->acc_ms[i];
+    if (reset) for (int i = 0; i < 4; ++i) d->acc_ms[i] = 0;
+    return QD_OK;
+}
+
+extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset,
+                               const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
+                               uint32_t *d_err_bits, int32_t *d_status, void *stream)
+{
+    if (!d || !d_det || !d_err_bits || !d_status) return fail(QD_EINVAL, "null argument");
+    if (B < 0 || B > 0x7FFFFFFF) return fail(QD_EINVAL, "batch size out of range");
+    if (B == 0) return QD_OK;
+    if (det_offset < 0 || det_stride < det_offset + d->g->m) return fail(QD_EINVAL, "detector slice [%lld, %lld) exceeds the row stride %lld", (long long)det_offset, (long long)(det_offset + d->g->m), (long long)det_stride);
+    if (d_upd && (upd_rows < 0 || upd_rows > d->g->m || upd_stride < upd_rows)) return fail(QD_EINVAL, "bad syndrome-update shape");
+    HIP_TRY(hipSetDevice(d->g->device));
+    if (B > d->cap) {
+        int rc = qd_decoder_reserve(d, B);
+        if (rc) return rc;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool osd = d->prm.osd_method != QD_OSD_OFF;
+    DecodeArgs a{};
+    a.det = d_det; a.det_stride = det_stride; a.det_offset = det_offset;
+    a.upd = d_upd; a.upd_stride = upd_stride; a.upd_rows = d_upd ? upd_rows : 0;
+    a.max_iter = d->prm.max_iter; a.ms_scale = (float)d->prm.ms_scaling_factor; a.want_llr = osd ? 1 : 0;
+    a.err_bits = d_err_bits; a.status = d_status;
+    a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
+    a.order_ws = d->order_ws; a.q_spill = d->q_spill;
+    HIP_TRY(hipMemsetAsync(d->fail_count, 0, sizeof(int32_t), s));
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (d->profiling) {
+        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
+        d->ev.push_back(e0); d->ev.push_back(e1); d->ev.push_back(e2);
+        HIP_TRY(hipEventRecord(e0, s));
+    }
+    HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
+    if (d->profiling) HIP_TRY(hipEventRecord(e1, s));
+    if (osd) HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, std::min<int64_t>(B, d->osd_blocks), s));
+    if (d->profiling) HIP_TRY(hipEventRecord(e2, s));
+    return QD_OK;
+}
+
+extern "C" int qd_decoder_failed_llr(qd_decoder *d, int64_t b, float *d_out, void *stream)
+{
+    if (!d || !d_out || !d->llr_ws) return fail(QD_EINVAL, "no posterior workspace (OSD off or nothing decoded yet)");
+    HIP_TRY(hipSetDevice(d->g->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(hipStreamSynchronize(s));
+    int32_t nfail = 0;
+    HIP_TRY(hipMemcpy(&nfail, d->fail_count, sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> list((size_t)std::max(nfail, 1));
+    if (nfail > 0) HIP_TRY(hipMemcpy(list.data(), d->fail_list, sizeof(int32_t) * (size_t)nfail, hipMemcpyDeviceToHost));
+    for (int i = 0; i < nfail; ++i)
+        if (list[i] == (int32_t)b) {
+            // workspace rows are in bit-slot order; hand back fault order
+            const qd_graph *g = d->g;
+            std::vector<float> slot(g->bp.n_pad), outv(g->n);
+            std::vector<uint32_t> orig(g->bp.n_pad);
+            HIP_TRY(hipMemcpy(slot.data(), d->llr_ws + (size_t)i * g->bp.n_pad, sizeof(float) * g->bp.n_pad, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(orig.data(), g->bp.bit_orig, sizeof(uint32_t) * g->bp.n_pad, hipMemcpyDeviceToHost));
+            for (int sidx = 0; sidx < g->n; ++sidx) outv[orig[sidx]] = slot[sidx];
+            HIP_TRY(hipMemcpy(d_out, outv.data(), sizeof(float) * g->n, hipMemcpyHostToDevice));
+            return QD_OK;
+        }
+    return fail(QD_EINVAL, "shot %lld converged (no stored posterior)", (long long)b);
+}
+
+extern "C" int qd_spmat_create(int32_t nrows, int32_t ncols, const int32_t *row_ptr, const int32_t *col_idx,
+                               int32_t device, qd_spmat **out)
+{
+    if (!out) return fail(QD_EINVAL, "out is null");
+    *out = nullptr;
+    if (nrows < 0 || ncols < 0 || !row_ptr) return fail(QD_EINVAL, "bad shape");
+    const int nnz = row_ptr[nrows];
+    if (nnz > 0 && !col_idx) return fail(QD_EINVAL, "null col_idx");
+    for (int e = 0; e < nnz; ++e)
+        if (col_idx[e] < 0 || col_idx[e] >= ncols) return fail(QD_EINVAL, "column index out of range");
+    if (hipSetDevice(device) != hipSuccess) return fail(QD_EHIP, "hipSetDevice(%d) failed", device);
+    qd_spmat *s = new qd_spmat();
+    s->device = device;
+    std::vector<uint32_t> rp(row_ptr, row_ptr + nrows + 1), ci(col_idx, col_idx + nnz);
+    int rc = s->mem.upload(rp, &s->d.row_ptr) | s->mem.upload(ci, &s->d.col_idx);
+    if (rc) { s->mem.release(); delete s; return fail(QD_EHIP, "device allocation/upload failed"); }
+    s->d.nrows = nrows; s->d.ncols = ncols; s->d.nnz = nnz;
+    *out = s;
+    return QD_OK;
+}
+
+extern "C" void qd_spmat_destroy(qd_spmat *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    s->mem.release();
+    delete s;
+}
+
+extern "C" int qd_gf2_spmv_batch(const qd_spmat *A, const uint32_t *d_err_bits, int64_t err_stride_words, int64_t B,
+                                 uint8_t *d_out, int64_t out_stride, int32_t accumulate, void *stream)
+{
+    if (!A || !d_err_bits || !d_out) return fail(QD_EINVAL, "null argument");
+    if (err_stride_words * 32 < A->d.ncols) return fail(QD_EINVAL, "error rows hold %lld bits, matrix has %d columns", (long long)err_stride_words * 32, A->d.ncols);
+    if (out_stride < A->d.nrows) return fail(QD_EINVAL, "out_stride smaller than the row count");
+    HIP_TRY(hipSetDevice(A->device));
+    HIP_TRY(qd_launch_spmv(A->d, d_err_bits, err_stride_words, B, d_out, out_stride, accumulate, reinterpret_cast<hipStream_t>(stream)));
+    return QD_OK;
+}
+
+extern "C" int qd_unpack_bits(const uint32_t *d_bits, int64_t stride_words, int32_t nbits, int64_t B, uint8_t *d_out,
+                              int64_t out_stride, void *stream)
+{
+    if (!d_bits || !d_out || nbits < 0 || stride_words * 32 < nbits || out_stride < nbits) return fail(QD_EINVAL, "bad unpack arguments");
+    HIP_TRY(qd_launch_unpack(d_bits, stride_words, nbits, B, d_out, out_stride, reinterpret_cast<hipStream_t>(stream)));
+    return QD_OK;
+}
+
+extern "C" int qd_count_mismatch(const uint8_t *d_pred, const uint8_t *d_obs, int32_t k, int64_t B, int64_t *d_count,
+                                 void *stream)
+{
+    if (!d_pred || !d_obs || !d_count || k <= 0) return fail(QD_EINVAL, "bad count arguments");
+    HIP_TRY(qd_launch_count(d_pred, d_obs, k, B, d_count, reinterpret_cast<hipStream_t>(stream)));
+    return QD_OK;
+}
+
+extern "C" int qd_sample_dem(const qd_spmat *Ht, const qd_spmat *Lt, const double *priors, uint64_t seed, int64_t shot0,
+                             int64_t B, uint8_t *d_det, int64_t det_stride, uint8_t *d_obs, int64_t obs_stride,
+                             void *stream)
+{
+    if (!Ht || !Lt || !priors || !d_det || !d_obs) return fail(QD_EINVAL, "null argument");
+    if (Ht->d.nrows != Lt->d.nrows) return fail(QD_EINVAL, "Ht and Lt must both have one row per fault");
+    const int n = Ht->d.nrows, m = Ht->d.ncols, nobs = Lt->d.ncols;
+    if (det_stride < m || obs_stride < nobs) return fail(QD_EINVAL, "output strides too small");
+    if (((m + 31) / 32 + (nobs + 31) / 32) * 4 > 64 * 1024) return fail(QD_ECAPACITY, "too many detectors for the sampler's LDS bit array");
+    HIP_TRY(hipSetDevice(Ht->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    std::vector<uint32_t> thr((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        double t = std::floor(priors[j] * 4294967296.0);
+        thr[j] = (uint32_t)std::min(std::max(t, 0.0), 4294967295.0);
+    }
+    uint32_t *d_thr = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_thr, sizeof(uint32_t) * (size_t)std::max(n, 4)));
+    hipError_t e = hipMemcpy(d_thr, thr.data(), sizeof(uint32_t) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = qd_launch_sample(Ht->d, Lt->d, d_thr, seed, shot0, B, m, nobs, d_det, det_stride, d_obs, obs_stride, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_thr);
+    if (e != hipSuccess) return fail(QD_EHIP, "sampler: %s", hipGetErrorString(e));
+    return QD_OK;
+}

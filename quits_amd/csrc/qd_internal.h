@@ -1,0 +1,78 @@
+// qd_internal.h -- device-side views shared by the kernels and the C-ABI host code (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define QD_WAVE 64
+#define QD_MAX_COL_DEG 16      // bit-side sign copy is a uint16 per fault
+#define QD_MAX_ROW_DEG 255     // edge position inside a check is a byte
+#define QD_LDS_BYTES (160 * 1024)
+
+// One window's Tanner graph as the BP kernel wants it.
+//   check slots: checks sorted by degree (descending); bit slots: faults sorted by degree (descending), so that a
+//   wavefront's lanes run the same trip count.  Adjacency is stored ELL-transposed ([k][slot]) so that lane = slot
+//   reads are coalesced; indices refer to SLOTS, the LDS arrays are indexed by slot.
+struct BpGraphDev {
+    int m, n, m_pad, n_pad;
+    int max_rdeg, max_cdeg, neg_words, out_words;
+    const uint16_t *chk_adj;    // [max_rdeg][m_pad]   bit slot of the k-th fault of the check (k ascending = original column order)
+    const uint8_t *chk_deg;     // [m_pad]
+    const uint32_t *chk_orig;   // [m_pad]             detector index of the check slot
+    const uint32_t *bit_adj;    // [max_cdeg][n_pad]   check slot | (edge position inside that check) << 16; q ascending = original row order
+    const uint8_t *bit_deg;     // [n_pad]
+    const float *bit_llr0;      // [n_pad]             log((1-p)/p), computed in double on the host, rounded once
+    const uint32_t *bit_orig;   // [n_pad]             fault index of the bit slot
+    // LDS carve-up (byte offsets, 16-byte aligned)
+    int off_chk, off_cneg, off_llr, off_bneg, off_out, off_misc, lds_bytes;   // off_misc: 64 ints of reduction scratch
+    int threads;
+};
+
+// Elimination (OSD) view: original indexing.
+struct OsdGraphDev {
+    int m, n, m_pad, max_cdeg;
+    int mw;                     // words per Q row = ceil(m / 64)
+    int npow2;                  // bitonic sort size
+    int kw_lds;                 // Q word-planes that live in LDS; planes >= kw_lds spill to global
+    const uint32_t *csc_ptr;    // [n + 1]
+    const uint16_t *csc_row;    // [nnz]  detector index, ascending inside a column
+    int off_q, off_tb, off_sp, off_rowpiv, off_prow, off_pcol, off_pairs, off_cols, off_red, off_out, lds_bytes;
+    int threads;
+};
+
+struct DecodeArgs {
+    const uint8_t *det;         // [B][det_stride] one byte per detector
+    int64_t det_stride, det_offset;
+    const uint8_t *upd;         // [B][upd_stride] or null
+    int64_t upd_stride;
+    int upd_rows;
+    int max_iter;
+    float ms_scale;             // 0 -> 1 - 2^-it
+    int want_llr;               // 1: non-converged shots publish their posteriors for OSD
+    uint32_t *err_bits;         // [B][out_words]
+    int32_t *status;            // [B]
+    // workspace
+    float *llr_ws;              // [cap][n_pad]  posterior by bit slot, one row per non-converged shot
+    int32_t *fail_list;         // [cap]
+    int32_t *fail_count;        // [1]
+    uint16_t *order_ws;         // [cap][n]      sorted column order (OSD)
+    uint64_t *q_spill;          // [cap][(mw - kw_lds)][m_pad]
+};
+
+// Workgroup-wide OR without static LDS (a static __shared__ object in front of the dynamic region can knock the
+// 16-byte alignment the ds_read_b128 gathers rely on).  `red` = 32 ints of dynamic LDS; `phase` alternates 0/1 between
+// successive calls so a fast wave cannot overwrite flags a slow wave still reads.  Contains one barrier.
+__device__ __forceinline__ int qd_block_or(int pred, volatile int *red, int nwaves, int phase)
+{
+    const unsigned long long bal = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) red[phase * 16 + (threadIdx.x >> 6)] = (bal != 0ull);
+    __syncthreads();
+    int r = 0;
+    for (int w = 0; w < nwaves; ++w) r |= red[phase * 16 + w];
+    return r;
+}
+
+struct SpmatDev {
+    int nrows, ncols, nnz;
+    const uint32_t *row_ptr;
+    const uint32_t *col_idx;
+};

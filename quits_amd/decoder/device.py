@@ -1,0 +1,205 @@
+"""Thin Python objects over the C ABI (include/quits_amd.h): device-resident window graphs, batch decoders and
+GF(2) matrices.  PyTorch is used for device memory and streams only."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from .. import _lib
+from .base import as_csr_int32
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _stream_ptr():
+    torch = _torch()
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class WindowGraph:
+    """Device copy of one window check matrix + priors (qd_graph).  Stands in for the sparse-matrix half of
+    `BpOsdDecoder(pcm, channel_probs=...)` (reference sliding_window.py:149)."""
+
+    def __init__(self, pcm, priors, device: Optional[int] = None):
+        L = _lib.require_gpu()
+        torch = _torch()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        rp, ci, (m, n) = as_csr_int32(pcm)
+        pri = np.ascontiguousarray(np.broadcast_to(np.asarray(priors, dtype=np.float64), (n,)))
+        self.m, self.n = int(m), int(n)
+        self.words = (self.n + 31) // 32
+        h = C.c_void_p()
+        _lib.check(L.qd_graph_create(self.m, self.n, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p),
+                                     pri.ctypes.data_as(C.c_void_p), self.device, C.byref(h)))
+        self._h = h
+        self._L = L
+        self.priors = pri
+
+    def info(self) -> dict:
+        arr = (C.c_int32 * 10)()
+        _lib.check(self._L.qd_graph_info(self._h, arr))
+        keys = ("m", "n", "nnz", "max_row_weight", "max_col_weight", "bp_threads", "bp_lds_bytes", "osd_threads",
+                "osd_lds_bytes", "rank")
+        return dict(zip(keys, [int(x) for x in arr]))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                self._L.qd_graph_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+
+class BatchDecoder:
+    """qd_decoder: BP(+OSD-0) over a batch of shots for one window."""
+
+    def __init__(self, graph: WindowGraph, bp_method="minimum_sum", schedule="parallel", max_iter=0,
+                 osd_method="osd_0", osd_order=0, ms_scaling_factor=1.0):
+        self.graph = graph
+        L = graph._L
+        try:
+            prm = _lib.QdParams(_lib.QD_BP[_norm(bp_method)], _lib.QD_SCHEDULE[_norm(schedule)], int(max_iter),
+                                _lib.QD_OSD[_norm(osd_method)], int(osd_order), 0, float(ms_scaling_factor))
+        except KeyError as exc:
+            raise ValueError("unknown decoder option %s" % exc) from exc
+        h = C.c_void_p()
+        rc = L.qd_decoder_create(graph._h, C.byref(prm), C.byref(h))
+        if rc == -2:
+            raise NotImplementedError(L.qd_last_error().decode())
+        _lib.check(rc)
+        self._h = h
+        self._L = L
+        self.params = prm
+
+    def reserve(self, max_batch: int):
+        _lib.check(self._L.qd_decoder_reserve(self._h, int(max_batch)))
+
+    def decode(self, det, det_offset: int = 0, upd=None, err_bits=None, status=None):
+        """det: cuda uint8 [B, stride]; upd: cuda uint8 [B, rows] or None.
+        Returns (err_bits int32 [B, words], status int32 [B])."""
+        torch = _torch()
+        assert det.is_cuda and det.dtype == torch.uint8 and det.dim() == 2 and det.stride(1) == 1
+        B = det.shape[0]
+        g = self.graph
+        if err_bits is None:
+            err_bits = torch.empty((B, g.words), dtype=torch.int32, device=det.device)
+        if status is None:
+            status = torch.empty((B,), dtype=torch.int32, device=det.device)
+        if upd is not None:
+            assert upd.is_cuda and upd.dtype == torch.uint8 and upd.dim() == 2 and upd.stride(1) == 1
+            up, us, ur = _ptr(upd), upd.stride(0), upd.shape[1]
+        else:
+            up, us, ur = C.c_void_p(0), 0, 0
+        _lib.check(self._L.qd_decode_batch(self._h, _ptr(det), det.stride(0), int(det_offset), up, us, ur, B,
+                                           _ptr(err_bits), _ptr(status), _stream_ptr()))
+        return err_bits, status
+
+    def failed_llr(self, b: int):
+        torch = _torch()
+        out = torch.empty((self.graph.n,), dtype=torch.float32, device="cuda")
+        _lib.check(self._L.qd_decoder_failed_llr(self._h, int(b), _ptr(out), _stream_ptr()))
+        return out
+
+    def set_profiling(self, on: bool):
+        _lib.check(self._L.qd_decoder_set_profiling(self._h, 1 if on else 0))
+
+    def profile(self, reset: bool = True) -> dict:
+        arr = (C.c_double * 4)()
+        _lib.check(self._L.qd_decoder_profile(self._h, arr, 1 if reset else 0))
+        return {"bp_ms": arr[0], "osd_ms": arr[1], "bp_launches": int(arr[2]), "osd_launches": int(arr[3])}
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                self._L.qd_decoder_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+
+class GF2Matrix:
+    """Sparse GF(2) matrix on the device (qd_spmat), CSR."""
+
+    def __init__(self, mat, device: Optional[int] = None):
+        L = _lib.require_gpu()
+        torch = _torch()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        rp, ci, (r, c) = as_csr_int32(mat)
+        self.shape = (int(r), int(c))
+        h = C.c_void_p()
+        _lib.check(L.qd_spmat_create(self.shape[0], self.shape[1], rp.ctypes.data_as(C.c_void_p),
+                                     ci.ctypes.data_as(C.c_void_p), self.device, C.byref(h)))
+        self._h = h
+        self._L = L
+
+    def xor_apply(self, err_bits, out, accumulate: bool):
+        """out[b, :nrows] (^)= A @ e_b mod 2, e_b = packed bits err_bits[b]."""
+        _lib.check(self._L.qd_gf2_spmv_batch(self._h, _ptr(err_bits), err_bits.stride(0), err_bits.shape[0], _ptr(out),
+                                             out.stride(0), 1 if accumulate else 0, _stream_ptr()))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            try:
+                self._L.qd_spmat_destroy(self._h)
+            except Exception:
+                pass
+            self._h = None
+
+
+def unpack_bits(bits, nbits: int):
+    torch = _torch()
+    L = _lib.load()
+    out = torch.empty((bits.shape[0], nbits), dtype=torch.uint8, device=bits.device)
+    _lib.check(L.qd_unpack_bits(_ptr(bits), bits.stride(0), int(nbits), bits.shape[0], _ptr(out), out.stride(0),
+                                _stream_ptr()))
+    return out
+
+
+def count_mismatch(pred, obs) -> "object":
+    """Device int64 scalar tensor: number of shots with pred != obs on any bit."""
+    torch = _torch()
+    L = _lib.load()
+    assert pred.shape == obs.shape and pred.dtype == torch.uint8 and obs.dtype == torch.uint8
+    pred = pred.contiguous()
+    obs = obs.contiguous()
+    cnt = torch.zeros((1,), dtype=torch.int64, device=pred.device)
+    _lib.check(L.qd_count_mismatch(_ptr(pred), _ptr(obs), pred.shape[1], pred.shape[0], _ptr(cnt), _stream_ptr()))
+    return cnt
+
+
+class DemSampler:
+    """Device-side detector-error-model sampler (stands in for stim's detector sampler, simulation.py:23-27)."""
+
+    def __init__(self, check_matrix, observable_matrix, priors, device: Optional[int] = None):
+        from scipy.sparse import csr_matrix
+        self.Ht = GF2Matrix(csr_matrix(check_matrix).T.tocsr(), device)
+        self.Lt = GF2Matrix(csr_matrix(observable_matrix).T.tocsr(), device)
+        self.m = self.Ht.shape[1]
+        self.nobs = self.Lt.shape[1]
+        self.priors = np.ascontiguousarray(priors, dtype=np.float64)
+        assert self.priors.shape[0] == self.Ht.shape[0]
+
+    def sample(self, shots: int, seed: int, shot0: int = 0):
+        torch = _torch()
+        det = torch.empty((shots, self.m), dtype=torch.uint8, device="cuda")
+        obs = torch.empty((shots, self.nobs), dtype=torch.uint8, device="cuda")
+        L = self.Ht._L
+        _lib.check(L.qd_sample_dem(self.Ht._h, self.Lt._h, self.priors.ctypes.data_as(C.c_void_p),
+                                   C.c_uint64(int(seed) & (2 ** 64 - 1)), int(shot0), int(shots), _ptr(det),
+                                   det.stride(0), _ptr(obs), obs.stride(0), _stream_ptr()))
+        return det, obs
+
+
+def _norm(x):
+    return x.lower() if isinstance(x, str) else x

@@ -1,0 +1,62 @@
+"""Fixture loaders shared by the tests (data only; nothing here touches /root/reference)."""
+import gzip
+import json
+import os
+
+import numpy as np
+from scipy.sparse import csc_matrix
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def circuit_text(name):
+    with gzip.open(os.path.join(GOLD, "circuits", name + ".stim.gz"), "rb") as f:
+        return f.read().decode()
+
+
+def circuit_index():
+    return json.load(open(os.path.join(GOLD, "circuits", "index.json")))
+
+
+def code(name):
+    z = np.load(os.path.join(GOLD, "codes", name + ".npz"))
+    out = {}
+    for k in ("hz", "hx", "lz", "lx"):
+        shp = tuple(int(x) for x in z[k + "_shape"])
+        out[k] = np.unpackbits(z[k + "_bits"])[: shp[0] * shp[1]].reshape(shp)
+    return out
+
+
+def csc_from(z, prefix):
+    idx = z[prefix + "_indices"]
+    return csc_matrix((np.ones(len(idx), np.uint8), idx, z[prefix + "_indptr"]),
+                      shape=tuple(int(x) for x in z[prefix + "_shape"]))
+
+
+def windows_npz(name):
+    return np.load(os.path.join(GOLD, "windows", name + ".npz"))
+
+
+def dem_matrices(name):
+    z = windows_npz(name)
+    return csc_from(z, "H"), csc_from(z, "L"), z["priors"]
+
+
+def window_set(name, W, F):
+    """The reference's spacetime() output for (W, F) as a list of dicts, in the oracle's window format."""
+    z = windows_npz(name)
+    tag = "W%dF%d" % (W, F)
+    nwin = int(z[tag + "_nwin"][0])
+    hz_rows = None
+    out = []
+    for k in range(nwin):
+        out.append({"H": csc_from(z, "%s_H%d" % (tag, k)), "L": csc_from(z, "%s_L%d" % (tag, k)),
+                    "priors": z["%s_p%d" % (tag, k)],
+                    "U": csc_from(z, "%s_U%d" % (tag, k)) if k < nwin - 1 else None})
+    return out
+
+
+def same_sparse(a, b):
+    a = csc_matrix(a); a.sort_indices()
+    b = csc_matrix(b); b.sort_indices()
+    return a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)

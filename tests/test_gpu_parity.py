@@ -1,0 +1,195 @@
+"""GPU parity: libquits_amd.so (through the C ABI) against the CPU oracle on identical inputs.
+
+Bar: bit-exact.  The oracle's float form (oracle/bp_core.inc bp_minsum_compressed, REAL=float) performs the HIP
+kernel's operations in the same order, and OSD is integer work."""
+import numpy as np
+import pytest
+
+import helpers
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(max_iter, osd="osd_0", alpha=1.0, form=orc.FORM_COMPRESSED_F32):
+    return orc.make_params("minimum_sum", "parallel", max_iter, osd, 0, alpha, form)
+
+
+def _gpu_decode(H, pri, synd, max_iter, osd="osd_0", alpha=1.0):
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    g = WindowGraph(H, pri)
+    d = BatchDecoder(g, max_iter=max_iter, osd_method=osd, ms_scaling_factor=alpha)
+    det = torch.from_numpy(np.ascontiguousarray(synd)).cuda()
+    bits, status = d.decode(det)
+    err = unpack_bits(bits, g.n).cpu().numpy()
+    return err, status.cpu().numpy(), d
+
+
+@pytest.mark.parametrize("name,shots", [("bb72_custom_r6_p0.003", 1500), ("hgp225_cardinal_r3_p0.01", 300)])
+def test_sampler_matches_oracle(gpu, name, shots):
+    from quits_amd.decoder.device import DemSampler
+    H, L, pri = helpers.dem_matrices(name)
+    det, obs = DemSampler(H, L, pri).sample(shots, seed=1234567, shot0=77)
+    s_ref, o_ref, _ = orc.sample_dem(H, L, pri, seed=1234567, shot0=77, B=shots)
+    assert np.array_equal(det.cpu().numpy(), s_ref)
+    assert np.array_equal(obs.cpu().numpy(), o_ref)
+
+
+@pytest.mark.parametrize("name,shots,max_iter,alpha", [
+    ("bb72_custom_r6_p0.003", 1200, 30, 1.0),
+    ("bb72_custom_r6_p0.003", 400, 25, 0.0),
+    ("bb72_custom_r6_p0.003", 400, 25, 0.8125),
+    ("hgp225_cardinal_r3_p0.01", 200, 20, 1.0),
+    ("bb144_custom_r12_p0.003", 300, 50, 1.0),
+])
+def test_bp_bit_exact(gpu, name, shots, max_iter, alpha):
+    H, L, pri = helpers.dem_matrices(name)
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=5, shot0=0, B=shots)
+    synd[0] = 0                                         # all-zero syndrome short-circuit
+    err, status, _ = _gpu_decode(H, pri, synd, max_iter, osd="osd_off", alpha=alpha)
+    g = orc.Graph(H, pri)
+    prm = _params(max_iter, "osd_off", alpha)
+    ref, flags = g.decode_batch(synd, prm)
+    conv = (status >> 16) & 1
+    assert np.array_equal(conv, flags[:, 0]), "convergence flags differ"
+    assert np.array_equal(status & 0xFFFF, flags[:, 1]), "iteration counts differ"
+    assert np.array_equal(err, ref), "hard decisions differ"
+    assert status[0] & (1 << 19) and not err[0].any()
+    assert 0 < conv.mean() < 1 or shots < 50
+
+
+@pytest.mark.parametrize("name,shots,max_iter", [
+    ("bb72_custom_r6_p0.003", 1200, 20),
+    ("hgp225_cardinal_r3_p0.01", 200, 10),
+    ("bb144_custom_r12_p0.003", 400, 30),
+])
+def test_bposd_bit_exact(gpu, name, shots, max_iter):
+    H, L, pri = helpers.dem_matrices(name)
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=11, shot0=0, B=shots)
+    err, status, dec = _gpu_decode(H, pri, synd, max_iter, osd="osd_0")
+    g = orc.Graph(H, pri)
+    ref, flags = g.decode_batch(synd, _params(max_iter, "osd_0"))
+    used_osd = (status >> 17) & 1
+    assert np.array_equal(used_osd, 1 - flags[:, 0])
+    assert used_osd.sum() > 10, "test does not exercise OSD"
+    assert np.array_equal((status >> 20) & 0xFFF, np.minimum(flags[:, 2], 4095)), "pivot counts differ"
+    bad = np.flatnonzero((err != ref).any(axis=1))
+    assert bad.size == 0, "OSD output differs on shots %s" % bad[:10]
+    # every output reproduces its syndrome (DEM-sampled syndromes are in the column space)
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+    # posterior hand-off: the LLRs OSD saw are the oracle's BP posteriors, bit for bit
+    b = int(np.flatnonzero(used_osd)[0])
+    llr = dec.failed_llr(b).cpu().numpy()
+    _, _, llr_ref, _ = g.bp(synd[b], _params(max_iter, "osd_0"))
+    assert np.array_equal(llr, llr_ref.astype(np.float32))
+
+
+def test_osd_inconsistent_and_rank_deficient(gpu):
+    """Syndromes outside the column space: defined by the oracle (lowest-index pivot row), flagged in status."""
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")   # rank 1002 of 1008
+    rng = np.random.default_rng(3)
+    synd = (rng.random((64, H.shape[0])) < 0.15).astype(np.uint8)
+    err, status, _ = _gpu_decode(H, pri, synd, 8, osd="osd_0")
+    g = orc.Graph(H, pri)
+    ref, flags = g.decode_batch(synd, _params(8, "osd_0"))
+    assert np.array_equal(err, ref)
+    assert np.array_equal((status >> 18) & 1, flags[:, 3])
+    assert flags[:, 3].sum() > 0
+
+
+@pytest.mark.parametrize("name,code,cases", [
+    ("bb72_custom_r6_p0.003", "bb72", ((3, 1, 20), (5, 3, 12), (8, 1, 30), (9, 2, 30))),
+    ("hgp225_cardinal_r3_p0.01", "hgp225", ((3, 1, 15), (2, 1, 15))),
+])
+def test_sliding_window_matches_reference_loop(gpu, name, code, cases):
+    """The batched device driver against the REFERENCE's own per-shot loop (golden G5: reference
+    sliding_window_circuit_mem driven with the oracle decoder as plug-in)."""
+    import warnings
+    from quits_amd.decoder import sliding_window_bposd_circuit_mem
+    from quits_amd.dem import Circuit
+    z = np.load(helpers.GOLD + "/loop/%s.npz" % name)
+    shp = tuple(z["shape"])
+    synd = np.unpackbits(z["syndromes"], axis=1)[:, :shp[1]]
+    cd = helpers.code(code)
+    circ = Circuit(helpers.circuit_text(name))
+    for (W, F, mi) in cases:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            pred = sliding_window_bposd_circuit_mem(synd, circ, cd["hz"], cd["lz"], W, F, max_iter=mi, osd_order=0,
+                                                    bp_method="minimum_sum", schedule="parallel", osd_method="osd_0")
+        assert pred.dtype == np.int64 and pred.shape == (shp[0], cd["lz"].shape[0])
+        assert np.array_equal(pred, z["circ_W%dF%d_it%d_f32c" % (W, F, mi)]), (W, F, mi)
+
+
+@pytest.mark.parametrize("name,code,cases", [
+    ("bb72_custom_r6_p0.003", "bb72", ((3, 1, 20), (5, 3, 12))),
+    ("hgp225_cardinal_r3_p0.01", "hgp225", ((3, 1, 15), (2, 1, 15))),
+])
+def test_phenom_sliding_window_matches_reference_loop(gpu, name, code, cases):
+    from quits_amd.decoder import sliding_window_bposd_phenom_mem
+    z = np.load(helpers.GOLD + "/loop/%s.npz" % name)
+    shp = tuple(z["shape"])
+    synd = np.unpackbits(z["syndromes"], axis=1)[:, :shp[1]]
+    cd = helpers.code(code)
+    for (W, F, mi) in cases:
+        pred = sliding_window_bposd_phenom_mem(synd, cd["hz"], cd["lz"], W, F, eff_error_rate_per_fault=0.03,
+                                               max_iter=mi, osd_order=0, bp_method="minimum_sum",
+                                               schedule="parallel", osd_method="osd_0")
+        assert np.array_equal(pred, z["phen_W%dF%d_it%d_f32c" % (W, F, mi)]), (W, F, mi)
+
+
+def test_plugin_class_in_host_loop(gpu):
+    """B1: the HIP decoder as a per-shot plug-in object (ldpc's constructor/decode surface)."""
+    from quits_amd.decoder import BpOsdDecoder
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=21, shot0=0, B=24)
+    dec = BpOsdDecoder(H, channel_probs=pri, max_iter=15, bp_method="minimum_sum", schedule="parallel",
+                       osd_method="osd_0", osd_order=0)
+    g = orc.Graph(H, pri)
+    ref, flags = g.decode_batch(synd, _params(15, "osd_0"))
+    for i in range(synd.shape[0]):
+        e = dec.decode(synd[i].astype(int))
+        assert e.dtype == np.int64 or e.dtype == int
+        assert np.array_equal(e, ref[i])
+        assert dec.converge == bool(flags[i, 0])
+
+
+def test_unsupported_options_fail_loudly(gpu):
+    from quits_amd.decoder import BpOsdDecoder
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    for kw in (dict(bp_method="product_sum"), dict(schedule="serial"), dict(osd_method="osd_cs", osd_order=2)):
+        with pytest.raises(NotImplementedError):
+            BpOsdDecoder(H, channel_probs=pri, max_iter=5, **{**dict(bp_method="minimum_sum", schedule="parallel",
+                                                               osd_method="osd_0", osd_order=0), **kw})
+
+
+def test_headline_scale_properties(gpu):
+    """BASELINE config 3 size ([[144,12,12]], 12 rounds, single window) at a batch the oracle cannot follow:
+    size-independent properties -- every output reproduces its syndrome, the zero syndrome maps to zero, decoding
+    is invariant under permuting the shots, and the LER agrees with the oracle's within Monte-Carlo error."""
+    import torch
+    from quits_amd.decoder.device import (BatchDecoder, DemSampler, GF2Matrix, WindowGraph, count_mismatch)
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    N = 20000
+    det, obs = DemSampler(H, L, pri).sample(N, seed=99)
+    g = WindowGraph(H, pri)
+    dec = BatchDecoder(g, max_iter=50, osd_method="osd_0")
+    bits, status = dec.decode(det)
+    Hm, Lm = GF2Matrix(H), GF2Matrix(L)
+    resyn = torch.empty((N, H.shape[0]), dtype=torch.uint8, device="cuda")
+    Hm.xor_apply(bits, resyn, accumulate=False)
+    assert torch.equal(resyn, det)
+    pred = torch.zeros((N, L.shape[0]), dtype=torch.uint8, device="cuda")
+    Lm.xor_apply(bits, pred, accumulate=True)
+    fails = int(count_mismatch(pred, obs).item())
+    perm = torch.randperm(N, device="cuda")
+    bits2, status2 = dec.decode(det[perm].contiguous())
+    assert torch.equal(bits2, bits[perm]) and torch.equal(status2 & 0xFFFFF, status[perm] & 0xFFFFF)
+    # oracle LER on the first 600 of the same shots
+    n_ref = 600
+    ref, _ = orc.Graph(H, pri).decode_batch(det[:n_ref].cpu().numpy(), _params(50, "osd_0"))
+    assert np.array_equal(ref, np.unpackbits(bits[:n_ref].cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :H.shape[1]])
+    p = fails / N
+    assert 0.01 < p < 0.12, p
