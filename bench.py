@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- decoded shots/s + logical error rate of the MI355X sliding-window BP-OSD decoder.
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): [[144,12,12]] bivariate-bicycle code,
+custom circuit, R = 12 (= d) noisy rounds, p = 0.003 on all four channels, Z basis -> detector error model
+1008 x 9504 (33192 edges); decoder = flooding min-sum BP (ms_scaling_factor 1.0 = ldpc's default, the reference
+wrapper does not expose it) with max_iter = 50, then OSD-0; one window over the whole history (BASELINE.json names
+no W/F).  `--window W F` switches to a sliding window.
+
+A step = one pass of the hot path (detector record on device -> logical predictions + mismatch count on device)
+over one batch of `--shots` DEM-sampled shots.  Inputs are generated on the device before the timed region.
+One process per GPU; shots are independent so ranks share nothing but the final (errors, shots) all-reduce.
+
+Prints ONE JSON line on rank 0 (contract in the task description), with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
+    ap.add_argument("--max-iter", type=int, default=50)
+    ap.add_argument("--p", type=float, default=0.003)
+    ap.add_argument("--window", type=int, nargs=2, default=None, metavar=("W", "F"))
+    ap.add_argument("--cpu-shots", type=int, default=2000, help="bounded CPU-baseline sample (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU; the decoder has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    import helpers
+    from quits_amd.decoder.base import detector_error_model_to_matrix
+    from quits_amd.decoder.device import DemSampler, count_mismatch
+    from quits_amd.decoder.sliding_window import build_circuit_plan
+    from quits_amd.dem import Circuit
+
+    R = 12
+    cname = "bb144_custom_r12_p%g" % args.p
+    circ = Circuit(helpers.circuit_text(cname))
+    code = helpers.code("bb144")
+    hz, lz = code["hz"], code["lz"]
+    H, Lobs, pri = detector_error_model_to_matrix(circ)
+    m, n = H.shape
+    E = int(H.nnz)
+    W, F = (R + 2, 1) if args.window is None else args.window
+    opts = dict(bp_method="minimum_sum", schedule="parallel", max_iter=args.max_iter, osd_method="osd_0", osd_order=0)
+    plan = build_circuit_plan(circ, hz, W, F, R, dict(opts), dict(opts))
+    decs = []
+    for w in plan.windows:
+        if w["dec"] not in decs:
+            decs.append(w["dec"])
+    for d in decs:
+        d.reserve(args.shots)
+        d.set_profiling(True)
+
+    # ---- synthetic inputs, resident in HBM before the timed region
+    sampler = DemSampler(H, Lobs, pri)
+    nbatch = args.steps + args.warmup
+    batches = []
+    for i in range(nbatch):
+        shot0 = (rank * nbatch + i) * args.shots
+        batches.append(sampler.sample(args.shots, seed=1, shot0=shot0))
+    torch.cuda.synchronize()
+
+    def step(i, stats=None):
+        det, obs = batches[i]
+        pred = plan.decode(det, stats)
+        return count_mismatch(pred, obs), pred
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    for d in decs:
+        d.profile(reset=True)
+
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fails = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    stats = []
+    for i in range(args.warmup, nbatch):
+        c, _ = step(i, stats)
+        fails += c
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    counts = torch.tensor([int(fails.item()), args.shots * args.steps], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)       # the path's only collective: 16 bytes over RCCL
+    elapsed = float(tmax.item())
+    n_err, n_shots = int(counts[0].item()), int(counts[1].item())
+
+    # ---- per-kernel device time (HIP events recorded by the library on the launch stream) and algorithmic bytes
+    prof = {"bp_ms": 0.0, "osd_ms": 0.0, "bp_launches": 0, "osd_launches": 0}
+    for d in decs:
+        pr = d.profile(reset=True)
+        for k in prof:
+            prof[k] += pr[k]
+    st = torch.cat(stats)
+    iters = (st & 0xFFFF).to(torch.int64)
+    total_iters = int(iters.sum().item())
+    conv_frac = float(((st >> 16) & 1).float().mean().item())
+    osd_frac = float(((st >> 17) & 1).float().mean().item())
+    # B_iter = (4E + 2n) * sizeof(msg) per shot per BP iteration, per window graph
+    b_iter = {}
+    for w in plan.windows:
+        info = w["graph"].info()
+        b_iter[id(w["dec"])] = (4 * info["nnz"] + 2 * info["n"]) * 4
+    algo_bytes = 0
+    # stats holds one status tensor per (chunk, window) in call order
+    idx = 0
+    for s_t in stats:
+        w = plan.windows[idx % len(plan.windows)]
+        algo_bytes += int((s_t & 0xFFFF).to(torch.int64).sum().item()) * b_iter[id(w["dec"])]
+        idx += 1
+    bp_s = prof["bp_ms"] / 1e3
+    achieved = (algo_bytes / bp_s / 1e9) if bp_s > 0 else 0.0
+
+    value = n_shots / elapsed
+    pl = n_err / n_shots
+    out = {
+        "metric": "decoded shots/sec + logical-error-rate, [[144,12,12]] BB code, d rounds, p=0.003",
+        "value": value, "unit": "shots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BB [[144,12,12]] custom circuit, R=12, p=%g, Z basis; DEM %dx%d (E=%d); "
+                               "min-sum flooding BP max_iter=%d ms_scaling=1.0 + OSD-0; W=%d F=%d (%d window%s)"
+                               % (args.p, m, n, E, args.max_iter, W, F, len(plan.windows), "" if len(plan.windows) == 1 else "s"),
+                   "shots_per_step_per_gpu": args.shots, "parallelism": "shots sharded over %d GPU(s), no data-path collective" % world},
+        "logical_error_rate": pl, "ler_sigma": float(np.sqrt(max(pl * (1 - pl), 1e-30) / n_shots)),
+        "lfr_per_round": 1.0 - (1.0 - pl) ** (1.0 / R),
+        "bp_converged_frac": conv_frac, "osd_frac": osd_frac, "mean_bp_iters": total_iters / max(1, st.numel()),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "qd_bp_minsum_kernel", "avg_launch_ms": prof["bp_ms"] / max(1, prof["bp_launches"]),
+                     "algorithmic_bytes_per_launch": algo_bytes / max(1, prof["bp_launches"]),
+                     "note": "algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the kernel "
+                             "keeps this message state in LDS, so the figure is the traffic an HBM-resident formulation "
+                             "would need, not bytes that cross HBM (see DESIGN.md section 5)",
+                     "osd_kernel_ms_per_launch": prof["osd_ms"] / max(1, prof["osd_launches"])},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as orc
+        ns = min(args.cpu_shots, args.shots)
+        det_h = batches[args.warmup][0][:ns].cpu().numpy()
+        obs_h = batches[args.warmup][1][:ns].cpu().numpy()
+        from quits_amd.decoder.base import spacetime, window_count
+        ncr, _, _ = window_count(R, W, F)
+        checks, commits, priors, updates = spacetime(circ, hz, W, F, ncr)
+        wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None,
+                 "row0": F * k * hz.shape[0]} for k in range(len(checks))]
+        prm = orc.make_params("minimum_sum", "parallel", args.max_iter, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)
+        t1 = time.perf_counter()
+        ref, cstat = orc.sliding_window_decode(wins, hz.shape[0], det_h, prm)
+        cpu_s = time.perf_counter() - t1
+        cpu_fail = int((ref != obs_h).any(axis=1).sum())
+        gpu_pred = plan.decode(batches[args.warmup][0][:ns]).cpu().numpy()
+        gpu_fail = int((gpu_pred != obs_h).any(axis=1).sum())
+        out["cpu_baseline"] = {
+            "value": ns / cpu_s, "unit": "shots/s", "cores": 1, "kind": "port",
+            "sample": "first %d shots of the first timed batch, same window plan and parameters; oracle/qd_oracle.c "
+                      "(double precision, ldpc's update order), one thread" % ns,
+            "ler": cpu_fail / ns, "gpu_ler_same_sample": gpu_fail / ns,
+            "shots_with_identical_prediction": float((ref == gpu_pred).all(axis=1).mean()),
+            "speedup_vs_cpu_core": value / (ns / cpu_s)}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
