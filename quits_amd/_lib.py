@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libquits_amd.so")
+LIB_PATH = os.environ.get("QUITS_AMD_LIB", os.path.join(_HERE, "lib", "libquits_amd.so"))
 
 QD_BP = {"product_sum": 0, "ps": 0, "prod_sum": 0, "minimum_sum": 1, "min_sum": 1, "ms": 1, 0: 0, 1: 1}
 QD_SCHEDULE = {"parallel": 0, "p": 0, "serial": 1, "s": 1, 0: 0, 1: 1}

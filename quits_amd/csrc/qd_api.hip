@@ -105,7 +105,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     *out = nullptr;
     if (m <= 0 || n <= 0 || !row_ptr || !col_idx || !priors) return fail(QD_EINVAL, "empty or null graph");
     if (m > 32767) return fail(QD_ECAPACITY, "m = %d detectors per window exceeds 32767", m);
-    if (n > 65535) return fail(QD_ECAPACITY, "n = %d faults per window exceeds 65535", n);
+    if (n > 65000) return fail(QD_ECAPACITY, "n = %d faults per window exceeds 65000", n);
     const int nnz = row_ptr[m];
     if (row_ptr[0] != 0 || nnz < 0) return fail(QD_EINVAL, "bad row_ptr");
     std::vector<int> rdeg(m), cdeg(n, 0);
@@ -141,9 +141,11 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     for (int s = 0; s < n; ++s) bit_slot_of[bit_orig[s]] = s;
 
     const int m_pad = pad64(m), n_pad = pad64(n);
-    std::vector<uint16_t> chk_adj((size_t)max_rdeg * m_pad, 0);
-    std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0);
-    std::vector<uint32_t> chk_orig_u(m_pad, 0), bit_orig_u(n_pad, 0), bit_adj((size_t)max_cdeg * n_pad, 0);
+    const int max_rdeg_pad = (max_rdeg + 3) & ~3;
+    const int dummy_bit = n_pad, dummy_chk = m_pad;        // one extra LDS slot each
+    std::vector<uint16_t> chk_adj((size_t)max_rdeg_pad * m_pad, (uint16_t)dummy_bit);
+    std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0), chk_degp(m_pad, 0), bit_degp(n_pad, 0);
+    std::vector<uint32_t> chk_orig_u(m_pad, 0), bit_orig_u(n_pad, 0), bit_adj((size_t)max_cdeg * n_pad, (uint32_t)dummy_chk << 16);
     std::vector<float> llr0(n_pad, 1.0f);
     // CSC with the edge's position inside its row
     std::vector<int32_t> cp(n + 1, 0), ri(nnz), pos(nnz);
@@ -168,16 +170,31 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         bit_orig_u[s] = (uint32_t)j;
         llr0[s] = (float)std::log((1.0 - priors[j]) / priors[j]);
         for (int q = 0; q < cdeg[j]; ++q)
-            bit_adj[(size_t)q * n_pad + s] = (uint32_t)chk_slot_of[ri[cp[j] + q]] | ((uint32_t)pos[cp[j] + q] << 16);
+            bit_adj[(size_t)q * n_pad + s] = ((uint32_t)chk_slot_of[ri[cp[j] + q]] << 16) | (uint32_t)pos[cp[j] + q];
+    }
+    // wave-uniform trip counts (slots are degree-sorted, so a wavefront's lanes nearly agree anyway)
+    for (int w0 = 0; w0 < m_pad; w0 += 64) {
+        int mx = 0;
+        for (int s = w0; s < w0 + 64; ++s) mx = std::max(mx, (int)chk_deg[s]);
+        mx = (mx + 3) & ~3;
+        for (int s = w0; s < w0 + 64; ++s) chk_degp[s] = (uint8_t)mx;
+    }
+    for (int w0 = 0; w0 < n_pad; w0 += 64) {
+        int mx = 0;
+        for (int s = w0; s < w0 + 64; ++s) mx = std::max(mx, (int)bit_deg[s]);
+        for (int s = w0; s < w0 + 64; ++s) bit_degp[s] = (uint8_t)mx;
     }
     g->h_cp = cp; g->h_ri = ri;
 
     BpGraphDev &bp = g->bp;
     bp.m = m; bp.n = n; bp.m_pad = m_pad; bp.n_pad = n_pad; bp.max_rdeg = max_rdeg; bp.max_cdeg = max_cdeg;
-    bp.neg_words = (max_rdeg + 31) / 32; bp.out_words = (n + 31) / 32;
+    bp.neg_words = (max_rdeg_pad + 31) / 32; bp.out_words = (n + 31) / 32;
+    bp.max_rdeg_pad = max_rdeg_pad; bp.dummy_bit = dummy_bit; bp.dummy_chk = dummy_chk;
     int rc = 0;
     rc |= g->mem.upload(chk_adj, &bp.chk_adj);
     rc |= g->mem.upload(chk_deg, &bp.chk_deg);
+    rc |= g->mem.upload(chk_degp, &bp.chk_degp);
+    rc |= g->mem.upload(bit_degp, &bp.bit_degp);
     rc |= g->mem.upload(chk_orig_u, &bp.chk_orig);
     rc |= g->mem.upload(bit_adj, &bp.bit_adj);
     rc |= g->mem.upload(bit_deg, &bp.bit_deg);
@@ -185,10 +202,10 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     rc |= g->mem.upload(bit_orig_u, &bp.bit_orig);
     // LDS carve-up for BP
     int off = 0;
-    bp.off_chk = off; off += m_pad * 16;
+    bp.off_chk = off; off += (m_pad + 4) * 16;                 // + the dummy check
     bp.off_cneg = off; off += align16((bp.neg_words - 1) * m_pad * 4);
-    bp.off_llr = off; off += align16(n_pad * 4);
-    bp.off_bneg = off; off += align16(n_pad * 2);
+    bp.off_llr = off; off += align16((n_pad + 4) * 4);         // + the dummy bit
+    bp.off_bneg = off;                                          // (no bit-side sign copy any more)
     bp.off_out = off; off += align16(bp.out_words * 4);
     bp.off_misc = off; off += 256;
     bp.lds_bytes = off;

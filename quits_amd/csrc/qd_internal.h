@@ -15,11 +15,15 @@
 struct BpGraphDev {
     int m, n, m_pad, n_pad;
     int max_rdeg, max_cdeg, neg_words, out_words;
-    const uint16_t *chk_adj;    // [max_rdeg][m_pad]   bit slot of the k-th fault of the check (k ascending = original column order)
-    const uint8_t *chk_deg;     // [m_pad]
+    int max_rdeg_pad;           // max_rdeg rounded up to a multiple of 4
+    int dummy_bit, dummy_chk;   // LDS slots that pad short rows/columns: llr[dummy_bit] = +inf, chk[dummy_chk] = zero message
+    const uint16_t *chk_adj;    // [max_rdeg_pad][m_pad]  bit slot of the k-th fault of the check (k ascending = original column order), dummy_bit beyond the degree
+    const uint8_t *chk_deg;     // [m_pad]             true degree
+    const uint8_t *chk_degp;    // [m_pad]             trip count: max degree inside the slot's wavefront, rounded up to 4 (wave-uniform)
     const uint32_t *chk_orig;   // [m_pad]             detector index of the check slot
-    const uint32_t *bit_adj;    // [max_cdeg][n_pad]   check slot | (edge position inside that check) << 16; q ascending = original row order
-    const uint8_t *bit_deg;     // [n_pad]
+    const uint32_t *bit_adj;    // [max_cdeg][n_pad]   (check slot << 16) | edge position inside that check; q ascending = original row order; dummy_chk beyond the degree
+    const uint8_t *bit_deg;     // [n_pad]             true degree
+    const uint8_t *bit_degp;    // [n_pad]             trip count: max degree inside the slot's wavefront (wave-uniform)
     const float *bit_llr0;      // [n_pad]             log((1-p)/p), computed in double on the host, rounded once
     const uint32_t *bit_orig;   // [n_pad]             fault index of the bit slot
     // LDS carve-up (byte offsets, 16-byte aligned)
