@@ -18,6 +18,17 @@
 #include "qd_internal.h"
 #include <float.h>
 
+// Four LDS byte offsets per vector load: uint2 = 4 x uint16 (windows up to 16379 fault slots), uint4 = 4 x uint32.
+template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint2 &v)
+{
+    const uint32_t w = (I < 2) ? v.x : v.y;
+    return (I & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
+{
+    return I == 0 ? v.x : (I == 1 ? v.y : (I == 2 ? v.z : v.w));
+}
+
 #ifndef QD_ABLATE
 #define QD_ABLATE 0        // timing experiments only (tools/ablate_bp.sh); any value but 0 breaks the results
 #endif
@@ -25,33 +36,51 @@
 #define QD_BP_MINWAVES 8   // waves per SIMD the register allocator must leave room for (8 = two 1024-thread workgroups per CU)
 #endif
 
-// One edge of the check pass.  L = posterior of the fault, k = edge position inside the check, kk = its bit inside the
-// current 32-edge sign word `sgnw` (bit = sign of the previous check->bit message on that edge).
-// Branch-free: the second minimum is the median of (min1, min2, |b|).
-#define QD_CHECK_EDGE(L, k, kk)                                                                              \
+// One edge of the check pass.
+//   off  = LDS byte offset of the fault's posterior (doubles as the edge's label for the argmin bookkeeping)
+//   sb   = bit of `sgnw` that holds the sign of the previous check->bit message on this edge
+// Branch-free: the second minimum is the median of (min1, min2, |b|); the new sign bits are shifted in from bit 0.
+// (b <= 0) is taken as the sign bit of (bits(b) - 1): exact for every float except -0.0, which cannot occur here -- a
+// posterior is a sum that starts from a non-zero prior, and x - y only yields -0 from (-0) - (+0).
+#define QD_CHECK_EDGE(off, sb)                                                                               \
     {                                                                                                        \
-        us ^= ((L) <= 0.f);                                                                                  \
-        const float mag_ = ((k) == idx_old) ? st.y : st.x;                                                   \
-        const float prev_ = __uint_as_float(__builtin_amdgcn_ubfe(sgnw, (kk), 1) << 31 | __float_as_uint(mag_)); \
-        const float bm_ = (L) - prev_;                 /* bit->check message, "total minus own" */            \
+        const float L_ = *reinterpret_cast<const float *>(smem_llr + (off));                                 \
+        us ^= (L_ <= 0.f);                                                                                   \
+        const float mag_ = ((off) == idx_old) ? st.y : st.x;                                                 \
+        const float prev_ = __uint_as_float(((sgnw >> (sb)) & 1u) << 31 | __float_as_uint(mag_));            \
+        const float bm_ = L_ - prev_;                  /* bit->check message, "total minus own" */            \
         const float ab_ = fabsf(bm_);                                                                        \
-        neww |= ((bm_ <= 0.f) ? 1u : 0u) << (kk);      /* bp.hpp: a message <= 0 counts as negative */        \
-        idx = (ab_ < a1) ? (k) : idx;                                                                        \
+        neww = __builtin_amdgcn_alignbit(neww, __float_as_uint(bm_) - 1u, 31);   /* neww = neww << 1 | (bm_ <= 0) */ \
+        idx = (ab_ < a1) ? (off) : idx;                                                                      \
         a2 = __builtin_amdgcn_fmed3f(a1, a2, ab_);                                                           \
         a1 = fminf(a1, ab_);                                                                                 \
     }
 
+// One edge of the bit pass: rec = (check state offset << 16) | sign word index << 5 | sign bit index.
+#define QD_BIT_EDGE(rec)                                                                                     \
+    {                                                                                                        \
+        const uint32_t r_ = (rec);                                                                           \
+        const float4 st_ = *reinterpret_cast<const float4 *>(smem_chk + (r_ >> 16));                         \
+        const float mag_ = (__float_as_uint(st_.z) << 16 == mylabel) ? st_.y : st_.x;                        \
+        uint32_t sw_ = __float_as_uint(st_.w);                                                               \
+        if (WIDE && (r_ & 0xE0u)) sw_ = csgn_hi[(((r_ >> 5) & 7u) - 1u) * m_pad + (r_ >> 20)];               \
+        acc += __uint_as_float(((sw_ >> (r_ & 31u)) & 1u) << 31 | __float_as_uint(mag_));                    \
+    }
+
 // State of a check in LDS (16 bytes, one ds_read_b128):  x = min1 * alpha,  y = min2 * alpha,
-//   z = argmin position | syndrome bit << 9,  w = SIGN bits of the outgoing messages on edges 0..31
+//   z = slot of the argmin fault (16 bits) | syndrome bit << 16,
+//   w = SIGN bits of the outgoing messages on edges 0..31, edge k at bit (edges_in_word - 1 - k)
 //   (sign of check->bit message k = syndrome ^ parity of all incoming signs ^ incoming sign k).
 // Edges 32.. of wide checks keep their sign words in `csgn_hi`.
-template <int T, int MAXCD, bool WIDE>
+template <int T, int NCH, bool WIDE, typename ADJ4>
 __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraphDev g, DecodeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float4 *chk = reinterpret_cast<float4 *>(smem + g.off_chk);
+    unsigned char *smem_chk = smem + g.off_chk;
+    unsigned char *smem_llr = smem + g.off_llr;
+    float4 *chk = reinterpret_cast<float4 *>(smem_chk);
     uint32_t *csgn_hi = reinterpret_cast<uint32_t *>(smem + g.off_cneg);
-    float *llr = reinterpret_cast<float *>(smem + g.off_llr);
+    float *llr = reinterpret_cast<float *>(smem_llr);
     uint32_t *outw = reinterpret_cast<uint32_t *>(smem + g.off_out);
     volatile int *misc = reinterpret_cast<volatile int *>(smem + g.off_misc);   // [0..31] OR flags, [32] fail slot
     constexpr int NW = T / 64;
@@ -61,6 +90,8 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
     const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
     const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
     const int m_pad = g.m_pad, n_pad = g.n_pad;
+    const uint4 *rec4 = reinterpret_cast<const uint4 *>(g.bit_rec);
+    const ADJ4 *adj4 = reinterpret_cast<const ADJ4 *>(g.chk_adj);
 
     // ---- load the window syndrome (sliding_window.py:168-169) and reset the state
     int any = 0;
@@ -69,15 +100,15 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         uint32_t s = det[o] & 1u;
         if (upd && (int)o < a.upd_rows) s ^= upd[o] & 1u;
         any |= (int)s;
-        chk[c] = make_float4(0.f, 0.f, __uint_as_float(0xFFu | (s << 9)), __uint_as_float(0u));   // no message yet
+        chk[c] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFu | (s << 16)), __uint_as_float(0u));   // no message yet
         if (WIDE)
             for (int w = 1; w < g.neg_words; ++w) csgn_hi[(w - 1) * m_pad + c] = 0u;
     }
-    for (int b = tid; b < g.n; b += T) llr[b] = g.bit_llr0[b];
+    for (int b = tid; b < g.n; b += T) llr[b] = __uint_as_float(rec4[b].x);
     for (int w = tid; w < g.out_words; w += T) outw[w] = 0u;
     if (tid == 0) {
         llr[g.dummy_bit] = __builtin_inff();                                            // padding edge of a short row: |b| = inf, never a minimum, never negative
-        chk[g.dummy_chk] = make_float4(0.f, 0.f, __uint_as_float(0xFFu), __uint_as_float(0u));   // padding edge of a short column: message +0
+        chk[g.dummy_chk] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFu), __uint_as_float(0u));   // padding edge of a short column: message +0
     }
     any = qd_block_or(any, misc, NW, 0);
     if (!any) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
@@ -94,42 +125,28 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         for (int c = tid; c < g.m; c += T) {
             const float4 st = chk[c];
             const uint32_t meta = __float_as_uint(st.z);
-            const int idx_old = (int)(meta & 0xFFu);
-            const uint32_t synd = (meta >> 9) & 1u;
-            const int degp = __builtin_amdgcn_readfirstlane((int)g.chk_degp[c]);   // wave-uniform, multiple of 4
+            const uint32_t idx_old = (meta & 0xFFFFu) << 2;           // label = LDS offset of the argmin fault's posterior
+            const uint32_t synd = (meta >> 16) & 1u;
+            const int degp = g.chk_degp_w[__builtin_amdgcn_readfirstlane(c) >> 6];     // scalar load; multiple of 4
             bool us = (synd != 0u);
-            int idx = 255;
+            uint32_t idx = 0xFFFFu << 2;
             float a1 = FLT_MAX, a2 = FLT_MAX;
             uint32_t neg0 = 0u, npar = 0u;
             for (int k0 = 0; k0 < degp; k0 += 32) {
                 const uint32_t sgnw = (!WIDE || k0 == 0) ? __float_as_uint(st.w) : csgn_hi[((k0 >> 5) - 1) * m_pad + c];
                 uint32_t neww = 0u;
                 const int kend = min(degp - k0, 32);                // multiple of 4
-                const uint16_t *adj = g.chk_adj + (size_t)k0 * m_pad + c;
-#if QD_ABLATE == 1 || QD_ABLATE == 12
-                uint32_t j0 = (c * 7 + k0 * 13) % g.n, j1 = j0 + 1, j2 = j0 + 2, j3 = j0 + 3;
-#elif QD_ABLATE == 2
-                uint32_t j0 = c, j1 = c, j2 = c, j3 = c;
-#else
-                uint32_t j0 = adj[0], j1 = adj[m_pad], j2 = adj[2 * m_pad], j3 = adj[3 * m_pad];
-#endif
+                const ADJ4 *ap = adj4 + (size_t)(k0 >> 2) * m_pad + c;
+                ADJ4 nx = ap[0];
 #pragma unroll 1
                 for (int kk = 0; kk < kend; kk += 4) {
-                    const float L0 = llr[j0], L1 = llr[j1], L2 = llr[j2], L3 = llr[j3];
-#if QD_ABLATE == 1 || QD_ABLATE == 12
-                    j0 = (j0 + 977) % g.n; j1 = (j1 + 977) % g.n; j2 = (j2 + 977) % g.n; j3 = (j3 + 977) % g.n;
-#elif QD_ABLATE == 2
-#else
-                    if (kk + 4 < kend) {                             // next four fault indices while these are processed
-                        const uint16_t *nx = adj + (size_t)(kk + 4) * m_pad;
-                        j0 = nx[0]; j1 = nx[m_pad]; j2 = nx[2 * m_pad]; j3 = nx[3 * m_pad];
-                    }
-#endif
-                    const int kb = k0 + kk;
-                    QD_CHECK_EDGE(L0, kb + 0, kk + 0)
-                    QD_CHECK_EDGE(L1, kb + 1, kk + 1)
-                    QD_CHECK_EDGE(L2, kb + 2, kk + 2)
-                    QD_CHECK_EDGE(L3, kb + 3, kk + 3)
+                    const ADJ4 cur = nx;
+                    if (kk + 4 < kend) nx = ap[(size_t)((kk >> 2) + 1) * m_pad];   // next four fault offsets while these are processed
+                    const int sb = kend - 1 - kk;
+                    QD_CHECK_EDGE(qd_adj_get<0>(cur), sb)
+                    QD_CHECK_EDGE(qd_adj_get<1>(cur), sb - 1)
+                    QD_CHECK_EDGE(qd_adj_get<2>(cur), sb - 2)
+                    QD_CHECK_EDGE(qd_adj_get<3>(cur), sb - 3)
                 }
                 npar ^= neww;
                 if (k0 == 0) neg0 = neww;
@@ -140,7 +157,7 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             const uint32_t flip = 0u - ((synd ^ (uint32_t)__popc(npar)) & 1u);
             if (WIDE)
                 for (int k0 = 32; k0 < degp; k0 += 32) csgn_hi[((k0 >> 5) - 1) * m_pad + c] ^= flip;
-            chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float((uint32_t)idx | (synd << 9)), __uint_as_float(neg0 ^ flip));
+            chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float((idx >> 2) | (synd << 16)), __uint_as_float(neg0 ^ flip));
         }
         const int anyun = qd_block_or(unsat ? 1 : 0, misc, NW, phase);
         phase ^= 1;
@@ -148,28 +165,38 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         if (t == a.max_iter) break;
         // ---- bit pass t+1: posterior = prior + sum of check->bit messages, in ascending detector order
         for (int b = tid; b < g.n; b += T) {
-            const int d = __builtin_amdgcn_readfirstlane((int)g.bit_degp[b]);     // wave-uniform
-            uint32_t aj[MAXCD];
-#pragma unroll
-#if QD_ABLATE == 3 || QD_ABLATE == 12
-            for (int q = 0; q < MAXCD; ++q) aj[q] = (uint32_t)(((b * 5 + q * 131) % g.m) << 16) | (uint32_t)q;
-#elif QD_ABLATE == 4
-            for (int q = 0; q < MAXCD; ++q) aj[q] = (uint32_t)((b % g.m) << 16) | (uint32_t)q;
-#else
-            for (int q = 0; q < MAXCD; ++q) aj[q] = (q < d) ? g.bit_adj[(size_t)q * n_pad + b] : 0u;
-#endif
-            float acc = g.bit_llr0[b];
-#pragma unroll
-            for (int q = 0; q < MAXCD; ++q) {
-                if (q < d) {
-                    const uint32_t cs = aj[q] >> 16, pos = aj[q] & 0xFFu;       // check slot | edge position inside it
-                    const float4 st = chk[cs];
-                    const uint32_t meta = __float_as_uint(st.z);
-                    const float mag = (pos == (meta & 0xFFu)) ? st.y : st.x;
-                    uint32_t sw = __float_as_uint(st.w);
-                    if (WIDE && pos >= 32u) sw = csgn_hi[((pos >> 5) - 1) * m_pad + cs];
-                    acc += __uint_as_float(__builtin_amdgcn_ubfe(sw, pos & 31u, 1) << 31 | __float_as_uint(mag));
-                }
+            const int b0 = __builtin_amdgcn_readfirstlane(b);           // first slot of this wavefront
+            const uint32_t mylabel = (uint32_t)b << 16;                 // my slot, where the check keeps its argmin slot after << 16
+            const uint4 r0 = rec4[b];
+            uint4 r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1, r4 = r1;
+            if (NCH > 1 && b0 < g.bit_thr[3]) r1 = rec4[(size_t)n_pad + b];
+            if (NCH > 2 && b0 < g.bit_thr[7]) r2 = rec4[(size_t)2 * n_pad + b];
+            if (NCH > 3 && b0 < g.bit_thr[11]) r3 = rec4[(size_t)3 * n_pad + b];
+            if (NCH > 4 && b0 < g.bit_thr[15]) r4 = rec4[(size_t)4 * n_pad + b];
+            float acc = __uint_as_float(r0.x);
+            if (b0 < g.bit_thr[0]) QD_BIT_EDGE(r0.y)
+            if (b0 < g.bit_thr[1]) QD_BIT_EDGE(r0.z)
+            if (b0 < g.bit_thr[2]) QD_BIT_EDGE(r0.w)
+            if (NCH > 1) {
+                if (b0 < g.bit_thr[3]) QD_BIT_EDGE(r1.x)
+                if (b0 < g.bit_thr[4]) QD_BIT_EDGE(r1.y)
+                if (b0 < g.bit_thr[5]) QD_BIT_EDGE(r1.z)
+                if (b0 < g.bit_thr[6]) QD_BIT_EDGE(r1.w)
+            }
+            if (NCH > 2) {
+                if (b0 < g.bit_thr[7]) QD_BIT_EDGE(r2.x)
+                if (b0 < g.bit_thr[8]) QD_BIT_EDGE(r2.y)
+                if (b0 < g.bit_thr[9]) QD_BIT_EDGE(r2.z)
+                if (b0 < g.bit_thr[10]) QD_BIT_EDGE(r2.w)
+            }
+            if (NCH > 3) {
+                if (b0 < g.bit_thr[11]) QD_BIT_EDGE(r3.x)
+                if (b0 < g.bit_thr[12]) QD_BIT_EDGE(r3.y)
+                if (b0 < g.bit_thr[13]) QD_BIT_EDGE(r3.z)
+                if (b0 < g.bit_thr[14]) QD_BIT_EDGE(r3.w)
+            }
+            if (NCH > 4) {
+                if (b0 < g.bit_thr[15]) QD_BIT_EDGE(r4.x)
             }
             llr[b] = acc;
         }
@@ -196,22 +223,33 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------------
-template <int T, int MAXCD, bool WIDE>
+template <int T, int NCH, bool WIDE, typename ADJ4>
 static hipError_t launch_bp_k(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
 {
-    auto k = qd_bp_minsum_kernel<T, MAXCD, WIDE>;
+    auto k = qd_bp_minsum_kernel<T, NCH, WIDE, ADJ4>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(T), g.lds_bytes, s, g, a);
     return hipGetLastError();
 }
 
+template <int T, int NCH>
+static hipError_t launch_bp_n(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
+{
+    const bool wide = g.max_rdeg_pad > 32;
+    if (g.adj32) return wide ? launch_bp_k<T, NCH, true, uint4>(g, a, B, s) : launch_bp_k<T, NCH, false, uint4>(g, a, B, s);
+    return wide ? launch_bp_k<T, NCH, true, uint2>(g, a, B, s) : launch_bp_k<T, NCH, false, uint2>(g, a, B, s);
+}
+
 template <int T>
 static hipError_t launch_bp_t(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
 {
-    const bool wide = g.max_rdeg_pad > 32;
-    if (g.max_cdeg <= 8) return wide ? launch_bp_k<T, 8, true>(g, a, B, s) : launch_bp_k<T, 8, false>(g, a, B, s);
-    return wide ? launch_bp_k<T, QD_MAX_COL_DEG, true>(g, a, B, s) : launch_bp_k<T, QD_MAX_COL_DEG, false>(g, a, B, s);
+    switch (g.rec_words / 4) {
+    case 1: return launch_bp_n<T, 1>(g, a, B, s);
+    case 2: return launch_bp_n<T, 2>(g, a, B, s);
+    case 3: return launch_bp_n<T, 3>(g, a, B, s);
+    default: return launch_bp_n<T, 5>(g, a, B, s);
+    }
 }
 
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)

@@ -143,10 +143,16 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int m_pad = pad64(m), n_pad = pad64(n);
     const int max_rdeg_pad = (max_rdeg + 3) & ~3;
     const int dummy_bit = n_pad, dummy_chk = m_pad;        // one extra LDS slot each
-    std::vector<uint16_t> chk_adj((size_t)max_rdeg_pad * m_pad, (uint16_t)dummy_bit);
-    std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0), chk_degp(m_pad, 0), bit_degp(n_pad, 0);
-    std::vector<uint32_t> chk_orig_u(m_pad, 0), bit_orig_u(n_pad, 0), bit_adj((size_t)max_cdeg * n_pad, (uint32_t)dummy_chk << 16);
-    std::vector<float> llr0(n_pad, 1.0f);
+    if ((m_pad + 1) * 16 > 65535) {
+        delete g;
+        return fail(QD_ECAPACITY, "m = %d detectors per window: check-state offsets exceed 16 bits", m);
+    }
+    const int adj32 = ((n_pad + 1) * 4 > 65535) ? 1 : 0;
+    const int rec_words = ((1 + max_cdeg) + 3) & ~3;
+    std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0);
+    std::vector<int32_t> chk_degp_w(m_pad / 64, 0);
+    std::vector<uint32_t> chk_orig_u(m_pad, 0), bit_orig_u(n_pad, 0);
+    std::vector<uint32_t> bit_rec((size_t)n_pad * rec_words, (uint32_t)(dummy_chk * 16) << 16);
     // CSC with the edge's position inside its row
     std::vector<int32_t> cp(n + 1, 0), ri(nnz), pos(nnz);
     for (int j = 0; j < n; ++j) cp[j + 1] = cp[j] + cdeg[j];
@@ -158,31 +164,47 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
                 ri[dst] = i; pos[dst] = e - row_ptr[i];
             }
     }
+    for (int s = 0; s < m; ++s) { chk_deg[s] = (uint8_t)rdeg[chk_orig[s]]; chk_orig_u[s] = (uint32_t)chk_orig[s]; }
+    // wave-uniform trip counts (slots are degree-sorted, so a wavefront's lanes nearly agree anyway)
+    for (int w0 = 0; w0 < m_pad; w0 += 64) {
+        int mx = 0;
+        for (int s = w0; s < w0 + 64; ++s) mx = std::max(mx, (int)chk_deg[s]);
+        chk_degp_w[w0 / 64] = (mx + 3) & ~3;
+    }
+    // check -> fault adjacency, ELL-transposed, as LDS byte offsets of the posteriors
+    std::vector<uint16_t> chk_adj16;
+    std::vector<uint32_t> chk_adj32;
+    if (adj32) chk_adj32.assign((size_t)max_rdeg_pad * m_pad, (uint32_t)dummy_bit * 4u);
+    else chk_adj16.assign((size_t)max_rdeg_pad * m_pad, (uint16_t)(dummy_bit * 4));
     for (int s = 0; s < m; ++s) {
         const int i = chk_orig[s];
-        chk_deg[s] = (uint8_t)rdeg[i];
-        chk_orig_u[s] = (uint32_t)i;
-        for (int k = 0; k < rdeg[i]; ++k) chk_adj[(size_t)k * m_pad + s] = (uint16_t)bit_slot_of[col_idx[row_ptr[i] + k]];
+        for (int k = 0; k < rdeg[i]; ++k) {
+            const uint32_t off = (uint32_t)bit_slot_of[col_idx[row_ptr[i] + k]] * 4u;
+            const size_t at = ((size_t)(k >> 2) * m_pad + s) * 4 + (k & 3);      // [group of 4 edges][slot][4]: one vector load per group
+            if (adj32) chk_adj32[at] = off;
+            else chk_adj16[at] = (uint16_t)off;
+        }
+    }
+    // fault records: prior + (check state offset, where that check keeps this edge's sign)
+    auto rec_at = [&](int slot, int word) { return ((size_t)(word >> 2) * n_pad + slot) * 4 + (word & 3); };   // [chunk][slot][4]
+    for (int s = 0; s < n_pad; ++s) {
+        const float one = 1.0f;
+        std::memcpy(&bit_rec[rec_at(s, 0)], &one, 4);
     }
     for (int s = 0; s < n; ++s) {
         const int j = bit_orig[s];
         bit_deg[s] = (uint8_t)cdeg[j];
         bit_orig_u[s] = (uint32_t)j;
-        llr0[s] = (float)std::log((1.0 - priors[j]) / priors[j]);
-        for (int q = 0; q < cdeg[j]; ++q)
-            bit_adj[(size_t)q * n_pad + s] = ((uint32_t)chk_slot_of[ri[cp[j] + q]] << 16) | (uint32_t)pos[cp[j] + q];
-    }
-    // wave-uniform trip counts (slots are degree-sorted, so a wavefront's lanes nearly agree anyway)
-    for (int w0 = 0; w0 < m_pad; w0 += 64) {
-        int mx = 0;
-        for (int s = w0; s < w0 + 64; ++s) mx = std::max(mx, (int)chk_deg[s]);
-        mx = (mx + 3) & ~3;
-        for (int s = w0; s < w0 + 64; ++s) chk_degp[s] = (uint8_t)mx;
-    }
-    for (int w0 = 0; w0 < n_pad; w0 += 64) {
-        int mx = 0;
-        for (int s = w0; s < w0 + 64; ++s) mx = std::max(mx, (int)bit_deg[s]);
-        for (int s = w0; s < w0 + 64; ++s) bit_degp[s] = (uint8_t)mx;
+        const float l0 = (float)std::log((1.0 - priors[j]) / priors[j]);
+        std::memcpy(&bit_rec[rec_at(s, 0)], &l0, 4);
+        for (int q = 0; q < cdeg[j]; ++q) {
+            const int cs = chk_slot_of[ri[cp[j] + q]];
+            const int k = pos[cp[j] + q];
+            const int degp = chk_degp_w[cs / 64];
+            const int w = k >> 5, kend = std::min(degp - 32 * w, 32);
+            const int sbit = kend - 1 - (k & 31);              // the check pass shifts signs in from bit 0 (v_alignbit)
+            bit_rec[rec_at(s, 1 + q)] = ((uint32_t)(cs * 16) << 16) | ((uint32_t)w << 5) | (uint32_t)sbit;
+        }
     }
     g->h_cp = cp; g->h_ri = ri;
 
@@ -190,22 +212,28 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     bp.m = m; bp.n = n; bp.m_pad = m_pad; bp.n_pad = n_pad; bp.max_rdeg = max_rdeg; bp.max_cdeg = max_cdeg;
     bp.neg_words = (max_rdeg_pad + 31) / 32; bp.out_words = (n + 31) / 32;
     bp.max_rdeg_pad = max_rdeg_pad; bp.dummy_bit = dummy_bit; bp.dummy_chk = dummy_chk;
+    bp.rec_words = rec_words; bp.adj32 = adj32;
+    for (int q = 0; q < QD_MAX_COL_DEG; ++q) {
+        int cnt = 0;
+        for (int w0 = 0; w0 < n_pad; w0 += 64) {
+            int mx = 0;
+            for (int s = w0; s < w0 + 64; ++s) mx = std::max(mx, (int)bit_deg[s]);
+            if (mx > q) cnt = w0 + 64;
+        }
+        bp.bit_thr[q] = cnt;
+    }
     int rc = 0;
-    rc |= g->mem.upload(chk_adj, &bp.chk_adj);
-    rc |= g->mem.upload(chk_deg, &bp.chk_deg);
-    rc |= g->mem.upload(chk_degp, &bp.chk_degp);
-    rc |= g->mem.upload(bit_degp, &bp.bit_degp);
+    if (adj32) { const uint32_t *p32 = nullptr; rc |= g->mem.upload(chk_adj32, &p32); bp.chk_adj = p32; }
+    else { const uint16_t *p16 = nullptr; rc |= g->mem.upload(chk_adj16, &p16); bp.chk_adj = p16; }
+    rc |= g->mem.upload(chk_degp_w, &bp.chk_degp_w);
     rc |= g->mem.upload(chk_orig_u, &bp.chk_orig);
-    rc |= g->mem.upload(bit_adj, &bp.bit_adj);
-    rc |= g->mem.upload(bit_deg, &bp.bit_deg);
-    rc |= g->mem.upload(llr0, &bp.bit_llr0);
+    rc |= g->mem.upload(bit_rec, &bp.bit_rec);
     rc |= g->mem.upload(bit_orig_u, &bp.bit_orig);
     // LDS carve-up for BP
     int off = 0;
     bp.off_chk = off; off += (m_pad + 4) * 16;                 // + the dummy check
     bp.off_cneg = off; off += align16((bp.neg_words - 1) * m_pad * 4);
     bp.off_llr = off; off += align16((n_pad + 4) * 4);         // + the dummy bit
-    bp.off_bneg = off;                                          // (no bit-side sign copy any more)
     bp.off_out = off; off += align16(bp.out_words * 4);
     bp.off_misc = off; off += 256;
     bp.lds_bytes = off;

@@ -10,24 +10,26 @@
 
 // One window's Tanner graph as the BP kernel wants it.
 //   check slots: checks sorted by degree (descending); bit slots: faults sorted by degree (descending), so that a
-//   wavefront's lanes run the same trip count.  Adjacency is stored ELL-transposed ([k][slot]) so that lane = slot
-//   reads are coalesced; indices refer to SLOTS, the LDS arrays are indexed by slot.
+//   wavefront's lanes run the same trip count.  Indices refer to SLOTS; the LDS arrays are indexed by slot.
+//   Everything is pre-scaled to LDS byte offsets so the kernel does no address arithmetic on the gathers.
 struct BpGraphDev {
     int m, n, m_pad, n_pad;
     int max_rdeg, max_cdeg, neg_words, out_words;
     int max_rdeg_pad;           // max_rdeg rounded up to a multiple of 4
     int dummy_bit, dummy_chk;   // LDS slots that pad short rows/columns: llr[dummy_bit] = +inf, chk[dummy_chk] = zero message
-    const uint16_t *chk_adj;    // [max_rdeg_pad][m_pad]  bit slot of the k-th fault of the check (k ascending = original column order), dummy_bit beyond the degree
-    const uint8_t *chk_deg;     // [m_pad]             true degree
-    const uint8_t *chk_degp;    // [m_pad]             trip count: max degree inside the slot's wavefront, rounded up to 4 (wave-uniform)
-    const uint32_t *chk_orig;   // [m_pad]             detector index of the check slot
-    const uint32_t *bit_adj;    // [max_cdeg][n_pad]   (check slot << 16) | edge position inside that check; q ascending = original row order; dummy_chk beyond the degree
-    const uint8_t *bit_deg;     // [n_pad]             true degree
-    const uint8_t *bit_degp;    // [n_pad]             trip count: max degree inside the slot's wavefront (wave-uniform)
-    const float *bit_llr0;      // [n_pad]             log((1-p)/p), computed in double on the host, rounded once
-    const uint32_t *bit_orig;   // [n_pad]             fault index of the bit slot
+    int rec_words;              // uint32 words per fault record (multiple of 4)
+    int adj32;                  // 1: chk_adj holds uint32 entries (windows with more than 16379 fault slots), else uint16
+    const void *chk_adj;        // [max_rdeg_pad/4][m_pad][4] LDS byte offset (slot * 4) of the k-th fault of the check, k ascending =
+                                //                        original column order; dummy_bit * 4 beyond the degree
+    const int32_t *chk_degp_w;  // [m_pad / 64]           trip count of a wavefront of check slots: its max degree rounded up to 4
+    const uint32_t *chk_orig;   // [m_pad]                detector index of the check slot
+    const uint32_t *bit_rec;    // [rec_words/4][n_pad][4] word 0 = prior LLR (float bits: log((1-p)/p) computed in double, rounded once);
+                                //                        word 1+q = (check slot * 16) << 16 | sign word index << 5 | sign bit index
+                                //                        for the q-th check of the fault (q ascending = original row order)
+    const uint32_t *bit_orig;   // [n_pad]                fault index of the bit slot
+    int bit_thr[QD_MAX_COL_DEG];// bit_thr[q] = number of bit slots (multiple of 64) whose wavefront has a fault of degree > q
     // LDS carve-up (byte offsets, 16-byte aligned)
-    int off_chk, off_cneg, off_llr, off_bneg, off_out, off_misc, lds_bytes;   // off_misc: 64 ints of reduction scratch
+    int off_chk, off_cneg, off_llr, off_out, off_misc, lds_bytes;   // off_misc: 64 ints of reduction scratch
     int threads;
 };
 
