@@ -37,14 +37,14 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
 #endif
 
 // One edge of the check pass.
-//   off  = LDS byte offset of the fault's posterior (doubles as the edge's label for the argmin bookkeeping)
+//   off  = absolute LDS byte offset of the fault's posterior (doubles as the edge's label for the argmin bookkeeping)
 //   sb   = bit of `sgnw` that holds the sign of the previous check->bit message on this edge
 // Branch-free: the second minimum is the median of (min1, min2, |b|); the new sign bits are shifted in from bit 0.
 // (b <= 0) is taken as the sign bit of (bits(b) - 1): exact for every float except -0.0, which cannot occur here -- a
 // posterior is a sum that starts from a non-zero prior, and x - y only yields -0 from (-0) - (+0).
 #define QD_CHECK_EDGE(off, sb)                                                                               \
     {                                                                                                        \
-        const float L_ = *reinterpret_cast<const float *>(smem_llr + (off));                                 \
+        const float L_ = *reinterpret_cast<const float *>(smem + (off));                                     \
         us ^= (L_ <= 0.f);                                                                                   \
         const float mag_ = ((off) == idx_old) ? st.y : st.x;                                                 \
         const float prev_ = __uint_as_float(((sgnw >> (sb)) & 1u) << 31 | __float_as_uint(mag_));            \
@@ -56,33 +56,41 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
         a1 = fminf(a1, ab_);                                                                                 \
     }
 
-// One edge of the bit pass: rec = (check state offset << 16) | sign word index << 5 | sign bit index.
-#define QD_BIT_EDGE(rec)                                                                                     \
+// Bit pass, one edge.  rec = (LDS byte offset of the check state) << 16 | where its sign lives.
+//   load:  gather the 16-byte check state (all of a fault's gathers are issued before any is used)
+//   use :  magnitude = min2 if this fault is the check's argmin, else min1; sign = the check's outgoing sign bit
+#define QD_BIT_LOAD(rec) (*reinterpret_cast<const float4 *>(smem + ((rec) >> 16)))
+#define QD_BIT_USE(rec, st_)                                                                                 \
     {                                                                                                        \
-        const uint32_t r_ = (rec);                                                                           \
-        const float4 st_ = *reinterpret_cast<const float4 *>(smem_chk + (r_ >> 16));                         \
-        const float mag_ = (__float_as_uint(st_.z) << 16 == mylabel) ? st_.y : st_.x;                        \
-        uint32_t sw_ = __float_as_uint(st_.w);                                                               \
-        if (WIDE && (r_ & 0xE0u)) sw_ = csgn_hi[(((r_ >> 5) & 7u) - 1u) * m_pad + (r_ >> 20)];               \
-        acc += __uint_as_float(((sw_ >> (r_ & 31u)) & 1u) << 31 | __float_as_uint(mag_));                    \
+        const uint32_t z_ = __float_as_uint((st_).z);                                                        \
+        const float mag_ = ((z_ << 17) == mylabel) ? (st_).y : (st_).x;                                      \
+        uint32_t sg_;                                                                                        \
+        if (SM == 2) {                                                                                       \
+            uint32_t sw_ = __float_as_uint((st_).w);                                                         \
+            if ((rec) & 0xE0u) sw_ = csgn_hi[((((rec) >> 5) & 7u) - 1u) * m_pad + ((rec) >> 20)];            \
+            sg_ = sw_ >> ((rec) & 31u);                                                                      \
+        } else if (SM == 1) {                                                                                \
+            sg_ = (uint32_t)((((uint64_t)z_ << 32) | __float_as_uint((st_).w)) >> ((rec) & 63u));           \
+        } else {                                                                                             \
+            sg_ = __float_as_uint((st_).w) >> ((rec) & 31u);                                                 \
+        }                                                                                                    \
+        acc += __uint_as_float(sg_ << 31 | __float_as_uint(mag_));                                           \
     }
 
 // State of a check in LDS (16 bytes, one ds_read_b128):  x = min1 * alpha,  y = min2 * alpha,
-//   z = slot of the argmin fault (16 bits) | syndrome bit << 16,
-//   w = SIGN bits of the outgoing messages on edges 0..31, edge k at bit (edges_in_word - 1 - k)
+//   z = slot of the argmin fault (bits 0..14) | syndrome bit << 15 | (sign mode 1: sign bits of edges 32..47) << 16,
+//   w = SIGN bits of the outgoing messages on edges 0..31; inside a word, edge k sits at bit (edges_in_word - 1 - k)
 //   (sign of check->bit message k = syndrome ^ parity of all incoming signs ^ incoming sign k).
-// Edges 32.. of wide checks keep their sign words in `csgn_hi`.
-template <int T, int NCH, bool WIDE, typename ADJ4>
+// Sign mode 2 (checks wider than 48): edges 32.. keep their sign words in `csgn_hi`.
+template <int T, int NCH, int SM, typename ADJ4>
 __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraphDev g, DecodeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *smem_chk = smem + g.off_chk;
-    unsigned char *smem_llr = smem + g.off_llr;
-    float4 *chk = reinterpret_cast<float4 *>(smem_chk);
+    float4 *chk = reinterpret_cast<float4 *>(smem + g.off_chk);
     uint32_t *csgn_hi = reinterpret_cast<uint32_t *>(smem + g.off_cneg);
-    float *llr = reinterpret_cast<float *>(smem_llr);
+    float *llr = reinterpret_cast<float *>(smem + g.off_llr);
     uint32_t *outw = reinterpret_cast<uint32_t *>(smem + g.off_out);
-    volatile int *misc = reinterpret_cast<volatile int *>(smem + g.off_misc);   // [0..31] OR flags, [32] fail slot
+    int *misc = reinterpret_cast<int *>(smem + g.off_misc);   // [0..31] OR flags, [32] fail slot
     constexpr int NW = T / 64;
 
     const int tid = threadIdx.x;
@@ -92,24 +100,27 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
     const int m_pad = g.m_pad, n_pad = g.n_pad;
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(g.bit_rec);
     const ADJ4 *adj4 = reinterpret_cast<const ADJ4 *>(g.chk_adj);
+    const uint32_t llr_base = (uint32_t)g.off_llr;
 
     // ---- load the window syndrome (sliding_window.py:168-169) and reset the state
     int any = 0;
+    if (tid < 64) misc[tid] = 0;
     for (int c = tid; c < g.m; c += T) {
         const uint32_t o = g.chk_orig[c];
         uint32_t s = det[o] & 1u;
         if (upd && (int)o < a.upd_rows) s ^= upd[o] & 1u;
         any |= (int)s;
-        chk[c] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFu | (s << 16)), __uint_as_float(0u));   // no message yet
-        if (WIDE)
+        chk[c] = make_float4(0.f, 0.f, __uint_as_float(0x7FFFu | (s << 15)), __uint_as_float(0u));   // no message yet
+        if (SM == 2)
             for (int w = 1; w < g.neg_words; ++w) csgn_hi[(w - 1) * m_pad + c] = 0u;
     }
     for (int b = tid; b < g.n; b += T) llr[b] = __uint_as_float(rec4[b].x);
     for (int w = tid; w < g.out_words; w += T) outw[w] = 0u;
     if (tid == 0) {
         llr[g.dummy_bit] = __builtin_inff();                                            // padding edge of a short row: |b| = inf, never a minimum, never negative
-        chk[g.dummy_chk] = make_float4(0.f, 0.f, __uint_as_float(0xFFFFu), __uint_as_float(0u));   // padding edge of a short column: message +0
+        chk[g.dummy_chk] = make_float4(0.f, 0.f, __uint_as_float(0x7FFFu), __uint_as_float(0u));   // padding edge of a short column: message +0
     }
+    __syncthreads();
     any = qd_block_or(any, misc, NW, 0);
     if (!any) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
         for (int w = tid; w < g.out_words; w += T) a.err_bits[shot * g.out_words + w] = 0u;
@@ -125,15 +136,17 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         for (int c = tid; c < g.m; c += T) {
             const float4 st = chk[c];
             const uint32_t meta = __float_as_uint(st.z);
-            const uint32_t idx_old = (meta & 0xFFFFu) << 2;           // label = LDS offset of the argmin fault's posterior
-            const uint32_t synd = (meta >> 16) & 1u;
+            const uint32_t idx_old = llr_base + ((meta & 0x7FFFu) << 2);   // label = LDS offset of the argmin fault's posterior
+            const uint32_t synd = (meta >> 15) & 1u;
             const int degp = g.chk_degp_w[__builtin_amdgcn_readfirstlane(c) >> 6];     // scalar load; multiple of 4
             bool us = (synd != 0u);
-            uint32_t idx = 0xFFFFu << 2;
+            uint32_t idx = llr_base + (0x7FFFu << 2);
             float a1 = FLT_MAX, a2 = FLT_MAX;
-            uint32_t neg0 = 0u, npar = 0u;
+            uint32_t neg0 = 0u, neg1 = 0u, npar = 0u;
             for (int k0 = 0; k0 < degp; k0 += 32) {
-                const uint32_t sgnw = (!WIDE || k0 == 0) ? __float_as_uint(st.w) : csgn_hi[((k0 >> 5) - 1) * m_pad + c];
+                uint32_t sgnw = __float_as_uint(st.w);
+                if (SM == 1 && k0 != 0) sgnw = meta >> 16;
+                if (SM == 2 && k0 != 0) sgnw = csgn_hi[((k0 >> 5) - 1) * m_pad + c];
                 uint32_t neww = 0u;
                 const int kend = min(degp - k0, 32);                // multiple of 4
                 const ADJ4 *ap = adj4 + (size_t)(k0 >> 2) * m_pad + c;
@@ -150,23 +163,28 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
                 }
                 npar ^= neww;
                 if (k0 == 0) neg0 = neww;
-                else if (WIDE) csgn_hi[((k0 >> 5) - 1) * m_pad + c] = neww;   // fixed up below once the parity is known
+                else if (SM == 1) neg1 = neww;
+                else if (SM == 2) csgn_hi[((k0 >> 5) - 1) * m_pad + c] = neww;   // fixed up below once the parity is known
             }
             unsat |= us;
             // outgoing sign on edge k = syndrome ^ (parity of all incoming signs) ^ incoming sign k
             const uint32_t flip = 0u - ((synd ^ (uint32_t)__popc(npar)) & 1u);
-            if (WIDE)
+            if (SM == 2)
                 for (int k0 = 32; k0 < degp; k0 += 32) csgn_hi[((k0 >> 5) - 1) * m_pad + c] ^= flip;
-            chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float((idx >> 2) | (synd << 16)), __uint_as_float(neg0 ^ flip));
+            uint32_t nmeta = ((idx - llr_base) >> 2) | (synd << 15);
+            if (SM == 1) nmeta |= (neg1 ^ flip) << 16;
+            chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float(nmeta), __uint_as_float(neg0 ^ flip));
         }
         const int anyun = qd_block_or(unsat ? 1 : 0, misc, NW, phase);
         phase ^= 1;
         if (t >= 1 && !anyun) { converged = 1; break; }
         if (t == a.max_iter) break;
-        // ---- bit pass t+1: posterior = prior + sum of check->bit messages, in ascending detector order
+        // ---- bit pass t+1: posterior = prior + sum of check->bit messages, in ascending detector order.
+        // Records beyond a fault's degree point at the dummy check (message +0), so edges are handled in fixed groups
+        // (3 | 2 | 2 | 4 | 4 | 1) with one wave-uniform test per group instead of one per edge.
         for (int b = tid; b < g.n; b += T) {
             const int b0 = __builtin_amdgcn_readfirstlane(b);           // first slot of this wavefront
-            const uint32_t mylabel = (uint32_t)b << 16;                 // my slot, where the check keeps its argmin slot after << 16
+            const uint32_t mylabel = (uint32_t)b << 17;                 // my slot, where the check keeps its argmin slot after << 17
             const uint4 r0 = rec4[b];
             uint4 r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1, r4 = r1;
             if (NCH > 1 && b0 < g.bit_thr[3]) r1 = rec4[(size_t)n_pad + b];
@@ -174,29 +192,29 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             if (NCH > 3 && b0 < g.bit_thr[11]) r3 = rec4[(size_t)3 * n_pad + b];
             if (NCH > 4 && b0 < g.bit_thr[15]) r4 = rec4[(size_t)4 * n_pad + b];
             float acc = __uint_as_float(r0.x);
-            if (b0 < g.bit_thr[0]) QD_BIT_EDGE(r0.y)
-            if (b0 < g.bit_thr[1]) QD_BIT_EDGE(r0.z)
-            if (b0 < g.bit_thr[2]) QD_BIT_EDGE(r0.w)
-            if (NCH > 1) {
-                if (b0 < g.bit_thr[3]) QD_BIT_EDGE(r1.x)
-                if (b0 < g.bit_thr[4]) QD_BIT_EDGE(r1.y)
-                if (b0 < g.bit_thr[5]) QD_BIT_EDGE(r1.z)
-                if (b0 < g.bit_thr[6]) QD_BIT_EDGE(r1.w)
+            {
+                const float4 s0 = QD_BIT_LOAD(r0.y), s1 = QD_BIT_LOAD(r0.z), s2 = QD_BIT_LOAD(r0.w);
+                QD_BIT_USE(r0.y, s0) QD_BIT_USE(r0.z, s1) QD_BIT_USE(r0.w, s2)
             }
-            if (NCH > 2) {
-                if (b0 < g.bit_thr[7]) QD_BIT_EDGE(r2.x)
-                if (b0 < g.bit_thr[8]) QD_BIT_EDGE(r2.y)
-                if (b0 < g.bit_thr[9]) QD_BIT_EDGE(r2.z)
-                if (b0 < g.bit_thr[10]) QD_BIT_EDGE(r2.w)
+            if (NCH > 1 && b0 < g.bit_thr[3]) {
+                const float4 s0 = QD_BIT_LOAD(r1.x), s1 = QD_BIT_LOAD(r1.y);
+                QD_BIT_USE(r1.x, s0) QD_BIT_USE(r1.y, s1)
+                if (b0 < g.bit_thr[5]) {
+                    const float4 s2 = QD_BIT_LOAD(r1.z), s3 = QD_BIT_LOAD(r1.w);
+                    QD_BIT_USE(r1.z, s2) QD_BIT_USE(r1.w, s3)
+                }
             }
-            if (NCH > 3) {
-                if (b0 < g.bit_thr[11]) QD_BIT_EDGE(r3.x)
-                if (b0 < g.bit_thr[12]) QD_BIT_EDGE(r3.y)
-                if (b0 < g.bit_thr[13]) QD_BIT_EDGE(r3.z)
-                if (b0 < g.bit_thr[14]) QD_BIT_EDGE(r3.w)
+            if (NCH > 2 && b0 < g.bit_thr[7]) {
+                const float4 s0 = QD_BIT_LOAD(r2.x), s1 = QD_BIT_LOAD(r2.y), s2 = QD_BIT_LOAD(r2.z), s3 = QD_BIT_LOAD(r2.w);
+                QD_BIT_USE(r2.x, s0) QD_BIT_USE(r2.y, s1) QD_BIT_USE(r2.z, s2) QD_BIT_USE(r2.w, s3)
             }
-            if (NCH > 4) {
-                if (b0 < g.bit_thr[15]) QD_BIT_EDGE(r4.x)
+            if (NCH > 3 && b0 < g.bit_thr[11]) {
+                const float4 s0 = QD_BIT_LOAD(r3.x), s1 = QD_BIT_LOAD(r3.y), s2 = QD_BIT_LOAD(r3.z), s3 = QD_BIT_LOAD(r3.w);
+                QD_BIT_USE(r3.x, s0) QD_BIT_USE(r3.y, s1) QD_BIT_USE(r3.z, s2) QD_BIT_USE(r3.w, s3)
+            }
+            if (NCH > 4 && b0 < g.bit_thr[15]) {
+                const float4 s0 = QD_BIT_LOAD(r4.x);
+                QD_BIT_USE(r4.x, s0)
             }
             llr[b] = acc;
         }
@@ -223,10 +241,10 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------------
-template <int T, int NCH, bool WIDE, typename ADJ4>
+template <int T, int NCH, int SM, typename ADJ4>
 static hipError_t launch_bp_k(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
 {
-    auto k = qd_bp_minsum_kernel<T, NCH, WIDE, ADJ4>;
+    auto k = qd_bp_minsum_kernel<T, NCH, SM, ADJ4>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(T), g.lds_bytes, s, g, a);
@@ -236,9 +254,14 @@ static hipError_t launch_bp_k(const BpGraphDev &g, const DecodeArgs &a, int64_t 
 template <int T, int NCH>
 static hipError_t launch_bp_n(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
 {
-    const bool wide = g.max_rdeg_pad > 32;
-    if (g.adj32) return wide ? launch_bp_k<T, NCH, true, uint4>(g, a, B, s) : launch_bp_k<T, NCH, false, uint4>(g, a, B, s);
-    return wide ? launch_bp_k<T, NCH, true, uint2>(g, a, B, s) : launch_bp_k<T, NCH, false, uint2>(g, a, B, s);
+    if (g.adj32) {
+        if (g.sign_mode == 0) return launch_bp_k<T, NCH, 0, uint4>(g, a, B, s);
+        if (g.sign_mode == 1) return launch_bp_k<T, NCH, 1, uint4>(g, a, B, s);
+        return launch_bp_k<T, NCH, 2, uint4>(g, a, B, s);
+    }
+    if (g.sign_mode == 0) return launch_bp_k<T, NCH, 0, uint2>(g, a, B, s);
+    if (g.sign_mode == 1) return launch_bp_k<T, NCH, 1, uint2>(g, a, B, s);
+    return launch_bp_k<T, NCH, 2, uint2>(g, a, B, s);
 }
 
 template <int T>

@@ -147,12 +147,20 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         delete g;
         return fail(QD_ECAPACITY, "m = %d detectors per window: check-state offsets exceed 16 bits", m);
     }
-    const int adj32 = ((n_pad + 1) * 4 > 65535) ? 1 : 0;
+    if (n_pad + 1 > 32767) {
+        delete g;
+        return fail(QD_ECAPACITY, "n = %d faults per window: fault slots exceed 15 bits", n);
+    }
+    const int sign_mode = max_rdeg_pad <= 32 ? 0 : (max_rdeg_pad <= 48 ? 1 : 2);
+    const int neg_words_ = (max_rdeg_pad + 31) / 32;
+    const int off_chk_ = 0, off_cneg_ = (m_pad + 4) * 16;
+    const int off_llr_ = off_cneg_ + (sign_mode == 2 ? align16((neg_words_ - 1) * m_pad * 4) : 0);
+    const int adj32 = (off_llr_ + (n_pad + 1) * 4 > 65535) ? 1 : 0;
     const int rec_words = ((1 + max_cdeg) + 3) & ~3;
     std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0);
     std::vector<int32_t> chk_degp_w(m_pad / 64, 0);
     std::vector<uint32_t> chk_orig_u(m_pad, 0), bit_orig_u(n_pad, 0);
-    std::vector<uint32_t> bit_rec((size_t)n_pad * rec_words, (uint32_t)(dummy_chk * 16) << 16);
+    std::vector<uint32_t> bit_rec((size_t)n_pad * rec_words, (uint32_t)(off_chk_ + dummy_chk * 16) << 16);
     // CSC with the edge's position inside its row
     std::vector<int32_t> cp(n + 1, 0), ri(nnz), pos(nnz);
     for (int j = 0; j < n; ++j) cp[j + 1] = cp[j] + cdeg[j];
@@ -174,12 +182,12 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     // check -> fault adjacency, ELL-transposed, as LDS byte offsets of the posteriors
     std::vector<uint16_t> chk_adj16;
     std::vector<uint32_t> chk_adj32;
-    if (adj32) chk_adj32.assign((size_t)max_rdeg_pad * m_pad, (uint32_t)dummy_bit * 4u);
-    else chk_adj16.assign((size_t)max_rdeg_pad * m_pad, (uint16_t)(dummy_bit * 4));
+    if (adj32) chk_adj32.assign((size_t)max_rdeg_pad * m_pad, (uint32_t)(off_llr_ + dummy_bit * 4));
+    else chk_adj16.assign((size_t)max_rdeg_pad * m_pad, (uint16_t)(off_llr_ + dummy_bit * 4));
     for (int s = 0; s < m; ++s) {
         const int i = chk_orig[s];
         for (int k = 0; k < rdeg[i]; ++k) {
-            const uint32_t off = (uint32_t)bit_slot_of[col_idx[row_ptr[i] + k]] * 4u;
+            const uint32_t off = (uint32_t)off_llr_ + (uint32_t)bit_slot_of[col_idx[row_ptr[i] + k]] * 4u;
             const size_t at = ((size_t)(k >> 2) * m_pad + s) * 4 + (k & 3);      // [group of 4 edges][slot][4]: one vector load per group
             if (adj32) chk_adj32[at] = off;
             else chk_adj16[at] = (uint16_t)off;
@@ -203,7 +211,10 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             const int degp = chk_degp_w[cs / 64];
             const int w = k >> 5, kend = std::min(degp - 32 * w, 32);
             const int sbit = kend - 1 - (k & 31);              // the check pass shifts signs in from bit 0 (v_alignbit)
-            bit_rec[rec_at(s, 1 + q)] = ((uint32_t)(cs * 16) << 16) | ((uint32_t)w << 5) | (uint32_t)sbit;
+            // mode 0/1: bit index into the 64-bit value {z : w} of the state (signs 32..47 sit in z's bits 16..31)
+            const uint32_t where = sign_mode == 2 ? (((uint32_t)w << 5) | (uint32_t)sbit)
+                                                  : (uint32_t)(w == 0 ? sbit : 32 + 16 + sbit);
+            bit_rec[rec_at(s, 1 + q)] = ((uint32_t)(off_chk_ + cs * 16) << 16) | where;
         }
     }
     g->h_cp = cp; g->h_ri = ri;
@@ -212,7 +223,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     bp.m = m; bp.n = n; bp.m_pad = m_pad; bp.n_pad = n_pad; bp.max_rdeg = max_rdeg; bp.max_cdeg = max_cdeg;
     bp.neg_words = (max_rdeg_pad + 31) / 32; bp.out_words = (n + 31) / 32;
     bp.max_rdeg_pad = max_rdeg_pad; bp.dummy_bit = dummy_bit; bp.dummy_chk = dummy_chk;
-    bp.rec_words = rec_words; bp.adj32 = adj32;
+    bp.rec_words = rec_words; bp.adj32 = adj32; bp.sign_mode = sign_mode;
     for (int q = 0; q < QD_MAX_COL_DEG; ++q) {
         int cnt = 0;
         for (int w0 = 0; w0 < n_pad; w0 += 64) {
@@ -232,8 +243,12 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     // LDS carve-up for BP
     int off = 0;
     bp.off_chk = off; off += (m_pad + 4) * 16;                 // + the dummy check
-    bp.off_cneg = off; off += align16((bp.neg_words - 1) * m_pad * 4);
+    bp.off_cneg = off; off += (sign_mode == 2 ? align16((bp.neg_words - 1) * m_pad * 4) : 0);
     bp.off_llr = off; off += align16((n_pad + 4) * 4);         // + the dummy bit
+    if (bp.off_chk != off_chk_ || bp.off_cneg != off_cneg_ || bp.off_llr != off_llr_) {
+        g->mem.release(); delete g;
+        return fail(QD_EINVAL, "internal: LDS layout mismatch");
+    }
     bp.off_out = off; off += align16(bp.out_words * 4);
     bp.off_misc = off; off += 256;
     bp.lds_bytes = off;

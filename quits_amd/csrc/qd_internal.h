@@ -18,13 +18,16 @@ struct BpGraphDev {
     int max_rdeg_pad;           // max_rdeg rounded up to a multiple of 4
     int dummy_bit, dummy_chk;   // LDS slots that pad short rows/columns: llr[dummy_bit] = +inf, chk[dummy_chk] = zero message
     int rec_words;              // uint32 words per fault record (multiple of 4)
+    int sign_mode;              // 0: every check has <= 32 (padded) edges; 1: <= 48, signs 32..47 ride in the state's meta word;
+                                // 2: wider, signs 32.. live in separate LDS words
     int adj32;                  // 1: chk_adj holds uint32 entries (windows with more than 16379 fault slots), else uint16
-    const void *chk_adj;        // [max_rdeg_pad/4][m_pad][4] LDS byte offset (slot * 4) of the k-th fault of the check, k ascending =
-                                //                        original column order; dummy_bit * 4 beyond the degree
+    const void *chk_adj;        // [max_rdeg_pad/4][m_pad][4] absolute LDS byte offset (off_llr + slot * 4) of the posterior of the k-th
+                                //                        fault of the check, k ascending = original column order; the dummy bit beyond the degree
     const int32_t *chk_degp_w;  // [m_pad / 64]           trip count of a wavefront of check slots: its max degree rounded up to 4
     const uint32_t *chk_orig;   // [m_pad]                detector index of the check slot
     const uint32_t *bit_rec;    // [rec_words/4][n_pad][4] word 0 = prior LLR (float bits: log((1-p)/p) computed in double, rounded once);
-                                //                        word 1+q = (check slot * 16) << 16 | sign word index << 5 | sign bit index
+                                //                        word 1+q = (LDS byte offset of the check state) << 16 | where the check keeps this edge's
+                                //                        sign (mode 0/1: bit index 0..63 into {w, z}; mode 2: word index << 5 | bit index)
                                 //                        for the q-th check of the fault (q ascending = original row order)
     const uint32_t *bit_orig;   // [n_pad]                fault index of the bit slot
     int bit_thr[QD_MAX_COL_DEG];// bit_thr[q] = number of bit slots (multiple of 64) whose wavefront has a fault of degree > q
@@ -65,15 +68,19 @@ struct DecodeArgs {
 };
 
 // Workgroup-wide OR without static LDS (a static __shared__ object in front of the dynamic region can knock the
-// 16-byte alignment the ds_read_b128 gathers rely on).  `red` = 32 ints of dynamic LDS; `phase` alternates 0/1 between
-// successive calls so a fast wave cannot overwrite flags a slow wave still reads.  Contains one barrier.
-__device__ __forceinline__ int qd_block_or(int pred, volatile int *red, int nwaves, int phase)
+// 16-byte alignment the ds_read_b128 gathers rely on).  `red` = 32 ints of dynamic LDS, 16-byte aligned; `phase`
+// alternates 0/1 between successive calls so a fast wave cannot overwrite flags a slow wave still reads.  One barrier.
+__device__ __forceinline__ int qd_block_or(int pred, int *red, int nwaves, int phase)
 {
     const unsigned long long bal = __ballot(pred);
     if ((threadIdx.x & 63) == 0) red[phase * 16 + (threadIdx.x >> 6)] = (bal != 0ull);
     __syncthreads();
+    const int4 *r4 = reinterpret_cast<const int4 *>(red + phase * 16);
     int r = 0;
-    for (int w = 0; w < nwaves; ++w) r |= red[phase * 16 + w];
+    for (int w = 0; w < (nwaves + 3) / 4; ++w) {
+        const int4 v = r4[w];                   // slots beyond nwaves are zero (cleared once at kernel start)
+        r |= v.x | v.y | v.z | v.w;
+    }
     return r;
 }
 
