@@ -5,7 +5,8 @@
 // (oq_osd_column_order + elim_run + oq_osd0); identical results bit for bit (tests/test_gpu_parity.py).
 //
 //   1. column order: ascending posterior LLR, ties by ascending fault index  (ldpc soft_decision_col_sort; std::sort
-//      leaves ties open, this build fixes them).  Bitonic sort of 64-bit (monotone-key << 32 | index) words in LDS.
+//      leaves ties open, this build fixes them).  Keys are 64-bit (monotone-float << 32 | index) words, bitonic-sorted
+//      in LDS.
 //   2. Gaussian elimination over GF(2) in that column order, bit-packed:
 //        - rows are only ever modified by adding a pivot row, so the accumulated row transformation is the identity
 //          plus columns that belong to pivot rows; row r keeps those as a bit vector Q[r] indexed by pivot ORDER
@@ -20,6 +21,14 @@
 //          independent, their coefficients are final (the remaining pivots of ldpc's full elimination get 0).
 //          At p = 0.003 on the [[144,12,12]] window this is ~100 pivots instead of rank 1002.
 //   3. e[pivot column k] = transformed syndrome at pivot row k; everything else 0  (OSD-0).
+//
+// Two kernels share the elimination:
+//   qd_osd0_fast_kernel  sorts only the head of the order -- the <= 2048 columns with the smallest LLRs, picked with a
+//                        4096-bin histogram of the key's top bits -- and keeps <= 6..8 Q planes; ~75 KB of LDS, two
+//                        workgroups per CU.  Because elimination stops early this is enough for almost every shot; a
+//                        shot that runs out of sorted columns or of Q planes is appended to the "hard" list untouched.
+//   qd_osd0_full_kernel  sorts every column and keeps (or spills) all Q planes; one workgroup per CU; runs over the
+//                        hard list.  Same results by construction: both consume the same column order.
 #include "qd_internal.h"
 
 #define QD_NOKEY 0xFFFFFFFFu
@@ -29,117 +38,111 @@ __device__ __forceinline__ uint64_t &qd_qword(uint64_t *q_lds, uint64_t *q_glb, 
     return (w < kw_lds) ? q_lds[(size_t)w * m_pad + r] : q_glb[(size_t)(w - kw_lds) * m_pad + r];
 }
 
-template <int T>
-__global__ void __launch_bounds__(T) qd_osd0_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a)
+__device__ __forceinline__ uint32_t qd_mono_key(float llr)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x;
-    const int nfail = *a.fail_count;
-    constexpr int NW = T / 64;
-  // persistent: a fixed grid walks the list of non-converged shots; order/spill workspace is per workgroup
-  for (int slot = blockIdx.x; slot < nfail; slot += gridDim.x) {
-    const int64_t shot = a.fail_list[slot];
+    const float f = llr + 0.0f;                    // -0 -> +0, so that +-0 tie on the index like the oracle's '<'
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> unsigned
+}
 
-    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + g.off_q);      // phase 1; phase 2 reuses it as Q planes
-    uint64_t *qlds = sortbuf;
-    uint64_t *tb = reinterpret_cast<uint64_t *>(smem + g.off_tb);          // [m_pad] image of the 64 batch columns
-    uint8_t *sp = smem + g.off_sp;                                         // [m_pad] transformed syndrome
-    int16_t *rowpiv = reinterpret_cast<int16_t *>(smem + g.off_rowpiv);    // [m_pad] row -> pivot order or -1
-    uint16_t *prow = reinterpret_cast<uint16_t *>(smem + g.off_prow);      // [m_pad] pivot order -> row
-    uint32_t *pcol = reinterpret_cast<uint32_t *>(smem + g.off_pcol);      // [m_pad] pivot order -> fault
-    uint32_t *pairs = reinterpret_cast<uint32_t *>(smem + g.off_pairs);    // [64 * max_cdeg] column-in-batch | pivot order << 8
-    uint32_t *bcols = reinterpret_cast<uint32_t *>(smem + g.off_cols);     // [64]
-    volatile uint32_t *red = reinterpret_cast<volatile uint32_t *>(smem + g.off_red); // [0..15] keys A, [16..31] keys B, [32..63] flags, [64] npairs
-    uint32_t *outw = reinterpret_cast<uint32_t *>(smem + g.off_out);
-    uint16_t *order = a.order_ws + (int64_t)blockIdx.x * g.n;
-    uint64_t *qglb = a.q_spill ? a.q_spill + (int64_t)blockIdx.x * (int64_t)(g.mw - g.kw_lds) * g.m_pad : nullptr;
-
-    // ---------------- 1. column order
-    const float *llr = a.llr_ws + (int64_t)slot * bg.n_pad;
-    for (int i = tid; i < g.npow2; i += T) sortbuf[i] = ~0ull;
-    __syncthreads();
-    for (int b = tid; b < g.n; b += T) {
-        const float f = llr[b] + 0.0f;                    // -0 -> +0, so that +-0 tie on the index like the oracle's '<'
-        uint32_t u = __float_as_uint(f);
-        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // monotone float -> unsigned
-        const uint32_t j = bg.bit_orig[b];
-        sortbuf[j] = ((uint64_t)u << 32) | j;
-    }
-    __syncthreads();
-    for (int k = 2; k <= g.npow2; k <<= 1)
+template <int T>
+__device__ __forceinline__ void qd_bitonic_u64(uint64_t *buf, int P, int tid)
+{
+    for (int k = 2; k <= P; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int pi = tid; pi < (g.npow2 >> 1); pi += T) {
+            for (int pi = tid; pi < (P >> 1); pi += T) {
                 const int i = ((pi & ~(j - 1)) << 1) | (pi & (j - 1));
                 const int l = i | j;
-                const uint64_t x = sortbuf[i], y = sortbuf[l];
+                const uint64_t x = buf[i], y = buf[l];
                 const bool up = ((i & k) == 0);
-                if ((x > y) == up) { sortbuf[i] = y; sortbuf[l] = x; }
+                if ((x > y) == up) { buf[i] = y; buf[l] = x; }
             }
             __syncthreads();
         }
-    for (int i = tid; i < g.n; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
-    __syncthreads();   // order[] is re-read by this workgroup only (global, same CU -> L1/L2 coherent for own stores after the barrier's vmcnt drain)
+}
 
-    // ---------------- 2. elimination state
-    const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
-    const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
+struct OsdLds {
+    uint64_t *q;          // Q planes resident in LDS
+    uint64_t *tb;         // [m_pad] image of the 64 batch columns
+    uint8_t *sp;          // [m_pad] transformed syndrome
+    int16_t *rowpiv;      // [m_pad] row -> pivot order or -1
+    uint16_t *prow;       // [m_pad] pivot order -> row
+    uint32_t *pcol;       // [m_pad] pivot order -> fault
+    uint32_t *pairs;      // [64 * max_cdeg] column-in-batch | pivot order << 8
+    uint32_t *bcols;      // [64]
+    uint32_t *red;        // [0..15] keys A, [16..31] keys B, [32..63] flags, [64] counter
+    uint32_t *outw;       // packed solution
+};
+
+// Elimination over order[0..ncols).  kcap = number of pivots the Q storage can hold.
+// Returns 0 when finished (early stop, rank exhausted or every column consumed with ncols == n), 1 when it ran out of
+// sorted columns (ncols < n) or of Q capacity before finishing -- the caller must then redo the shot with more.
+template <int T>
+__device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t *qglb, int kw_lds, int kcap,
+                                const uint16_t *order, int ncols, const uint8_t *det, const uint8_t *upd,
+                                int upd_rows, int out_words, int *npiv_out, int *inconsistent_out)
+{
+    const int tid = threadIdx.x;
+    constexpr int NW = T / 64;
+    volatile uint32_t *red = S.red;
     for (int r = tid; r < g.m_pad; r += T) {
         uint8_t s = 0;
         if (r < g.m) {
             s = det[r] & 1u;
-            if (upd && r < a.upd_rows) s ^= upd[r] & 1u;
+            if (upd && r < upd_rows) s ^= upd[r] & 1u;
         }
-        sp[r] = s;
-        rowpiv[r] = -1;
+        S.sp[r] = s;
+        S.rowpiv[r] = -1;
     }
-    for (int i = tid; i < g.kw_lds * g.m_pad; i += T) qlds[i] = 0ull;
+    for (int i = tid; i < kw_lds * g.m_pad; i += T) S.q[i] = 0ull;
     if (qglb)
-        for (int i = tid; i < (g.mw - g.kw_lds) * g.m_pad; i += T) qglb[i] = 0ull;
-    for (int w = tid; w < bg.out_words; w += T) outw[w] = 0u;
+        for (int i = tid; i < (g.mw - kw_lds) * g.m_pad; i += T) qglb[i] = 0ull;
+    for (int w = tid; w < out_words; w += T) S.outw[w] = 0u;
     __syncthreads();
 
-    int npiv = 0, done = 0, inconsistent = 0;
-    for (int base = 0; base < g.n && !done; base += 64) {
+    int npiv = 0, done = 0, hard = 0;
+    for (int base = 0; base < ncols && !done && !hard; base += 64) {
         // ---- transform the next 64 columns: tb[r] bit c = (T * column_c)[r]
-        for (int r = tid; r < g.m_pad; r += T) tb[r] = 0ull;
+        for (int r = tid; r < g.m_pad; r += T) S.tb[r] = 0ull;
         if (tid == 0) red[64] = 0u;
-        if (tid < 64) bcols[tid] = (base + tid < g.n) ? (uint32_t)order[base + tid] : 0xFFFFFFFFu;
+        if (tid < 64) S.bcols[tid] = (base + tid < ncols) ? (uint32_t)order[base + tid] : 0xFFFFFFFFu;
         __syncthreads();
         for (int x = tid; x < 64 * g.max_cdeg; x += T) {
             const int c = x / g.max_cdeg, q = x - c * g.max_cdeg;
-            const uint32_t col = bcols[c];
+            const uint32_t col = S.bcols[c];
             if (col != 0xFFFFFFFFu) {
                 const uint32_t e0 = g.csc_ptr[col], e1 = g.csc_ptr[col + 1];
                 if (e0 + q < e1) {
                     const int r = g.csc_row[e0 + q];
-                    atomicXor(reinterpret_cast<unsigned long long *>(&tb[r]), 1ull << c);
-                    const int k = rowpiv[r];
-                    if (k >= 0) pairs[atomicAdd(const_cast<uint32_t *>(&red[64]), 1u)] = (uint32_t)c | ((uint32_t)k << 8);
+                    atomicXor(reinterpret_cast<unsigned long long *>(&S.tb[r]), 1ull << c);
+                    const int k = S.rowpiv[r];
+                    if (k >= 0) S.pairs[atomicAdd(const_cast<uint32_t *>(&red[64]), 1u)] = (uint32_t)c | ((uint32_t)k << 8);
                 }
             }
         }
         __syncthreads();
         const int np = (int)red[64];
-        for (int r = tid; r < g.m; r += T) {
-            uint64_t x = tb[r];
-            for (int i = 0; i < np; ++i) {
-                const uint32_t pr = pairs[i];
-                const int k = (int)(pr >> 8);
-                const uint64_t qw = qd_qword(qlds, qglb, g.kw_lds, g.m_pad, k >> 6, r);
-                x ^= ((qw >> (k & 63)) & 1ull) << (pr & 63u);
+        if (np)
+            for (int r = tid; r < g.m; r += T) {
+                uint64_t x = S.tb[r];
+                for (int i = 0; i < np; ++i) {
+                    const uint32_t pr = S.pairs[i];
+                    const int k = (int)(pr >> 8);
+                    const uint64_t qw = qd_qword(S.q, qglb, kw_lds, g.m_pad, k >> 6, r);
+                    x ^= ((qw >> (k & 63)) & 1ull) << (pr & 63u);
+                }
+                S.tb[r] = x;
             }
-            tb[r] = x;
-        }
         // ---- take pivots out of the batch, in column order
         int phase = 0;
         for (;;) {
             uint32_t key = QD_NOKEY;
             int resid = 0;
             for (int r = tid; r < g.m; r += T)
-                if (rowpiv[r] < 0) {
-                    const uint64_t x = tb[r];
+                if (S.rowpiv[r] < 0) {
+                    const uint64_t x = S.tb[r];
                     if (x) key = min(key, ((uint32_t)__builtin_ctzll(x) << 16) | (uint32_t)r);
-                    resid |= sp[r];
+                    resid |= S.sp[r];
                 }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o));
@@ -152,77 +155,225 @@ __global__ void __launch_bounds__(T) qd_osd0_kernel(OsdGraphDev g, BpGraphDev bg
             phase ^= 1;
             if (!anyres) { done = 1; break; }            // syndrome already in the span of the pivots found
             if (key == QD_NOKEY) break;                   // rest of the batch depends on earlier pivots
+            if (npiv >= kcap) { hard = 1; break; }        // no room for another pivot in this kernel's Q storage
             const int c = (int)(key >> 16), p = (int)(key & 0xFFFFu);
             const int K = npiv, kw = K >> 6;
             const uint64_t kb = 1ull << (K & 63);
-            const uint64_t tp = tb[p];
-            const uint8_t spp = sp[p];
+            const uint64_t tp = S.tb[p];
+            const uint8_t spp = S.sp[p];
             for (int r = tid; r < g.m; r += T)
-                if (r != p && ((tb[r] >> c) & 1ull)) {
-                    tb[r] ^= tp;
-                    sp[r] ^= spp;
+                if (r != p && ((S.tb[r] >> c) & 1ull)) {
+                    S.tb[r] ^= tp;
+                    S.sp[r] ^= spp;
                     for (int w = 0; w <= kw; ++w) {
-                        uint64_t &dst = qd_qword(qlds, qglb, g.kw_lds, g.m_pad, w, r);
-                        uint64_t v = dst ^ qd_qword(qlds, qglb, g.kw_lds, g.m_pad, w, p);
+                        uint64_t &dst = qd_qword(S.q, qglb, kw_lds, g.m_pad, w, r);
+                        uint64_t v = dst ^ qd_qword(S.q, qglb, kw_lds, g.m_pad, w, p);
                         if (w == kw) v ^= kb;
                         dst = v;
                     }
                 }
             // nobody reads rowpiv/prow/pcol during the update, so the new pivot can be recorded alongside it
-            if (tid == 0) { rowpiv[p] = (int16_t)K; prow[K] = (uint16_t)p; pcol[K] = bcols[c]; }
+            if (tid == 0) { S.rowpiv[p] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = S.bcols[c]; }
             npiv = K + 1;
             __syncthreads();                              // updated rows + the pivot record, before the next round
         }
     }
+    if (!done && !hard && ncols < g.n) {
+        // out of sorted columns: finished only if the syndrome happens to be resolved already or no row is left
+        int resid = 0;
+        for (int r = tid; r < g.m; r += T)
+            if (S.rowpiv[r] < 0) resid |= S.sp[r];
+        const unsigned long long bal = __ballot(resid);
+        __syncthreads();
+        if ((tid & 63) == 0) red[32 + (tid >> 6)] = (bal != 0ull);
+        __syncthreads();
+        int anyres = 0;
+        for (int w = 0; w < NW; ++w) anyres |= (int)red[32 + w];
+        if (anyres && npiv < g.m) hard = 1;
+        __syncthreads();
+    }
+    if (hard) return 1;
     // residual left on a non-pivot row <=> syndrome outside the column space
+    int inconsistent = 0;
     {
         int resid = 0;
         for (int r = tid; r < g.m; r += T)
-            if (rowpiv[r] < 0) resid |= sp[r];
+            if (S.rowpiv[r] < 0) resid |= S.sp[r];
         const unsigned long long bal = __ballot(resid);
         __syncthreads();
         if ((tid & 63) == 0) red[32 + (tid >> 6)] = (bal != 0ull);
         __syncthreads();
         for (int w = 0; w < NW; ++w) inconsistent |= (int)red[32 + w];
     }
-    // ---------------- 3. OSD-0 solution
+    // OSD-0 solution
     for (int k = tid; k < npiv; k += T)
-        if (sp[prow[k]]) {
-            const uint32_t j = pcol[k];
-            atomicOr(&outw[j >> 5], 1u << (j & 31u));
+        if (S.sp[S.prow[k]]) {
+            const uint32_t j = S.pcol[k];
+            atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
         }
     __syncthreads();
-    for (int w = tid; w < bg.out_words; w += T) a.err_bits[shot * bg.out_words + w] = outw[w];
-    if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
-    __syncthreads();   // LDS is recycled by the next shot
-  }
+    *npiv_out = npiv;
+    *inconsistent_out = inconsistent;
+    return 0;
 }
 
-hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t cap /* workgroups */, hipStream_t s)
+__device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off, OsdLds &S)
+{
+    S.q = reinterpret_cast<uint64_t *>(smem + off[0]);
+    S.tb = reinterpret_cast<uint64_t *>(smem + off[1]);
+    S.sp = smem + off[2];
+    S.rowpiv = reinterpret_cast<int16_t *>(smem + off[3]);
+    S.prow = reinterpret_cast<uint16_t *>(smem + off[4]);
+    S.pcol = reinterpret_cast<uint32_t *>(smem + off[5]);
+    S.pairs = reinterpret_cast<uint32_t *>(smem + off[6]);
+    S.bcols = reinterpret_cast<uint32_t *>(smem + off[7]);
+    S.red = reinterpret_cast<uint32_t *>(smem + off[8]);
+    S.outw = reinterpret_cast<uint32_t *>(smem + off[9]);
+}
+
+// ---- fast path: head of the order only --------------------------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(T, T / 128) qd_osd0_fast_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int nfail = *a.fail_count;
+    OsdLds S;
+    qd_osd_carve(smem, g.f_off, S);
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + g.f_off_hist);        // [4096], overlaps the Q planes (phase 1 only)
+    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + g.f_off_sort);     // [QD_OSD_FAST_CAP], overlaps the Q planes
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem + g.f_off_order);      // [QD_OSD_FAST_CAP]
+    volatile uint32_t *red = S.red;
+    for (int slot = blockIdx.x; slot < nfail; slot += gridDim.x) {
+        const int64_t shot = a.fail_list[slot];
+        const float *llr = a.llr_ws + (int64_t)slot * bg.n_pad;
+        // ---- 1a. histogram of the top 12 key bits; hi = largest bin count whose cumulative size fits the sort buffer
+        for (int i = tid; i < 4096; i += T) hist[i] = 0u;
+        if (tid == 0) { red[64] = 0u; red[65] = 0u; }
+        __syncthreads();
+        for (int b = tid; b < g.n; b += T) atomicAdd(&hist[qd_mono_key(llr[b]) >> 20], 1u);
+        __syncthreads();
+        {
+            // each thread owns 4096 / T consecutive bins; exclusive prefix over threads, then mark the last bin that fits
+            constexpr int PER = 4096 / T;
+            uint32_t loc[PER];
+            uint32_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) { loc[i] = hist[tid * PER + i]; sum += loc[i]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+                if ((tid & 63) >= o) incl += v;
+            }
+            if ((tid & 63) == 63) red[tid >> 6] = incl;          // wave totals
+            __syncthreads();
+            uint32_t wbase = 0;
+            for (int w = 0; w < (tid >> 6); ++w) wbase += red[w];
+            uint32_t cum = wbase + incl - sum;
+            uint32_t best = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                cum += loc[i];
+                if (cum <= (uint32_t)QD_OSD_FAST_CAP) best = (uint32_t)(tid * PER + i + 1);
+            }
+            if (best) atomicMax(const_cast<uint32_t *>(&red[64]), best);
+            __syncthreads();
+        }
+        const uint32_t hi = red[64];
+        // ---- 1b. gather and sort the head
+        for (int b = tid; b < g.n; b += T) {
+            const uint32_t u = qd_mono_key(llr[b]);
+            if ((u >> 20) < hi) sortbuf[atomicAdd(const_cast<uint32_t *>(&red[65]), 1u)] = ((uint64_t)u << 32) | bg.bit_orig[b];
+        }
+        __syncthreads();
+        const int cnt = (int)red[65];
+        int P = 64;
+        while (P < cnt) P <<= 1;
+        for (int i = cnt + tid; i < P; i += T) sortbuf[i] = ~0ull;
+        __syncthreads();
+        qd_bitonic_u64<T>(sortbuf, P, tid);
+        for (int i = tid; i < cnt; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
+        __syncthreads();
+        // ---- 2./3. elimination on the head
+        const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
+        const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
+        int npiv = 0, inconsistent = 0;
+        const int rc = qd_osd_eliminate<T>(g, S, nullptr, g.f_kw, g.f_kw * 64, order, cnt, det, upd, a.upd_rows,
+                                           bg.out_words, &npiv, &inconsistent);
+        if (rc) {
+            if (tid == 0) a.hard_list[atomicAdd(a.hard_count, 1)] = slot;
+        } else {
+            for (int w = tid; w < bg.out_words; w += T) a.err_bits[shot * bg.out_words + w] = S.outw[w];
+            if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
+        }
+        __syncthreads();   // LDS is recycled by the next shot
+    }
+}
+
+// ---- full path: every column sorted, every Q plane available ------------------------------------------------------------
+template <int T>
+__global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a, int use_hard_list)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int nlist = use_hard_list ? *a.hard_count : *a.fail_count;
+    OsdLds S;
+    qd_osd_carve(smem, g.off, S);
+    uint64_t *sortbuf = S.q;                                                    // phase 1; phase 2 reuses it as Q planes
+    // persistent: a fixed grid walks the list; order/spill workspace is per workgroup
+    for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int slot = use_hard_list ? a.hard_list[li] : li;
+        const int64_t shot = a.fail_list[slot];
+        uint16_t *order = a.order_ws + (int64_t)blockIdx.x * g.n;
+        uint64_t *qglb = a.q_spill ? a.q_spill + (int64_t)blockIdx.x * (int64_t)(g.mw - g.kw_lds) * g.m_pad : nullptr;
+        const float *llr = a.llr_ws + (int64_t)slot * bg.n_pad;
+        for (int i = tid; i < g.npow2; i += T) sortbuf[i] = ~0ull;
+        __syncthreads();
+        for (int b = tid; b < g.n; b += T) {
+            const uint32_t j = bg.bit_orig[b];
+            sortbuf[j] = ((uint64_t)qd_mono_key(llr[b]) << 32) | j;
+        }
+        __syncthreads();
+        qd_bitonic_u64<T>(sortbuf, g.npow2, tid);
+        for (int i = tid; i < g.n; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
+        __syncthreads();   // order[] is re-read by this workgroup only (same CU; the barrier drains the stores)
+        const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
+        const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
+        int npiv = 0, inconsistent = 0;
+        qd_osd_eliminate<T>(g, S, qglb, g.kw_lds, g.m, order, g.n, det, upd, a.upd_rows, bg.out_words, &npiv, &inconsistent);
+        for (int w = tid; w < bg.out_words; w += T) a.err_bits[shot * bg.out_words + w] = S.outw[w];
+        if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
+        __syncthreads();   // LDS is recycled by the next shot
+    }
+}
+
+template <int T>
+static hipError_t launch_osd_t(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
+                               int blocks_full, hipStream_t s)
 {
     hipError_t e;
-    switch (g.threads) {
-    case 256: {
-        auto k = qd_osd0_kernel<256>;
-        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
+    auto kf = qd_osd0_full_kernel<T>;
+    e = hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
+    if (e != hipSuccess) return e;
+    if (g.f_lds_bytes > 0) {
+        auto kq = qd_osd0_fast_kernel<T>;
+        e = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, g.f_lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)cap), dim3(256), g.lds_bytes, s, g, bg, a);
-        break;
-    }
-    case 512: {
-        auto k = qd_osd0_kernel<512>;
-        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)cap), dim3(512), g.lds_bytes, s, g, bg, a);
-        break;
-    }
-    default: {
-        auto k = qd_osd0_kernel<1024>;
-        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned)cap), dim3(1024), g.lds_bytes, s, g, bg, a);
-        break;
-    }
+        hipLaunchKernelGGL(kq, dim3((unsigned)blocks_fast), dim3(T), g.f_lds_bytes, s, g, bg, a);
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, 1);
+    } else {
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, 0);
     }
     return hipGetLastError();
+}
+
+hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
+                          int blocks_full, hipStream_t s)
+{
+    switch (g.threads) {
+    case 256: return launch_osd_t<256>(g, bg, a, blocks_fast, blocks_full, s);
+    case 512: return launch_osd_t<512>(g, bg, a, blocks_fast, blocks_full, s);
+    default: return launch_osd_t<1024>(g, bg, a, blocks_fast, blocks_full, s);
+    }
 }

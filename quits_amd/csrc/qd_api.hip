@@ -11,7 +11,8 @@
 #include <vector>
 
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
-hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t cap, hipStream_t s);
+hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
+                          int blocks_full, hipStream_t s);
 hipError_t qd_launch_spmv(const SpmatDev &A, const uint32_t *err, int64_t err_stride, int64_t B, uint8_t *out,
                           int64_t out_stride, int accumulate, hipStream_t s);
 hipError_t qd_launch_unpack(const uint32_t *bits, int64_t stride_words, int nbits, int64_t B, uint8_t *out,
@@ -75,6 +76,8 @@ struct qd_decoder {
     int32_t *fail_list = nullptr, *fail_count = nullptr;
     uint16_t *order_ws = nullptr;
     uint64_t *q_spill = nullptr;
+    int32_t *hard_list = nullptr;
+    int osd_blocks_fast = 0;
     int profiling = 0;
     std::vector<hipEvent_t> ev;        // triples (bp start, bp end / osd start, osd end)
     double acc_ms[4] = {0, 0, 0, 0};
@@ -266,30 +269,43 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     rc |= g->mem.upload(csc_ptr, &od.csc_ptr);
     rc |= g->mem.upload(csc_row, &od.csc_row);
     if (rc) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation/upload failed"); }
-    const int small = align16(m_pad * 8) /*tb*/ + align16(m_pad) /*sp*/ + align16(m_pad * 2) * 2 /*rowpiv,prow*/ +
-                      align16(m_pad * 4) /*pcol*/ + align16(64 * max_cdeg * 4) /*pairs*/ + 256 /*cols*/ + 512 /*red*/ +
-                      align16(bp.out_words * 4);
+    auto carve = [&](int *offs, int qbytes, int base) {
+        int o = base;
+        offs[0] = o; o += align16(qbytes);
+        offs[1] = o; o += align16(m_pad * 8);          // tb
+        offs[2] = o; o += align16(m_pad);              // sp
+        offs[3] = o; o += align16(m_pad * 2);          // rowpiv
+        offs[4] = o; o += align16(m_pad * 2);          // prow
+        offs[5] = o; o += align16(m_pad * 4);          // pcol
+        offs[6] = o; o += align16(64 * max_cdeg * 4);  // pairs
+        offs[7] = o; o += 256;                         // cols
+        offs[8] = o; o += 512;                         // red
+        offs[9] = o; o += align16(bp.out_words * 4);   // out
+        return o;
+    };
+    int tmp[10];
+    const int small = carve(tmp, 0, 0);
     const int q_budget = QD_LDS_BYTES - small - 64;
     const int sort_bytes = np2 * 8;
+    od.threads = m <= 256 ? 256 : (m <= 512 ? 512 : 1024);
     if (sort_bytes > q_budget) {
-        // BP still runs; OSD needs the sort buffer in LDS
-        od.lds_bytes = 0; od.kw_lds = 0; od.threads = 0;
+        // BP still runs; the full OSD kernel needs its sort buffer in LDS
+        od.lds_bytes = 0; od.kw_lds = 0; od.f_lds_bytes = 0; od.f_kw = 0;
     } else {
         od.kw_lds = std::min(od.mw, q_budget / (m_pad * 8));
-        const int qbytes = std::max(sort_bytes, od.kw_lds * m_pad * 8);
-        off = 0;
-        od.off_q = off; off += align16(qbytes);
-        od.off_tb = off; off += align16(m_pad * 8);
-        od.off_sp = off; off += align16(m_pad);
-        od.off_rowpiv = off; off += align16(m_pad * 2);
-        od.off_prow = off; off += align16(m_pad * 2);
-        od.off_pcol = off; off += align16(m_pad * 4);
-        od.off_pairs = off; off += align16(64 * max_cdeg * 4);
-        od.off_cols = off; off += 256;
-        od.off_red = off; off += 512;
-        od.off_out = off; off += align16(bp.out_words * 4);
-        od.lds_bytes = off;
-        od.threads = m <= 256 ? 256 : (m <= 512 ? 512 : 1024);
+        od.lds_bytes = carve(od.off, std::max(sort_bytes, od.kw_lds * m_pad * 8), 0);
+        // fast kernel: aim at two workgroups per CU
+        const int head = 4096 * 4 + QD_OSD_FAST_CAP * 8;                       // histogram + sort buffer
+        const int order_bytes = align16(QD_OSD_FAST_CAP * 2);
+        const int f_budget = QD_LDS_BYTES / 2 - 256 - small - order_bytes;
+        od.f_kw = std::min(od.mw, std::max(1, f_budget / (m_pad * 8)));
+        const int ubytes = std::max(head, od.f_kw * m_pad * 8);
+        int o = carve(od.f_off, ubytes, 0);
+        od.f_off_hist = od.f_off[0];
+        od.f_off_sort = od.f_off[0] + 4096 * 4;
+        od.f_off_order = o; o += order_bytes;
+        od.f_lds_bytes = o;
+        if (od.f_lds_bytes > QD_LDS_BYTES) od.f_lds_bytes = 0;                // cannot happen for m the BP kernel accepts
     }
     if (bp.lds_bytes > QD_LDS_BYTES) {
         g->mem.release();
@@ -373,6 +389,8 @@ static void free_ws(qd_decoder *d)
     if (d->fail_count) (void)hipFree(d->fail_count);
     if (d->order_ws) (void)hipFree(d->order_ws);
     if (d->q_spill) (void)hipFree(d->q_spill);
+    if (d->hard_list) (void)hipFree(d->hard_list);
+    d->hard_list = nullptr;
     d->llr_ws = nullptr; d->fail_list = nullptr; d->fail_count = nullptr; d->order_ws = nullptr; d->q_spill = nullptr;
     d->cap = 0;
 }
@@ -403,6 +421,9 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         const int per_cu = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.lds_bytes));
         d->osd_blocks = ncu * std::min(per_cu, 2048 / g->osd.threads);
+        const int per_cu_fast = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.f_lds_bytes));
+        d->osd_blocks_fast = ncu * std::min(per_cu_fast, 2048 / g->osd.threads);
+        HIP_TRY(hipMalloc((void **)&d->hard_list, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->llr_ws, sizeof(float) * (size_t)max_batch * g->bp.n_pad));
         HIP_TRY(hipMalloc((void **)&d->fail_list, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->order_ws, sizeof(uint16_t) * (size_t)d->osd_blocks * g->n));
@@ -462,7 +483,8 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
     a.err_bits = d_err_bits; a.status = d_status;
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
     a.order_ws = d->order_ws; a.q_spill = d->q_spill;
-    HIP_TRY(hipMemsetAsync(d->fail_count, 0, sizeof(int32_t), s));
+    a.hard_list = d->hard_list; a.hard_count = d->fail_count + 1;
+    HIP_TRY(hipMemsetAsync(d->fail_count, 0, 2 * sizeof(int32_t), s));
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (d->profiling) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
@@ -471,7 +493,9 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
     }
     HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
     if (d->profiling) HIP_TRY(hipEventRecord(e1, s));
-    if (osd) HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, std::min<int64_t>(B, d->osd_blocks), s));
+    if (osd)
+        HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
+                               (int)std::min<int64_t>(B, d->osd_blocks), s));
     if (d->profiling) HIP_TRY(hipEventRecord(e2, s));
     return QD_OK;
 }

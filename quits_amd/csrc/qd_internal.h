@@ -36,15 +36,20 @@ struct BpGraphDev {
     int threads;
 };
 
+#define QD_OSD_FAST_CAP 2048   // columns the fast OSD kernel sorts (the head of the order)
+
 // Elimination (OSD) view: original indexing.
 struct OsdGraphDev {
     int m, n, m_pad, max_cdeg;
     int mw;                     // words per Q row = ceil(m / 64)
-    int npow2;                  // bitonic sort size
-    int kw_lds;                 // Q word-planes that live in LDS; planes >= kw_lds spill to global
+    int npow2;                  // bitonic sort size of the full kernel
+    int kw_lds;                 // full kernel: Q word-planes that live in LDS; planes >= kw_lds spill to global
     const uint32_t *csc_ptr;    // [n + 1]
     const uint16_t *csc_row;    // [nnz]  detector index, ascending inside a column
-    int off_q, off_tb, off_sp, off_rowpiv, off_prow, off_pcol, off_pairs, off_cols, off_red, off_out, lds_bytes;
+    // LDS carve-up of the full kernel: off[] = q, tb, sp, rowpiv, prow, pcol, pairs, cols, red, out
+    int off[10], lds_bytes;
+    // ... and of the fast kernel (Q planes overlap the histogram + sort buffer); f_lds_bytes = 0 disables it
+    int f_off[10], f_off_hist, f_off_sort, f_off_order, f_kw, f_lds_bytes;
     int threads;
 };
 
@@ -63,8 +68,10 @@ struct DecodeArgs {
     float *llr_ws;              // [cap][n_pad]  posterior by bit slot, one row per non-converged shot
     int32_t *fail_list;         // [cap]
     int32_t *fail_count;        // [1]
-    uint16_t *order_ws;         // [cap][n]      sorted column order (OSD)
-    uint64_t *q_spill;          // [cap][(mw - kw_lds)][m_pad]
+    uint16_t *order_ws;         // [blocks][n]   sorted column order (full OSD kernel)
+    uint64_t *q_spill;          // [blocks][(mw - kw_lds)][m_pad]
+    int32_t *hard_list;         // [cap]         fail-list slots the fast OSD kernel could not finish
+    int32_t *hard_count;        // [1]
 };
 
 // Workgroup-wide OR without static LDS (a static __shared__ object in front of the dynamic region can knock the
