@@ -23,8 +23,8 @@
 //   3. e[pivot column k] = transformed syndrome at pivot row k; everything else 0  (OSD-0).
 //
 // Two kernels share the elimination:
-//   qd_osd0_fast_kernel  sorts only the head of the order -- the <= 2048 columns with the smallest LLRs, picked with a
-//                        4096-bin histogram of the key's top bits -- and keeps <= 6..8 Q planes; ~75 KB of LDS, two
+//   qd_osd0_fast_kernel  sorts only the head of the order -- the <= 2048 columns with the smallest LLRs, picked by
+//                        bisecting on the key's top 12 bits -- and keeps <= 6..8 Q planes; ~75 KB of LDS, two
 //                        workgroups per CU.  Because elimination stops early this is enough for almost every shot; a
 //                        shot that runs out of sorted columns or of Q planes is appended to the "hard" list untouched.
 //   qd_osd0_full_kernel  sorts every column and keeps (or spills) all Q planes; one workgroup per CU; runs over the
@@ -84,7 +84,7 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
 {
     const int tid = threadIdx.x;
     constexpr int NW = T / 64;
-    volatile uint32_t *red = S.red;
+    uint32_t *red = S.red;
     for (int r = tid; r < g.m_pad; r += T) {
         uint8_t s = 0;
         if (r < g.m) {
@@ -98,6 +98,8 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
     if (qglb)
         for (int i = tid; i < (g.mw - kw_lds) * g.m_pad; i += T) qglb[i] = 0ull;
     for (int w = tid; w < out_words; w += T) S.outw[w] = 0u;
+    if (tid < 32) red[tid] = QD_NOKEY;
+    else if (tid < 64) red[tid] = 0u;
     __syncthreads();
 
     int npiv = 0, done = 0, hard = 0;
@@ -116,7 +118,7 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
                     const int r = g.csc_row[e0 + q];
                     atomicXor(reinterpret_cast<unsigned long long *>(&S.tb[r]), 1ull << c);
                     const int k = S.rowpiv[r];
-                    if (k >= 0) S.pairs[atomicAdd(const_cast<uint32_t *>(&red[64]), 1u)] = (uint32_t)c | ((uint32_t)k << 8);
+                    if (k >= 0) S.pairs[atomicAdd(&red[64], 1u)] = (uint32_t)c | ((uint32_t)k << 8);
                 }
             }
         }
@@ -151,7 +153,16 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
             __syncthreads();
             key = QD_NOKEY;
             int anyres = 0;
-            for (int w = 0; w < NW; ++w) { key = min(key, (uint32_t)red[phase * 16 + w]); anyres |= (int)red[32 + phase * 16 + w]; }
+            {
+                const uint4 *kv = reinterpret_cast<const uint4 *>(red + phase * 16);
+                const uint4 *fv = reinterpret_cast<const uint4 *>(red + 32 + phase * 16);
+#pragma unroll
+                for (int w = 0; w < (NW + 3) / 4; ++w) {       // entries beyond NW hold NOKEY / 0 (set once per kernel)
+                    const uint4 k4 = kv[w], f4 = fv[w];
+                    key = min(key, min(min(k4.x, k4.y), min(k4.z, k4.w)));
+                    anyres |= (int)(f4.x | f4.y | f4.z | f4.w);
+                }
+            }
             phase ^= 1;
             if (!anyres) { done = 1; break; }            // syndrome already in the span of the pivots found
             if (key == QD_NOKEY) break;                   // rest of the batch depends on earlier pivots
@@ -240,51 +251,44 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_fast_kernel(OsdGraphDev g,
     const int nfail = *a.fail_count;
     OsdLds S;
     qd_osd_carve(smem, g.f_off, S);
-    uint32_t *hist = reinterpret_cast<uint32_t *>(smem + g.f_off_hist);        // [4096], overlaps the Q planes (phase 1 only)
     uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + g.f_off_sort);     // [QD_OSD_FAST_CAP], overlaps the Q planes
     uint16_t *order = reinterpret_cast<uint16_t *>(smem + g.f_off_order);      // [QD_OSD_FAST_CAP]
-    volatile uint32_t *red = S.red;
+    uint32_t *red = S.red;
     for (int slot = blockIdx.x; slot < nfail; slot += gridDim.x) {
         const int64_t shot = a.fail_list[slot];
         const float *llr = a.llr_ws + (int64_t)slot * bg.n_pad;
-        // ---- 1a. histogram of the top 12 key bits; hi = largest bin count whose cumulative size fits the sort buffer
-        for (int i = tid; i < 4096; i += T) hist[i] = 0u;
-        if (tid == 0) { red[64] = 0u; red[65] = 0u; }
+        // ---- 1a. hi = largest number of leading key bins (top 12 bits) whose population fits the sort buffer.
+        //      Bisection on counts: 12 rounds of (compare, wave popcount, one LDS add per wave).
+        uint32_t lo_b = 0, hi_b = 4096;                      // invariant: count(bin < lo_b) <= CAP
+        if (tid < 16) red[tid] = 0u;
         __syncthreads();
-        for (int b = tid; b < g.n; b += T) atomicAdd(&hist[qd_mono_key(llr[b]) >> 20], 1u);
-        __syncthreads();
-        {
-            // each thread owns 4096 / T consecutive bins; exclusive prefix over threads, then mark the last bin that fits
-            constexpr int PER = 4096 / T;
-            uint32_t loc[PER];
-            uint32_t sum = 0;
+        for (int it = 0; it < 12; ++it) {
+            const uint32_t mid = (lo_b + hi_b + 1) >> 1;
+            uint32_t c = 0;
+            for (int b = tid; b < g.n; b += T) c += ((qd_mono_key(llr[b]) >> 20) < mid) ? 1u : 0u;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) { loc[i] = hist[tid * PER + i]; sum += loc[i]; }
-            uint32_t incl = sum;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
-                if ((tid & 63) >= o) incl += v;
-            }
-            if ((tid & 63) == 63) red[tid >> 6] = incl;          // wave totals
+            for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+            if ((tid & 63) == 0) atomicAdd(&red[it & 1], c);
             __syncthreads();
-            uint32_t wbase = 0;
-            for (int w = 0; w < (tid >> 6); ++w) wbase += red[w];
-            uint32_t cum = wbase + incl - sum;
-            uint32_t best = 0;
-#pragma unroll
-            for (int i = 0; i < PER; ++i) {
-                cum += loc[i];
-                if (cum <= (uint32_t)QD_OSD_FAST_CAP) best = (uint32_t)(tid * PER + i + 1);
-            }
-            if (best) atomicMax(const_cast<uint32_t *>(&red[64]), best);
+            const uint32_t tot = red[it & 1];
+            if (tot <= (uint32_t)QD_OSD_FAST_CAP) lo_b = mid; else hi_b = mid - 1;
+            if (tid == 0) red[(it + 1) & 1] = 0u;
             __syncthreads();
         }
-        const uint32_t hi = red[64];
-        // ---- 1b. gather and sort the head
-        for (int b = tid; b < g.n; b += T) {
-            const uint32_t u = qd_mono_key(llr[b]);
-            if ((u >> 20) < hi) sortbuf[atomicAdd(const_cast<uint32_t *>(&red[65]), 1u)] = ((uint64_t)u << 32) | bg.bit_orig[b];
+        const uint32_t hi = lo_b;
+        // ---- 1b. gather and sort the head (one LDS counter bump per wavefront)
+        if (tid == 0) red[65] = 0u;
+        __syncthreads();
+        for (int b0 = 0; b0 < g.n; b0 += T) {
+            const int b = b0 + tid;
+            uint32_t u = 0;
+            bool take = false;
+            if (b < g.n) { u = qd_mono_key(llr[b]); take = (u >> 20) < hi; }
+            const unsigned long long bal = __ballot(take);
+            uint32_t wbase = 0;
+            if ((tid & 63) == 0 && bal) wbase = atomicAdd(&red[65], (uint32_t)__popcll(bal));
+            wbase = (uint32_t)__shfl((int)wbase, 0);
+            if (take) sortbuf[wbase + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull))] = ((uint64_t)u << 32) | bg.bit_orig[b];
         }
         __syncthreads();
         const int cnt = (int)red[65];
