@@ -99,6 +99,10 @@ int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int
  * Synchronises.  Test/diagnostic hook (ldpc exposes `log_prob_ratios` the same way). */
 int qd_decoder_failed_llr(qd_decoder *d, int64_t b, float *d_out, void *stream);
 
+/* Diagnostic: 16 cycle counters the OSD kernels accumulate per phase when the library is built with -DQD_OSD_TIMING
+ * (all zero otherwise); reading clears them.  Synchronises. */
+int qd_decoder_debug_counters(qd_decoder *d, uint64_t *out16);
+
 /* Per-kernel device time of this decoder accumulated between calls (milliseconds, HIP events on `stream`):
  * out[0] BP kernel, out[1] OSD kernel, out[2] number of BP launches, out[3] number of OSD launches.
  * enable != 0 turns event recording on.  qd_decoder_profile synchronises on the recorded events. */

@@ -33,6 +33,17 @@
 
 #define QD_NOKEY 0xFFFFFFFFu
 
+#ifdef QD_OSD_TIMING
+#define QD_TICK(slot)                                                                   \
+    {                                                                                   \
+        const unsigned long long now_ = wall_clock64();                                 \
+        if (threadIdx.x == 0 && a_dbg) atomicAdd(&a_dbg[slot], now_ - tick_);           \
+        tick_ = now_;                                                                   \
+    }
+#else
+#define QD_TICK(slot)
+#endif
+
 __device__ __forceinline__ uint64_t &qd_qword(uint64_t *q_lds, uint64_t *q_glb, int kw_lds, int m_pad, int w, int r)
 {
     return (w < kw_lds) ? q_lds[(size_t)w * m_pad + r] : q_glb[(size_t)(w - kw_lds) * m_pad + r];
@@ -70,21 +81,42 @@ struct OsdLds {
     uint32_t *pcol;       // [m_pad] pivot order -> fault
     uint32_t *pairs;      // [64 * max_cdeg] column-in-batch | pivot order << 8
     uint32_t *bcols;      // [64]
-    uint32_t *red;        // [0..15] keys A, [16..31] keys B, [32..63] flags, [64] counter
+    uint32_t *red;        // [0..15] keys A, [16..31] keys B, [32..47] flags A, [48..63] flags B, [64..] counters
     uint32_t *outw;       // packed solution
 };
+
+template <bool SPILL>
+__device__ __forceinline__ uint64_t qd_q_load(const OsdLds &S, uint64_t *qglb, int kw_lds, int m_pad, int w, int r)
+{
+    if (SPILL && w >= kw_lds) return qglb[(size_t)(w - kw_lds) * m_pad + r];
+    return S.q[(size_t)w * m_pad + r];
+}
+template <bool SPILL>
+__device__ __forceinline__ void qd_q_store(const OsdLds &S, uint64_t *qglb, int kw_lds, int m_pad, int w, int r, uint64_t v)
+{
+    if (SPILL && w >= kw_lds) qglb[(size_t)(w - kw_lds) * m_pad + r] = v;
+    else S.q[(size_t)w * m_pad + r] = v;
+}
 
 // Elimination over order[0..ncols).  kcap = number of pivots the Q storage can hold.
 // Returns 0 when finished (early stop, rank exhausted or every column consumed with ncols == n), 1 when it ran out of
 // sorted columns (ncols < n) or of Q capacity before finishing -- the caller must then redo the shot with more.
-template <int T>
+//
+// One barrier per pivot: a round is  [own rows -> candidate key] -> wave min -> LDS -> BARRIER -> every thread reads the
+// 16 partials -> every thread updates its own rows from row p (which its owner leaves alone this round).  The barrier
+// of round i+1 also separates the updates of round i from those of round i+1, and the two reduction buffers alternate.
+template <int T, bool SPILL>
 __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t *qglb, int kw_lds, int kcap,
                                 const uint16_t *order, int ncols, const uint8_t *det, const uint8_t *upd,
-                                int upd_rows, int out_words, int *npiv_out, int *inconsistent_out)
+                                int upd_rows, int out_words, int *npiv_out, int *inconsistent_out,
+                                unsigned long long *a_dbg = nullptr)
 {
     const int tid = threadIdx.x;
     constexpr int NW = T / 64;
     uint32_t *red = S.red;
+#ifdef QD_OSD_TIMING
+    unsigned long long tick_ = wall_clock64();
+#endif
     for (int r = tid; r < g.m_pad; r += T) {
         uint8_t s = 0;
         if (r < g.m) {
@@ -95,14 +127,15 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
         S.rowpiv[r] = -1;
     }
     for (int i = tid; i < kw_lds * g.m_pad; i += T) S.q[i] = 0ull;
-    if (qglb)
+    if (SPILL && qglb)
         for (int i = tid; i < (g.mw - kw_lds) * g.m_pad; i += T) qglb[i] = 0ull;
     for (int w = tid; w < out_words; w += T) S.outw[w] = 0u;
     if (tid < 32) red[tid] = QD_NOKEY;
     else if (tid < 64) red[tid] = 0u;
     __syncthreads();
 
-    int npiv = 0, done = 0, hard = 0;
+    QD_TICK(4)
+    int npiv = 0, done = 0, hard = 0, phase = 0;
     for (int base = 0; base < ncols && !done && !hard; base += 64) {
         // ---- transform the next 64 columns: tb[r] bit c = (T * column_c)[r]
         for (int r = tid; r < g.m_pad; r += T) S.tb[r] = 0ull;
@@ -130,13 +163,16 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
                 for (int i = 0; i < np; ++i) {
                     const uint32_t pr = S.pairs[i];
                     const int k = (int)(pr >> 8);
-                    const uint64_t qw = qd_qword(S.q, qglb, kw_lds, g.m_pad, k >> 6, r);
+                    const uint64_t qw = qd_q_load<SPILL>(S, qglb, kw_lds, g.m_pad, k >> 6, r);
                     x ^= ((qw >> (k & 63)) & 1ull) << (pr & 63u);
                 }
                 S.tb[r] = x;
             }
+        QD_TICK(5)
+#ifdef QD_OSD_TIMING
+        if (tid == 0 && a_dbg) atomicAdd(&a_dbg[12], 1ull);
+#endif
         // ---- take pivots out of the batch, in column order
-        int phase = 0;
         for (;;) {
             uint32_t key = QD_NOKEY;
             int resid = 0;
@@ -146,8 +182,7 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
                     if (x) key = min(key, ((uint32_t)__builtin_ctzll(x) << 16) | (uint32_t)r);
                     resid |= S.sp[r];
                 }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o));
+            key = qd_wave_umin(key);
             const unsigned long long bal = __ballot(resid);
             if ((tid & 63) == 0) { red[phase * 16 + (tid >> 6)] = key; red[32 + phase * 16 + (tid >> 6)] = (bal != 0ull); }
             __syncthreads();
@@ -157,7 +192,7 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
                 const uint4 *kv = reinterpret_cast<const uint4 *>(red + phase * 16);
                 const uint4 *fv = reinterpret_cast<const uint4 *>(red + 32 + phase * 16);
 #pragma unroll
-                for (int w = 0; w < (NW + 3) / 4; ++w) {       // entries beyond NW hold NOKEY / 0 (set once per kernel)
+                for (int w = 0; w < (NW + 3) / 4; ++w) {       // entries beyond NW hold NOKEY / 0 (set once per call)
                     const uint4 k4 = kv[w], f4 = fv[w];
                     key = min(key, min(min(k4.x, k4.y), min(k4.z, k4.w)));
                     anyres |= (int)(f4.x | f4.y | f4.z | f4.w);
@@ -172,22 +207,22 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
             const uint64_t kb = 1ull << (K & 63);
             const uint64_t tp = S.tb[p];
             const uint8_t spp = S.sp[p];
-            for (int r = tid; r < g.m; r += T)
-                if (r != p && ((S.tb[r] >> c) & 1ull)) {
+            for (int r = tid; r < g.m; r += T) {
+                if (r == p) { S.rowpiv[r] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = S.bcols[c]; }   // the owner records the pivot
+                else if ((S.tb[r] >> c) & 1ull) {
                     S.tb[r] ^= tp;
                     S.sp[r] ^= spp;
                     for (int w = 0; w <= kw; ++w) {
-                        uint64_t &dst = qd_qword(S.q, qglb, kw_lds, g.m_pad, w, r);
-                        uint64_t v = dst ^ qd_qword(S.q, qglb, kw_lds, g.m_pad, w, p);
+                        uint64_t v = qd_q_load<SPILL>(S, qglb, kw_lds, g.m_pad, w, r) ^ qd_q_load<SPILL>(S, qglb, kw_lds, g.m_pad, w, p);
                         if (w == kw) v ^= kb;
-                        dst = v;
+                        qd_q_store<SPILL>(S, qglb, kw_lds, g.m_pad, w, r, v);
                     }
                 }
-            // nobody reads rowpiv/prow/pcol during the update, so the new pivot can be recorded alongside it
-            if (tid == 0) { S.rowpiv[p] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = S.bcols[c]; }
+            }
             npiv = K + 1;
-            __syncthreads();                              // updated rows + the pivot record, before the next round
         }
+        __syncthreads();                                  // last round's updates, before the next batch re-uses tb / reads rowpiv
+        QD_TICK(6)
     }
     if (!done && !hard && ncols < g.n) {
         // out of sorted columns: finished only if the syndrome happens to be resolved already or no row is left
@@ -195,12 +230,12 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
         for (int r = tid; r < g.m; r += T)
             if (S.rowpiv[r] < 0) resid |= S.sp[r];
         const unsigned long long bal = __ballot(resid);
-        __syncthreads();
-        if ((tid & 63) == 0) red[32 + (tid >> 6)] = (bal != 0ull);
+        if ((tid & 63) == 0) red[32 + phase * 16 + (tid >> 6)] = (bal != 0ull);
         __syncthreads();
         int anyres = 0;
-        for (int w = 0; w < NW; ++w) anyres |= (int)red[32 + w];
+        for (int w = 0; w < NW; ++w) anyres |= (int)red[32 + phase * 16 + w];
         if (anyres && npiv < g.m) hard = 1;
+        phase ^= 1;
         __syncthreads();
     }
     if (hard) return 1;
@@ -211,10 +246,9 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
         for (int r = tid; r < g.m; r += T)
             if (S.rowpiv[r] < 0) resid |= S.sp[r];
         const unsigned long long bal = __ballot(resid);
+        if ((tid & 63) == 0) red[32 + phase * 16 + (tid >> 6)] = (bal != 0ull);
         __syncthreads();
-        if ((tid & 63) == 0) red[32 + (tid >> 6)] = (bal != 0ull);
-        __syncthreads();
-        for (int w = 0; w < NW; ++w) inconsistent |= (int)red[32 + w];
+        for (int w = 0; w < NW; ++w) inconsistent |= (int)red[32 + phase * 16 + w];
     }
     // OSD-0 solution
     for (int k = tid; k < npiv; k += T)
@@ -223,6 +257,7 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
             atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
         }
     __syncthreads();
+    QD_TICK(7)
     *npiv_out = npiv;
     *inconsistent_out = inconsistent;
     return 0;
@@ -243,70 +278,105 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
 }
 
 // ---- fast path: head of the order only --------------------------------------------------------------------------------
+// `cap` = number of columns to sort (<= QD_OSD_FAST_CAP).  Reads the shots to do from in_list (or the BP fail list
+// itself when in_list is null) and appends the ones it cannot finish to out_list.
+#define QD_OSD_KPT 24     // monotone keys a thread keeps in registers (covers n <= 24 * T; larger windows re-read the LLRs)
 template <int T>
-__global__ void __launch_bounds__(T, T / 128) qd_osd0_fast_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a)
+__global__ void __launch_bounds__(T, T / 256) qd_osd0_fast_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a, int cap,
+                                                                  const int32_t *in_list, const int32_t *in_count,
+                                                                  int32_t *out_list, int32_t *out_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int nfail = *a.fail_count;
+    const int nlist = *in_count;
     OsdLds S;
     qd_osd_carve(smem, g.f_off, S);
     uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + g.f_off_sort);     // [QD_OSD_FAST_CAP], overlaps the Q planes
     uint16_t *order = reinterpret_cast<uint16_t *>(smem + g.f_off_order);      // [QD_OSD_FAST_CAP]
     uint32_t *red = S.red;
-    for (int slot = blockIdx.x; slot < nfail; slot += gridDim.x) {
+    const bool in_regs = g.n <= QD_OSD_KPT * T;
+    for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
+        const int slot = in_list ? in_list[li] : li;
         const int64_t shot = a.fail_list[slot];
         const float *llr = a.llr_ws + (int64_t)slot * bg.n_pad;
-        // ---- 1a. hi = largest number of leading key bins (top 12 bits) whose population fits the sort buffer.
-        //      Bisection on counts: 12 rounds of (compare, wave popcount, one LDS add per wave).
-        uint32_t lo_b = 0, hi_b = 4096;                      // invariant: count(bin < lo_b) <= CAP
-        if (tid < 16) red[tid] = 0u;
+#ifdef QD_OSD_TIMING
+        unsigned long long *a_dbg = a.dbg;
+        unsigned long long tick_ = wall_clock64();
+#endif
+        uint32_t kreg[QD_OSD_KPT];
+        if (in_regs) {
+#pragma unroll
+            for (int i = 0; i < QD_OSD_KPT; ++i) {
+                const int b = tid + i * T;
+                kreg[i] = (b < g.n) ? qd_mono_key(llr[b]) : 0xFFFFFFFFu;
+            }
+        }
+        // ---- 1a. hi = largest number of leading key bins (top 12 bits) whose population fits `cap`.
+        //      Bisection on counts: 12 rounds of (compare, wave sum, one LDS add per wave, one barrier).
+        uint32_t lo_b = 0, hi_b = 4096;                      // invariant: count(bin < lo_b) <= cap
+        if (tid < 16) red[64 + tid] = 0u;
         __syncthreads();
         for (int it = 0; it < 12; ++it) {
             const uint32_t mid = (lo_b + hi_b + 1) >> 1;
             uint32_t c = 0;
-            for (int b = tid; b < g.n; b += T) c += ((qd_mono_key(llr[b]) >> 20) < mid) ? 1u : 0u;
+            if (in_regs) {
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
-            if ((tid & 63) == 0) atomicAdd(&red[it & 1], c);
+                for (int i = 0; i < QD_OSD_KPT; ++i) c += ((kreg[i] >> 20) < mid) ? 1u : 0u;
+            } else {
+                for (int b = tid; b < g.n; b += T) c += ((qd_mono_key(llr[b]) >> 20) < mid) ? 1u : 0u;
+            }
+            c = qd_wave_add(c);
+            if ((tid & 63) == 0) atomicAdd(&red[64 + it], c);
             __syncthreads();
-            const uint32_t tot = red[it & 1];
-            if (tot <= (uint32_t)QD_OSD_FAST_CAP) lo_b = mid; else hi_b = mid - 1;
-            if (tid == 0) red[(it + 1) & 1] = 0u;
-            __syncthreads();
+            if (red[64 + it] <= (uint32_t)cap) lo_b = mid; else hi_b = mid - 1;
         }
         const uint32_t hi = lo_b;
+        QD_TICK(0)
         // ---- 1b. gather and sort the head (one LDS counter bump per wavefront)
-        if (tid == 0) red[65] = 0u;
+        if (tid == 0) red[80] = 0u;
         __syncthreads();
-        for (int b0 = 0; b0 < g.n; b0 += T) {
-            const int b = b0 + tid;
-            uint32_t u = 0;
-            bool take = false;
-            if (b < g.n) { u = qd_mono_key(llr[b]); take = (u >> 20) < hi; }
+        for (int i = 0; i * T < g.n; ++i) {
+            const int b = tid + i * T;
+            uint32_t u = 0xFFFFFFFFu;
+            if (in_regs) {
+                // kreg is indexed with a compile-time constant only when the loop is unrolled; re-derive instead
+                u = (b < g.n) ? qd_mono_key(llr[b]) : 0xFFFFFFFFu;
+            } else if (b < g.n) u = qd_mono_key(llr[b]);
+            const bool take = (b < g.n) && (u >> 20) < hi;
             const unsigned long long bal = __ballot(take);
             uint32_t wbase = 0;
-            if ((tid & 63) == 0 && bal) wbase = atomicAdd(&red[65], (uint32_t)__popcll(bal));
+            if ((tid & 63) == 0 && bal) wbase = atomicAdd(&red[80], (uint32_t)__popcll(bal));
             wbase = (uint32_t)__shfl((int)wbase, 0);
             if (take) sortbuf[wbase + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull))] = ((uint64_t)u << 32) | bg.bit_orig[b];
         }
         __syncthreads();
-        const int cnt = (int)red[65];
+        const int cnt = (int)red[80];
         int P = 64;
         while (P < cnt) P <<= 1;
         for (int i = cnt + tid; i < P; i += T) sortbuf[i] = ~0ull;
         __syncthreads();
+        QD_TICK(1)
         qd_bitonic_u64<T>(sortbuf, P, tid);
         for (int i = tid; i < cnt; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
         __syncthreads();
+        QD_TICK(2)
         // ---- 2./3. elimination on the head
         const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
         const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
         int npiv = 0, inconsistent = 0;
-        const int rc = qd_osd_eliminate<T>(g, S, nullptr, g.f_kw, g.f_kw * 64, order, cnt, det, upd, a.upd_rows,
-                                           bg.out_words, &npiv, &inconsistent);
+#ifdef QD_OSD_TIMING
+        const int rc = qd_osd_eliminate<T, false>(g, S, nullptr, g.f_kw, g.f_kw * 64, order, cnt, det, upd, a.upd_rows,
+                                                  bg.out_words, &npiv, &inconsistent, a_dbg);
+        tick_ = wall_clock64();
+#else
+        const int rc = qd_osd_eliminate<T, false>(g, S, nullptr, g.f_kw, g.f_kw * 64, order, cnt, det, upd, a.upd_rows,
+                                                  bg.out_words, &npiv, &inconsistent);
+#endif
+#ifdef QD_OSD_TIMING
+        if (tid == 0) { atomicAdd(&a_dbg[8], 1ull); atomicAdd(&a_dbg[9], (unsigned long long)npiv); atomicAdd(&a_dbg[10], (unsigned long long)cnt); atomicAdd(&a_dbg[11], (unsigned long long)rc); }
+#endif
         if (rc) {
-            if (tid == 0) a.hard_list[atomicAdd(a.hard_count, 1)] = slot;
+            if (tid == 0) out_list[atomicAdd(out_count, 1)] = slot;
         } else {
             for (int w = tid; w < bg.out_words; w += T) a.err_bits[shot * bg.out_words + w] = S.outw[w];
             if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
@@ -317,17 +387,18 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_fast_kernel(OsdGraphDev g,
 
 // ---- full path: every column sorted, every Q plane available ------------------------------------------------------------
 template <int T>
-__global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a, int use_hard_list)
+__global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a,
+                                                         const int32_t *in_list, const int32_t *in_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int nlist = use_hard_list ? *a.hard_count : *a.fail_count;
+    const int nlist = *in_count;
     OsdLds S;
     qd_osd_carve(smem, g.off, S);
     uint64_t *sortbuf = S.q;                                                    // phase 1; phase 2 reuses it as Q planes
     // persistent: a fixed grid walks the list; order/spill workspace is per workgroup
     for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
-        const int slot = use_hard_list ? a.hard_list[li] : li;
+        const int slot = in_list ? in_list[li] : li;
         const int64_t shot = a.fail_list[slot];
         uint16_t *order = a.order_ws + (int64_t)blockIdx.x * g.n;
         uint64_t *qglb = a.q_spill ? a.q_spill + (int64_t)blockIdx.x * (int64_t)(g.mw - g.kw_lds) * g.m_pad : nullptr;
@@ -345,14 +416,15 @@ __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphD
         const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
         const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
         int npiv = 0, inconsistent = 0;
-        qd_osd_eliminate<T>(g, S, qglb, g.kw_lds, g.m, order, g.n, det, upd, a.upd_rows, bg.out_words, &npiv, &inconsistent);
+        qd_osd_eliminate<T, true>(g, S, qglb, g.kw_lds, g.m, order, g.n, det, upd, a.upd_rows, bg.out_words, &npiv, &inconsistent);
         for (int w = tid; w < bg.out_words; w += T) a.err_bits[shot * bg.out_words + w] = S.outw[w];
         if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
         __syncthreads();   // LDS is recycled by the next shot
     }
 }
 
-template <int T>
+// Three passes over ever shorter lists: head of 512 columns, head of 2048 columns, everything.
+template <int TF, int T>
 static hipError_t launch_osd_t(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                                int blocks_full, hipStream_t s)
 {
@@ -361,13 +433,19 @@ static hipError_t launch_osd_t(const OsdGraphDev &g, const BpGraphDev &bg, const
     e = hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     if (g.f_lds_bytes > 0) {
-        auto kq = qd_osd0_fast_kernel<T>;
+        auto kq = qd_osd0_fast_kernel<TF>;
         e = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, g.f_lds_bytes);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kq, dim3((unsigned)blocks_fast), dim3(T), g.f_lds_bytes, s, g, bg, a);
-        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, 1);
+        int32_t *cnt = a.hard_count;            // [0] after pass 1, [1] after pass 2
+        hipLaunchKernelGGL(kq, dim3((unsigned)blocks_fast), dim3(TF), g.f_lds_bytes, s, g, bg, a, 512,
+                           (const int32_t *)nullptr, (const int32_t *)a.fail_count, a.hard_list, cnt);
+        hipLaunchKernelGGL(kq, dim3((unsigned)blocks_fast), dim3(TF), g.f_lds_bytes, s, g, bg, a, QD_OSD_FAST_CAP,
+                           (const int32_t *)a.hard_list, (const int32_t *)cnt, a.hard_list2, cnt + 1);
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, (const int32_t *)a.hard_list2,
+                           (const int32_t *)(cnt + 1));
     } else {
-        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, 0);
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, (const int32_t *)nullptr,
+                           (const int32_t *)a.fail_count);
     }
     return hipGetLastError();
 }
@@ -376,8 +454,8 @@ hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const Deco
                           int blocks_full, hipStream_t s)
 {
     switch (g.threads) {
-    case 256: return launch_osd_t<256>(g, bg, a, blocks_fast, blocks_full, s);
-    case 512: return launch_osd_t<512>(g, bg, a, blocks_fast, blocks_full, s);
-    default: return launch_osd_t<1024>(g, bg, a, blocks_fast, blocks_full, s);
+    case 256: return launch_osd_t<256, 256>(g, bg, a, blocks_fast, blocks_full, s);
+    case 512: return launch_osd_t<512, 512>(g, bg, a, blocks_fast, blocks_full, s);
+    default: return launch_osd_t<512, 1024>(g, bg, a, blocks_fast, blocks_full, s);
     }
 }

@@ -76,7 +76,7 @@ struct qd_decoder {
     int32_t *fail_list = nullptr, *fail_count = nullptr;
     uint16_t *order_ws = nullptr;
     uint64_t *q_spill = nullptr;
-    int32_t *hard_list = nullptr;
+    int32_t *hard_list = nullptr, *hard_list2 = nullptr;
     int osd_blocks_fast = 0;
     int profiling = 0;
     std::vector<hipEvent_t> ev;        // triples (bp start, bp end / osd start, osd end)
@@ -279,7 +279,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         offs[5] = o; o += align16(m_pad * 4);          // pcol
         offs[6] = o; o += align16(64 * max_cdeg * 4);  // pairs
         offs[7] = o; o += 256;                         // cols
-        offs[8] = o; o += 512;                         // red
+        offs[8] = o; o += 1024;                        // red
         offs[9] = o; o += align16(bp.out_words * 4);   // out
         return o;
     };
@@ -288,6 +288,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int q_budget = QD_LDS_BYTES - small - 64;
     const int sort_bytes = np2 * 8;
     od.threads = m <= 256 ? 256 : (m <= 512 ? 512 : 1024);
+    od.f_threads = m <= 256 ? 256 : 512;
     if (sort_bytes > q_budget) {
         // BP still runs; the full OSD kernel needs its sort buffer in LDS
         od.lds_bytes = 0; od.kw_lds = 0; od.f_lds_bytes = 0; od.f_kw = 0;
@@ -390,7 +391,8 @@ static void free_ws(qd_decoder *d)
     if (d->order_ws) (void)hipFree(d->order_ws);
     if (d->q_spill) (void)hipFree(d->q_spill);
     if (d->hard_list) (void)hipFree(d->hard_list);
-    d->hard_list = nullptr;
+    if (d->hard_list2) (void)hipFree(d->hard_list2);
+    d->hard_list = nullptr; d->hard_list2 = nullptr;
     d->llr_ws = nullptr; d->fail_list = nullptr; d->fail_count = nullptr; d->order_ws = nullptr; d->q_spill = nullptr;
     d->cap = 0;
 }
@@ -413,8 +415,8 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
     free_ws(d);
     const qd_graph *g = d->g;
     const bool osd = d->prm.osd_method != QD_OSD_OFF;
-    HIP_TRY(hipMalloc((void **)&d->fail_count, 64));
-    HIP_TRY(hipMemset(d->fail_count, 0, 64));
+    HIP_TRY(hipMalloc((void **)&d->fail_count, 256));
+    HIP_TRY(hipMemset(d->fail_count, 0, 256));
     if (osd) {
         int ncu = 256;
         hipDeviceProp_t prop;
@@ -422,8 +424,9 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         const int per_cu = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.lds_bytes));
         d->osd_blocks = ncu * std::min(per_cu, 2048 / g->osd.threads);
         const int per_cu_fast = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.f_lds_bytes));
-        d->osd_blocks_fast = ncu * std::min(per_cu_fast, 2048 / g->osd.threads);
+        d->osd_blocks_fast = ncu * std::min(per_cu_fast, 2048 / std::max(1, g->osd.f_threads));
         HIP_TRY(hipMalloc((void **)&d->hard_list, sizeof(int32_t) * (size_t)max_batch));
+        HIP_TRY(hipMalloc((void **)&d->hard_list2, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->llr_ws, sizeof(float) * (size_t)max_batch * g->bp.n_pad));
         HIP_TRY(hipMalloc((void **)&d->fail_list, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->order_ws, sizeof(uint16_t) * (size_t)d->osd_blocks * g->n));
@@ -483,8 +486,9 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
     a.err_bits = d_err_bits; a.status = d_status;
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
     a.order_ws = d->order_ws; a.q_spill = d->q_spill;
-    a.hard_list = d->hard_list; a.hard_count = d->fail_count + 1;
-    HIP_TRY(hipMemsetAsync(d->fail_count, 0, 2 * sizeof(int32_t), s));
+    a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
+    a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;   // bytes 16..143 of the counter block
+    HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (d->profiling) {
         HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
@@ -497,6 +501,16 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
         HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                (int)std::min<int64_t>(B, d->osd_blocks), s));
     if (d->profiling) HIP_TRY(hipEventRecord(e2, s));
+    return QD_OK;
+}
+
+extern "C" int qd_decoder_debug_counters(qd_decoder *d, uint64_t *out16)
+{
+    if (!d || !out16 || !d->fail_count) return fail(QD_EINVAL, "no workspace yet");
+    HIP_TRY(hipSetDevice(d->g->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out16, reinterpret_cast<char *>(d->fail_count) + 16, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(reinterpret_cast<char *>(d->fail_count) + 16, 0, 16 * sizeof(uint64_t)));
     return QD_OK;
 }
 

@@ -49,7 +49,7 @@ struct OsdGraphDev {
     // LDS carve-up of the full kernel: off[] = q, tb, sp, rowpiv, prow, pcol, pairs, cols, red, out
     int off[10], lds_bytes;
     // ... and of the fast kernel (Q planes overlap the histogram + sort buffer); f_lds_bytes = 0 disables it
-    int f_off[10], f_off_hist, f_off_sort, f_off_order, f_kw, f_lds_bytes;
+    int f_off[10], f_off_hist, f_off_sort, f_off_order, f_kw, f_lds_bytes, f_threads;
     int threads;
 };
 
@@ -70,8 +70,10 @@ struct DecodeArgs {
     int32_t *fail_count;        // [1]
     uint16_t *order_ws;         // [blocks][n]   sorted column order (full OSD kernel)
     uint64_t *q_spill;          // [blocks][(mw - kw_lds)][m_pad]
-    int32_t *hard_list;         // [cap]         fail-list slots the fast OSD kernel could not finish
-    int32_t *hard_count;        // [1]
+    int32_t *hard_list;         // [cap]         fail-list slots the first fast OSD pass could not finish
+    int32_t *hard_list2;        // [cap]         ... and the second
+    int32_t *hard_count;        // [2]
+    unsigned long long *dbg;    // [16] phase cycle counters (only written by -DQD_OSD_TIMING builds)
 };
 
 // Workgroup-wide OR without static LDS (a static __shared__ object in front of the dynamic region can knock the
@@ -89,6 +91,30 @@ __device__ __forceinline__ int qd_block_or(int pred, int *red, int nwaves, int p
         r |= v.x | v.y | v.z | v.w;
     }
     return r;
+}
+
+// Wave-wide reductions on the DPP path (row shifts + row broadcasts: a handful of cycles per step, no LDS traffic);
+// the result is uniform (taken from lane 63).
+#define QD_DPP(v, old, ctrl, rowmask) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rowmask), 0xf, false))
+__device__ __forceinline__ uint32_t qd_wave_umin(uint32_t v)
+{
+    v = min(v, QD_DPP(v, 0xFFFFFFFFu, 0x111, 0xf));   // row_shr:1
+    v = min(v, QD_DPP(v, 0xFFFFFFFFu, 0x112, 0xf));   // row_shr:2
+    v = min(v, QD_DPP(v, 0xFFFFFFFFu, 0x114, 0xf));   // row_shr:4
+    v = min(v, QD_DPP(v, 0xFFFFFFFFu, 0x118, 0xf));   // row_shr:8   -> lane 15 of each row holds the row minimum
+    v = min(v, QD_DPP(v, 0xFFFFFFFFu, 0x142, 0xa));   // row_bcast:15 into rows 1 and 3
+    v = min(v, QD_DPP(v, 0xFFFFFFFFu, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t qd_wave_add(uint32_t v)
+{
+    v += QD_DPP(v, 0u, 0x111, 0xf);
+    v += QD_DPP(v, 0u, 0x112, 0xf);
+    v += QD_DPP(v, 0u, 0x114, 0xf);
+    v += QD_DPP(v, 0u, 0x118, 0xf);
+    v += QD_DPP(v, 0u, 0x142, 0xa);
+    v += QD_DPP(v, 0u, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 struct SpmatDev {

@@ -110,6 +110,11 @@ class BatchDecoder:
         _lib.check(self._L.qd_decoder_failed_llr(self._h, int(b), _ptr(out), _stream_ptr()))
         return out
 
+    def debug_counters(self):
+        arr = (C.c_uint64 * 16)()
+        _lib.check(self._L.qd_decoder_debug_counters(self._h, arr))
+        return [int(x) for x in arr]
+
     def set_profiling(self, on: bool):
         _lib.check(self._L.qd_decoder_set_profiling(self._h, 1 if on else 0))
 

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Phase breakdown of the fast OSD kernel (needs a -DQD_OSD_TIMING build: QUITS_AMD_LIB=build_ablate/lib_osdtiming.so)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, helpers
+from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
+H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+det, obs = DemSampler(H, L, pri).sample(32768, seed=5)
+g = WindowGraph(H, pri); d = BatchDecoder(g, max_iter=50, osd_method="osd_0")
+d.decode(det); torch.cuda.synchronize(); d.debug_counters()
+d.set_profiling(True); d.decode(det); torch.cuda.synchronize()
+c = d.debug_counters(); pr = d.profile()
+names = ["bisect", "gather", "sort", "-", "elim.init", "elim.batch-load", "elim.pivots", "elim.finish"]
+tot = sum(c[:8]) or 1
+print("hard after this pass(es):", c[11], "batches/shot", c[12] / max(c[8], 1))
+print("osd kernel ms", pr["osd_ms"], "shots", c[8], "mean pivots", c[9] / max(c[8], 1), "mean head cols", c[10] / max(c[8], 1))
+for i, nme in enumerate(names):
+    print("%-10s %6.1f %%   %8.0f ticks/shot" % (nme, 100.0 * c[i] / tot, c[i] / max(c[8], 1)))
+
