@@ -213,6 +213,10 @@ def sliding_window_circuit_mem(zcheck_samples, circuit, hz, lz, W, F, decoder1, 
 
     :return logical_z_pred: int64 array (# trials, # logical qubits)
     """
+    if F == 0:
+        # the reference only reaches this message through spacetime() (base.py:149-150) and, when R + 2 >= W, dies
+        # earlier on the integer division at sliding_window.py:135; one ValueError up front covers both
+        raise ValueError("Input parameter F cannot be zero.")
     nz = hz.shape[0]
     num_trials = zcheck_samples.shape[0]
     num_rounds = zcheck_samples.shape[1] // nz - 2

@@ -1,0 +1,85 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/quits_amd.h declares; package surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "quits_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from quits_amd import _lib
+    L = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 19
+    for s in syms:
+        assert hasattr(L, s), "libquits_amd.so does not export %s" % s
+    assert sorted(_lib.EXPORTS) == syms            # the Python binding list is the header's list
+    assert L.qd_version() >= 100
+    assert isinstance(L.qd_last_error(), bytes)
+
+
+def test_no_compute_without_gpu_but_argument_checks_work():
+    import torch
+    from quits_amd import _lib
+    L = _lib.load()
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert L.qd_device_count() == 0
+    h = ctypes.c_void_p()
+    rc = L.qd_graph_create(0, 0, None, None, None, 0, ctypes.byref(h))
+    assert rc == -1 and b"empty" in L.qd_last_error()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        _lib.require_gpu()
+
+
+def test_package_surface_mirrors_reference():
+    """Names of quits.decoder.__all__ (/root/reference/src/quits/decoder/__init__.py:13-24)."""
+    import inspect
+    import quits_amd.decoder as d
+    for name in ("dict_to_csc_matrix_column_row", "dict_to_csc_matrix_row_column", "detector_error_model_to_matrix",
+                 "spacetime", "sliding_window_phenom_mem", "sliding_window_circuit_mem",
+                 "sliding_window_bposd_phenom_mem", "sliding_window_bposd_circuit_mem",
+                 "sliding_window_bplsd_phenom_mem", "sliding_window_bplsd_circuit_mem"):
+        assert name in d.__all__ and callable(getattr(d, name))
+    sig = inspect.signature(d.sliding_window_bposd_circuit_mem)
+    assert list(sig.parameters) == ["zcheck_samples", "circuit", "hz", "lz", "W", "F", "max_iter", "osd_order",
+                                    "bp_method", "schedule", "osd_method", "tqdm_on"]
+    assert [sig.parameters[k].default for k in ("max_iter", "osd_order", "bp_method", "schedule", "osd_method", "tqdm_on")] \
+        == [2, 0, "product_sum", "serial", "osd_cs", False]
+    sig = inspect.signature(d.sliding_window_bposd_phenom_mem)
+    assert list(sig.parameters) == ["zcheck_samples", "hz", "lz", "W", "F", "eff_error_rate_per_fault", "max_iter",
+                                    "osd_order", "bp_method", "schedule", "osd_method", "tqdm_on", "error_rate"]
+    sig = inspect.signature(d.sliding_window_circuit_mem)
+    assert list(sig.parameters) == ["zcheck_samples", "circuit", "hz", "lz", "W", "F", "decoder1", "decoder2", "dict1",
+                                    "dict2", "error_rate_name1", "error_rate_name2", "function_name1", "function_name2",
+                                    "tqdm_on"]
+    with pytest.raises(NotImplementedError):
+        d.sliding_window_bplsd_circuit_mem()
+
+
+def test_dict_helpers():
+    from quits_amd.decoder import dict_to_csc_matrix_column_row, dict_to_csc_matrix_row_column
+    a = dict_to_csc_matrix_column_row({0: [1, 2], 2: [0]}, (3, 3))
+    assert a.toarray().tolist() == [[0, 0, 1], [1, 0, 0], [1, 0, 0]]
+    b = dict_to_csc_matrix_row_column({frozenset([0, 2]): 1, frozenset([1]): 0}, (3, 2))
+    assert b.toarray().tolist() == [[0, 1], [1, 0], [0, 1]]
+    assert a.dtype == np.uint8
+
+
+def test_product_path_does_not_import_the_oracle():
+    """quits_amd/ must never reach into oracle/ (the CPU restatement is test infrastructure)."""
+    pkg = os.path.join(ROOT, "quits_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "liboracle" not in txt and "qd_oracle" not in txt.replace("oracle/qd_oracle.c", ""), f

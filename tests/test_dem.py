@@ -1,0 +1,178 @@
+"""Circuit text -> detector error model (quits_amd/stim_text.py, quits_amd/dem.py): CPU tests."""
+import numpy as np
+import pytest
+
+import helpers
+from quits_amd.dem import Circuit, DetectorErrorModel, circuit_to_dem
+from quits_amd.decoder.base import detector_error_model_to_matrix
+from quits_amd.stim_text import CircuitSyntaxError, flatten
+
+EXPECTED = {   # detectors, DEM columns, nnz
+    "hgp225_cardinal_r3_p0.01": (540, 5409, 22356, 9),
+    "bb72_custom_r6_p0.003": (288, 2592, 9036, 12),
+    "bb144_custom_r12_p0.003": (1008, 9504, 33192, 12),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED))
+def test_dem_shapes_and_golden_matrices(name):
+    """H, L, priors equal the arrays the REFERENCE's detector_error_model_to_matrix produced from this DEM
+    (tests/golden/windows/*.npz, tools/gen_fixtures.py G3) -- pins the restated function bit for bit."""
+    dem = Circuit(helpers.circuit_text(name)).detector_error_model()
+    det, cols, nnz, nobs = EXPECTED[name]
+    assert (dem.num_detectors, dem.num_errors, dem.num_observables) == (det, cols, nobs)
+    H, L, pri = detector_error_model_to_matrix(dem)
+    Hg, Lg, pg = helpers.dem_matrices(name)
+    assert H.nnz == nnz and helpers.same_sparse(H, Hg) and helpers.same_sparse(L, Lg)
+    assert np.array_equal(pri, pg)
+    assert H.dtype == np.uint8 and pri.dtype == np.float64
+
+
+def test_merge_rule_matches_reference():
+    """G4: duplicate detector sets fold probabilities, first-seen column order, first-seen observables kept."""
+    z = np.load(helpers.GOLD + "/dem_merge.npz")
+    errors = []
+    for p, d, o in zip(z["err_p"], z["err_dets"], z["err_obs"]):
+        errors.append((float(p), tuple(int(x) for x in str(d).split(",") if x), tuple(int(x) for x in str(o).split(",") if x)))
+    dem = DetectorErrorModel(errors, int(z["num_detectors"][0]), int(z["num_observables"][0]))
+    H, L, pri = detector_error_model_to_matrix(dem)
+    assert helpers.same_sparse(H, helpers.csc_from(z, "H")) and helpers.same_sparse(L, helpers.csc_from(z, "L"))
+    assert np.allclose(pri, z["priors"], rtol=0, atol=0)
+
+
+def test_priors_and_ordering_bb144():
+    dem = Circuit(helpers.circuit_text("bb144_custom_r12_p0.003")).detector_error_model()
+    ps = np.array([e[0] for e in dem.errors])
+    assert abs(ps.sum() - 51.612) < 1e-2 and ps.min() > 1.5e-3 and ps.max() < 1.7e-2
+    keys = [tuple(d) + tuple(dem.num_detectors + o for o in ob) for (_, d, ob) in dem.errors]
+    assert keys == sorted(keys) and len(set(keys)) == len(keys)
+    # every fault touches at most two consecutive rounds of 72 detectors (what spacetime() relies on)
+    for (_, d, _) in dem.errors:
+        assert max(d) // 72 - min(d) // 72 <= 1
+
+
+def _forward_symptom(ops, num_det_of_meas, start, pauli):
+    """Independent check: push one Pauli fault FORWARD through the circuit and collect the flipped measurements."""
+    x, z = dict(), dict()
+    for q, p in pauli.items():
+        if p in "XY":
+            x[q] = 1
+        if p in "ZY":
+            z[q] = 1
+    flips = 0
+    m = sum(len(op.targets) for op in ops[:start] if op.name in ("M", "MX", "MR"))
+    for op in ops[start:]:
+        t = op.targets
+        if op.name == "CX":
+            for i in range(0, len(t), 2):
+                c, tg = t[i], t[i + 1]
+                if x.get(c):
+                    x[tg] = x.get(tg, 0) ^ 1
+                if z.get(tg):
+                    z[c] = z.get(c, 0) ^ 1
+        elif op.name == "H":
+            for q in t:
+                x[q], z[q] = z.get(q, 0), x.get(q, 0)
+        elif op.name in ("M", "MR", "MX"):
+            for q in t:
+                hit = z.get(q, 0) if op.name == "MX" else x.get(q, 0)
+                if hit:
+                    flips ^= num_det_of_meas[m]
+                m += 1
+                if op.name == "MR":
+                    x[q] = 0
+                    z[q] = 0
+        elif op.name in ("R", "RX"):
+            for q in t:
+                x[q] = 0
+                z[q] = 0
+    return flips
+
+
+@pytest.mark.parametrize("name", ["bb72_custom_r0_p0.003", "bb72_custom_r2_xbasis_mixed"])
+def test_backward_extractor_against_forward_propagation(name):
+    """Every fault component of every noise instruction, propagated forward by an independent Pauli-frame walk,
+    must land on a DEM column with that symptom, and the merged probabilities must agree."""
+    text = helpers.circuit_text(name)
+    ops, nmeas, ndet, nobs = flatten(text)
+    sens = [0] * nmeas
+    for op in ops:
+        if op.name == "DETECTOR":
+            for k in op.targets:
+                sens[k] ^= 1 << int(op.arg)
+        elif op.name == "OBSERVABLE_INCLUDE":
+            for k in op.targets:
+                sens[k] ^= 1 << (ndet + int(op.arg))
+    probs = {}
+
+    def add(sym, q):
+        if sym:
+            p = probs.get(sym, 0.0)
+            probs[sym] = p * (1 - q) + q * (1 - p)
+
+    for i, op in enumerate(ops):
+        if op.name == "X_ERROR":
+            for q in op.targets:
+                add(_forward_symptom(ops, sens, i + 1, {q: "X"}), op.arg)
+        elif op.name == "Z_ERROR":
+            for q in op.targets:
+                add(_forward_symptom(ops, sens, i + 1, {q: "Z"}), op.arg)
+        elif op.name == "DEPOLARIZE1":
+            q1 = 0.5 - 0.5 * np.sqrt(1 - 4 * op.arg / 3)
+            for q in op.targets:
+                for P in "XYZ":
+                    add(_forward_symptom(ops, sens, i + 1, {q: P}), q1)
+        elif op.name == "DEPOLARIZE2":
+            q2 = 0.5 - 0.5 * (1 - 16 * op.arg / 15) ** 0.125
+            t = op.targets
+            for j in range(0, len(t), 2):
+                for Pa in "IXYZ":
+                    for Pb in "IXYZ":
+                        if Pa + Pb != "II":
+                            pl = {}
+                            if Pa != "I":
+                                pl[t[j]] = Pa
+                            if Pb != "I":
+                                pl[t[j + 1]] = Pb
+                            add(_forward_symptom(ops, sens, i + 1, pl), q2)
+    dem = circuit_to_dem(text)
+    got = {}
+    for (p, d, o) in dem.errors:
+        got[sum(1 << x for x in d) | sum(1 << (ndet + x) for x in o)] = p
+    assert set(got) == set(probs)
+    for k in probs:
+        assert abs(got[k] - probs[k]) < 1e-15
+
+
+def test_parser_edge_cases():
+    ops, nm, nd, no = flatten("R 0 1\nREPEAT 3 {\n  H 0\n  CX 0 1\n  M 1\n  DETECTOR rec[-1]\n}\nM 0\nOBSERVABLE_INCLUDE(2) rec[-1] rec[-2]\n")
+    assert nm == 4 and nd == 3 and no == 3
+    assert [o.name for o in ops].count("CX") == 3
+    assert ops[-1].targets == (3, 2)
+    with pytest.raises(CircuitSyntaxError):
+        flatten("REPEAT 2 {\nH 0\n")
+    with pytest.raises(CircuitSyntaxError):
+        flatten("M 0\nDETECTOR rec[-2]\n")
+    with pytest.raises(CircuitSyntaxError):
+        flatten("FROBNICATE 0\n")
+    with pytest.raises(NotImplementedError):
+        flatten("PAULI_CHANNEL_1(0.1, 0.2, 0.3) 0\n")
+    with pytest.raises(CircuitSyntaxError):
+        flatten("CX 0 1 2\n")
+    assert circuit_to_dem("R 0\nM 0\nDETECTOR rec[-1]\n").num_errors == 0     # noiseless: empty DEM
+    d = circuit_to_dem("R 0\nX_ERROR(0.125) 0\nM 0\nDETECTOR rec[-1]\n")
+    assert d.errors == [(0.125, (0,), ())]
+    d = circuit_to_dem("RX 0\nZ_ERROR(0.25) 0\nX_ERROR(0.5) 0\nMX 0\nDETECTOR rec[-1]\nOBSERVABLE_INCLUDE(0) rec[-1]\n")
+    assert d.errors == [(0.25, (0,), (0,))]
+
+
+def test_circuit_wrapper_api():
+    c = Circuit(helpers.circuit_text("bb72_custom_r6_p0.003"))
+    assert c.num_detectors == 288 and c.num_observables == 12
+    assert c.detector_error_model() is c.detector_error_model(decompose_errors=False)
+    with pytest.raises(NotImplementedError):
+        c.detector_error_model(decompose_errors=True)
+    inst = c.detector_error_model().flattened()[0]
+    assert inst.type == "error" and len(inst.args_copy()) == 1
+    t = inst.targets_copy()
+    assert t[0].is_relative_detector_id() and not t[0].is_logical_observable_id()

@@ -1,0 +1,73 @@
+"""World-size-2 run of the multi-GPU plumbing on CPU (gloo): shot sharding + the one (errors, shots) all-reduce."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle")); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np
+import helpers, oracle as orc
+from quits_amd import parallel
+rank, world, _ = parallel.env_rank_world()
+dist = parallel.init_distributed("gloo")
+assert (dist is not None) == (world > 1)
+N = 301
+lo, hi = parallel.shard_range(N, rank, world)
+H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+synd, obs, _ = orc.sample_dem(H, L, pri, seed=42, shot0=lo, B=hi - lo)         # counter-based sampler: shard = slice
+err, _ = orc.Graph(H, pri).decode_batch(synd, orc.make_params("minimum_sum", "parallel", 10, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32))
+fails = int(((np.asarray(L @ err.T %% 2).T != obs).any(axis=1)).sum())
+tot_err, tot_shots = parallel.reduce_counts(dist, fails, hi - lo)
+tmax = parallel.reduce_max(dist, float(rank + 1))
+if rank == 0:
+    print(json.dumps({"errors": tot_err, "shots": tot_shots, "tmax": tmax, "local": [lo, hi]}))
+if dist is not None:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def _run(world):
+    code = WORKER % {"root": ROOT}
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    if world == 1:
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    else:
+        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                              "--master-addr", "127.0.0.1", "--master-port", "29617", _script(code)],
+                             env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def _script(code):
+    import tempfile
+    f = tempfile.NamedTemporaryFile("w", suffix="_worker.py", delete=False)
+    f.write(code)
+    f.close()
+    return f.name
+
+
+def test_shard_range_partitions():
+    from quits_amd.parallel import shard_range
+    for total in (0, 1, 7, 301, 10 ** 6):
+        for world in (1, 2, 3, 8):
+            parts = [shard_range(total, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == total
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_ranks_equal_one_rank():
+    one = _run(1)
+    two = _run(2)
+    assert one["shots"] == two["shots"] == 301
+    assert one["errors"] == two["errors"]           # same global shot indices -> same syndromes -> same failures
+    assert two["tmax"] == 2.0 and one["tmax"] == 1.0

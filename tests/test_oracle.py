@@ -1,0 +1,168 @@
+"""The CPU oracle (oracle/qd_oracle.c) against the reference's golden vectors and its own invariants."""
+import numpy as np
+import pytest
+from scipy.sparse import csc_matrix, csr_matrix
+
+import helpers
+import oracle as orc
+
+
+def _gf2_gauss_solve(A, b, order):
+    """Dense textbook elimination in a given column order (independent of the oracle's bookkeeping):
+    returns (solution using the first independent columns, rank, consistent)."""
+    A = A.copy() % 2
+    b = b.copy() % 2
+    m, n = A.shape
+    piv_rows, piv_cols = [], []
+    used = np.zeros(m, bool)
+    for c in order:
+        rows = np.flatnonzero((A[:, c] == 1) & ~used)
+        if rows.size == 0:
+            continue
+        p = rows[0]
+        used[p] = True
+        for r in np.flatnonzero(A[:, c]):
+            if r != p:
+                A[r] ^= A[p]
+                b[r] ^= b[p]
+        piv_rows.append(p)
+        piv_cols.append(c)
+    x = np.zeros(n, np.uint8)
+    for p, c in zip(piv_rows, piv_cols):
+        x[c] = b[p]
+    return x, len(piv_cols), not b[~used].any()
+
+
+def test_gf2_known_answers_from_reference():
+    """G6: rank and solvability as computed by the reference's gf2_util (gf2_rank / gf2_solve)."""
+    z = np.load(helpers.GOLD + "/gf2.npz")
+    rng = np.random.default_rng(0)
+    for i in range(int(z["count"][0])):
+        m, n = (int(v) for v in z["shape%d" % i])
+        A = np.unpackbits(z["A%d" % i], axis=1)[:, :n]
+        if not A.any(axis=0).all() or not A.any(axis=1).all():
+            cols = np.flatnonzero(A.any(axis=0))
+        g = None
+        # the oracle needs priors in (0,1) and column weights <= 64
+        if A.sum(axis=0).max() > 64:
+            continue
+        keep = np.flatnonzero(A.any(axis=0))
+        g = orc.Graph(csr_matrix(A), np.full(n, 0.1))
+        assert g.rank() == int(z["rank%d" % i][0])
+        b = z["b%d" % i]
+        llr = rng.normal(size=n)
+        e, st = g.osd0(b, llr, stop_early=True)
+        assert not st["inconsistent"] and np.array_equal(A @ e % 2, b)
+        e_full, _ = g.osd0(b, llr, stop_early=False)
+        assert np.array_equal(e, e_full)
+        x, rank, ok = _gf2_gauss_solve(A, b, list(orc.column_order(llr)))
+        assert ok and rank == g.rank() and np.array_equal(x, e)
+        if int(z["bbad_ok%d" % i][0]) == 0:            # a right-hand side the reference reports unsolvable
+            _, st_bad = g.osd0(z["bbad%d" % i], llr, stop_early=True)
+            assert st_bad["inconsistent"]
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10."""
+    out = np.zeros(4, np.uint32)
+    L = orc.lib()
+    L.oq_philox(0, 0, 0, 0, 0, 0, out)
+    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    L.oq_philox(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, out)
+    assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    L.oq_philox(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0, out)
+    assert [hex(v) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+    assert L.oq_prob_threshold(0.5) == 2 ** 31 and L.oq_prob_threshold(0.0) == 0
+
+
+def test_sampler_statistics_and_determinism():
+    H, Lm, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    s1, o1, nf = orc.sample_dem(H, Lm, pri, seed=3, shot0=0, B=4000)
+    s2, o2, _ = orc.sample_dem(H, Lm, pri, seed=3, shot0=1000, B=500)
+    assert np.array_equal(s1[1000:1500], s2) and np.array_equal(o1[1000:1500], o2)      # counter-based: shots are addressable
+    assert abs(nf.mean() - pri.sum()) < 4 * np.sqrt(pri.sum() / 4000)
+    s3, _, _ = orc.sample_dem(H, Lm, pri, seed=4, shot0=0, B=100)
+    assert not np.array_equal(s1[:100], s3)
+
+
+@pytest.mark.parametrize("form", [orc.FORM_LDPC_F64, orc.FORM_COMPRESSED_F32, orc.FORM_COMPRESSED_F64, orc.FORM_LDPC_F32])
+def test_bp_invariants(form):
+    H, Lm, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    g = orc.Graph(H, pri)
+    prm = orc.make_params("minimum_sum", "parallel", 30, "osd_0", 0, 1.0, form)
+    conv, dec, llr, it = g.bp(np.zeros(H.shape[0], np.uint8), prm)
+    assert conv and it == 0 and not dec.any()                       # zero syndrome -> zero correction
+    synd, obs, _ = orc.sample_dem(H, Lm, pri, seed=9, shot0=0, B=200)
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    nconv = 0
+    for i in range(200):
+        conv, dec, llr, it = g.bp(synd[i], prm)
+        if conv:
+            nconv += 1
+            assert np.array_equal(Hd @ dec % 2, synd[i]) and 1 <= it <= 30
+            assert np.array_equal(dec, (llr <= 0).astype(np.uint8))
+        else:
+            assert it == 30
+    assert nconv > 100
+    # single faults: BP must converge to a correction with the fault's observable signature
+    Ld = np.asarray(Lm.todense(), dtype=np.int64)
+    for j in (0, 17, 400, 1300, 2591):
+        s = Hd[:, j] % 2
+        conv, dec, _, _ = g.bp(s.astype(np.uint8), prm)
+        assert conv and np.array_equal(Ld @ dec % 2, Ld[:, j] % 2)
+
+
+def test_forms_agree_statistically_and_schedules_run():
+    H, Lm, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    g = orc.Graph(H, pri)
+    synd, obs, _ = orc.sample_dem(H, Lm, pri, seed=10, shot0=0, B=400)
+    res = {}
+    for name, prm in (("ldpc", orc.make_params("minimum_sum", "parallel", 30, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)),
+                      ("gpu", orc.make_params("minimum_sum", "parallel", 30, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32)),
+                      ("c64", orc.make_params("minimum_sum", "parallel", 30, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F64)),
+                      ("ps", orc.make_params("product_sum", "parallel", 30, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)),
+                      ("serial", orc.make_params("minimum_sum", "serial", 10, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)),
+                      ("serial_ps", orc.make_params("product_sum", "serial", 10, "osd_cs", 2, 1.0, orc.FORM_LDPC_F64))):
+        err, flags = g.decode_batch(synd, prm)
+        assert np.array_equal((err.astype(np.int64) @ np.asarray(H.todense(), dtype=np.int64).T) % 2, synd), name
+        res[name] = (np.asarray(Lm @ err.T % 2).T != obs).any(axis=1).mean()
+    # same algorithm, different rounding: logical error rates within Monte-Carlo noise of each other
+    assert abs(res["ldpc"] - res["gpu"]) < 0.06 and abs(res["ldpc"] - res["c64"]) < 0.06
+    assert all(0.0 <= v < 0.35 for v in res.values())
+    with pytest.raises(ValueError):      # the compressed form only exists for flooding min-sum
+        g.decode_batch(synd[:2], orc.make_params("product_sum", "parallel", 5, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32))
+
+
+def test_osd_cs_never_worse_than_osd0():
+    H, Lm, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    g = orc.Graph(H, pri)
+    synd, _, _ = orc.sample_dem(H, Lm, pri, seed=12, shot0=0, B=60)
+    prm = orc.make_params("minimum_sum", "parallel", 8, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)
+    w = np.log(1.0 / pri)
+    checked = 0
+    for i in range(60):
+        conv, dec, llr, _ = g.bp(synd[i], prm)
+        if conv:
+            continue
+        e0, _ = g.osd0(synd[i], llr)
+        e1 = g.osd_w(synd[i], llr, "osd_cs", 1)
+        ee = g.osd_w(synd[i], llr, "osd_e", 3)
+        Hd = np.asarray(H.todense(), dtype=np.int64)
+        for e in (e0, e1, ee):
+            assert np.array_equal(Hd @ e % 2, synd[i])
+        assert w @ e1 <= w @ e0 + 1e-9 and w @ ee <= w @ e0 + 1e-9
+        checked += 1
+        if checked == 6:
+            break
+    assert checked >= 3
+
+
+def test_oracle_plugin_surface():
+    H, Lm, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    d = orc.OracleBpOsdDecoder(csc_matrix(H), channel_probs=pri, max_iter=10, bp_method="minimum_sum",
+                               schedule="parallel", osd_method="osd_0", osd_order=0)
+    s, _, _ = orc.sample_dem(H, Lm, pri, seed=1, shot0=5, B=1)
+    e = d.decode(s[0].astype(int))
+    assert e.shape == (H.shape[1],) and np.array_equal(np.asarray(H @ e % 2).ravel(), s[0])
+    with pytest.raises(ValueError):
+        orc.OracleBpOsdDecoder(csc_matrix(H))
