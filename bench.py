@@ -43,19 +43,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from quits_amd import parallel
+    rank, world, local_rank = parallel.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; the decoder has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    dist = parallel.init_distributed("nccl")      # "nccl" is RCCL on ROCm; None for a single process
 
     import helpers
     from quits_amd.decoder.base import detector_error_model_to_matrix
@@ -115,13 +110,9 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    counts = torch.tensor([int(fails.item()), args.shots * args.steps], dtype=torch.int64, device="cuda")
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)       # the path's only collective: 16 bytes over RCCL
-    elapsed = float(tmax.item())
-    n_err, n_shots = int(counts[0].item()), int(counts[1].item())
+    elapsed = parallel.reduce_max(dist, elapsed, "cuda")
+    # the path's only collective: 16 bytes over RCCL
+    n_err, n_shots = parallel.reduce_counts(dist, int(fails.item()), args.shots * args.steps, "cuda")
 
     # ---- per-kernel device time (HIP events recorded by the library on the launch stream) and algorithmic bytes
     prof = {"bp_ms": 0.0, "osd_ms": 0.0, "bp_launches": 0, "osd_launches": 0}
@@ -149,6 +140,19 @@ def main():
     bp_s = prof["bp_ms"] / 1e3
     achieved = (algo_bytes / bp_s / 1e9) if bp_s > 0 else 0.0
 
+    # HBM bytes per BP launch from the PMC passes of tools/profile_bench.sh (rocprofv3 cannot run inside this process);
+    # only quoted when the committed profile was taken on this exact workload.
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        try:
+            pm = json.load(open(pmc_path))
+            key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
+            if key in pm:
+                traffic, traffic_src = pm[key]["bp_bytes_per_launch"], pm[key]["source"]
+        except (ValueError, KeyError):
+            pass
+
     value = n_shots / elapsed
     pl = n_err / n_shots
     out = {
@@ -164,7 +168,7 @@ def main():
         "lfr_per_round": 1.0 - (1.0 - pl) ** (1.0 / R),
         "bp_converged_frac": conv_frac, "osd_frac": osd_frac, "mean_bp_iters": total_iters / max(1, st.numel()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "qd_bp_minsum_kernel", "avg_launch_ms": prof["bp_ms"] / max(1, prof["bp_launches"]),
                      "algorithmic_bytes_per_launch": algo_bytes / max(1, prof["bp_launches"]),
                      "note": "algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the kernel "
