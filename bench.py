@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--p", type=float, default=0.003)
+    ap.add_argument("--code", default="bb144", choices=["bb144", "bb72", "hgp225"],
+                    help="bb144 = the headline (BASELINE configs[2]); bb72 = configs[1]; hgp225 = configs[0] (their circuits at their p)")
     ap.add_argument("--window", type=int, nargs=2, default=None, metavar=("W", "F"))
     ap.add_argument("--cpu-shots", type=int, default=2000, help="bounded CPU-baseline sample (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -58,10 +60,14 @@ def main():
     from quits_amd.decoder.sliding_window import build_circuit_plan
     from quits_amd.dem import Circuit
 
-    R = 12
-    cname = "bb144_custom_r12_p%g" % args.p
+    if args.code == "bb144":
+        R, cname = 12, "bb144_custom_r12_p%g" % args.p
+    elif args.code == "bb72":
+        R, cname = 6, "bb72_custom_r6_p0.003"
+    else:
+        R, cname = 3, "hgp225_cardinal_r3_p0.01"
     circ = Circuit(helpers.circuit_text(cname))
-    code = helpers.code("bb144")
+    code = helpers.code(args.code)
     hz, lz = code["hz"], code["lz"]
     H, Lobs, pri = detector_error_model_to_matrix(circ)
     m, n = H.shape
@@ -160,9 +166,10 @@ def main():
         "value": value, "unit": "shots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BB [[144,12,12]] custom circuit, R=12, p=%g, Z basis; DEM %dx%d (E=%d); "
+        "config": {"workload": "%s circuit %s, R=%d, Z basis; DEM %dx%d (E=%d); "
                                "min-sum flooding BP max_iter=%d ms_scaling=1.0 + OSD-0; W=%d F=%d (%d window%s)"
-                               % (args.p, m, n, E, args.max_iter, W, F, len(plan.windows), "" if len(plan.windows) == 1 else "s"),
+                               % ({"bb144": "BB [[144,12,12]]", "bb72": "BB [[72,12,6]]", "hgp225": "HGP [[225,9,6]]"}[args.code],
+                                  cname, R, m, n, E, args.max_iter, W, F, len(plan.windows), "" if len(plan.windows) == 1 else "s"),
                    "shots_per_step_per_gpu": args.shots, "parallelism": "shots sharded over %d GPU(s), no data-path collective" % world},
         "logical_error_rate": pl, "ler_sigma": float(np.sqrt(max(pl * (1 - pl), 1e-30) / n_shots)),
         "lfr_per_round": 1.0 - (1.0 - pl) ** (1.0 / R),

@@ -1,0 +1,11 @@
+#!/bin/bash
+# BASELINE.json configs beyond the headline, one JSON line each (GPU box).  usage: tools/run_configs.sh > out.jsonl
+cd "$(dirname "$0")/.."
+B="python bench.py --steps 2 --warmup 1 --cpu-shots 300"
+$B --code hgp225 --shots 16384 --max-iter 30 2>/dev/null                 # configs[0] shape on the GPU (single window)
+$B --code hgp225 --shots 16384 --max-iter 30 --window 3 1 2>/dev/null
+$B --code bb72 --shots 65536 2>/dev/null                                   # configs[1]: [[72,12,6]], single window
+$B --code bb72 --shots 65536 --window 3 1 2>/dev/null                      # configs[1], W=3 F=1 (6 windows)
+$B --window 3 1 --shots 65536 2>/dev/null                                  # headline code, W=3 F=1 (12 windows)
+$B --window 5 3 --shots 65536 2>/dev/null                                  # headline code, W=5 F=3 (4 windows)
+for p in 0.001 0.002 0.004 0.005 0.006; do $B --p $p --shots 65536 --no-cpu 2>/dev/null; done   # configs[3] p-sweep (1 GPU)
