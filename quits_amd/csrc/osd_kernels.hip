@@ -23,21 +23,21 @@
 //   3. e[pivot column k] = transformed syndrome at pivot row k; everything else 0  (OSD-0).
 //
 // Two kernels share the elimination:
-//   qd_osd0_fast_kernel  sorts only the head of the order -- the <= 2048 columns with the smallest LLRs, picked by
-//                        bisecting on the key's top 12 bits -- and keeps <= 6..8 Q planes; ~75 KB of LDS, two
-//                        workgroups per CU.  Because elimination stops early this is enough for almost every shot; a
-//                        shot that runs out of sorted columns or of Q planes is appended to the "hard" list untouched.
-//   qd_osd0_full_kernel  sorts every column and keeps (or spills) all Q planes; one workgroup per CU; runs over the
-//                        hard list.  Same results by construction: both consume the same column order.
+//   qd_osd0_reg_kernel   draws the order lazily in tiers of 1024 columns (bisection on the key value), keeps each thread's
+//                        rows in registers with a write-through LDS mirror, ~80 KB of LDS -> two workgroups per CU.
+//   qd_osd0_full_kernel  sorts every column up front, all state in LDS, one workgroup per CU; used when a window has
+//                        more than 2048 detectors.  Same results by construction: both consume the same column order.
 #include "qd_internal.h"
 
 #define QD_NOKEY 0xFFFFFFFFu
 
 #ifdef QD_OSD_TIMING
+// phase timers accumulate in registers and are flushed once per shot (a global atomic per tick would stall every
+// following barrier on vmcnt(0) and measure itself)
 #define QD_TICK(slot)                                                                   \
     {                                                                                   \
         const unsigned long long now_ = wall_clock64();                                 \
-        if (threadIdx.x == 0 && a_dbg) atomicAdd(&a_dbg[slot], now_ - tick_);           \
+        acc_[slot] += now_ - tick_;                                                     \
         tick_ = now_;                                                                   \
     }
 #else
@@ -114,9 +114,6 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
     const int tid = threadIdx.x;
     constexpr int NW = T / 64;
     uint32_t *red = S.red;
-#ifdef QD_OSD_TIMING
-    unsigned long long tick_ = wall_clock64();
-#endif
     for (int r = tid; r < g.m_pad; r += T) {
         uint8_t s = 0;
         if (r < g.m) {
@@ -134,7 +131,6 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
     else if (tid < 64) red[tid] = 0u;
     __syncthreads();
 
-    QD_TICK(4)
     int npiv = 0, done = 0, hard = 0, phase = 0;
     for (int base = 0; base < ncols && !done && !hard; base += 64) {
         // ---- transform the next 64 columns: tb[r] bit c = (T * column_c)[r]
@@ -168,10 +164,6 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
                 }
                 S.tb[r] = x;
             }
-        QD_TICK(5)
-#ifdef QD_OSD_TIMING
-        if (tid == 0 && a_dbg) atomicAdd(&a_dbg[12], 1ull);
-#endif
         // ---- take pivots out of the batch, in column order
         for (;;) {
             uint32_t key = QD_NOKEY;
@@ -222,7 +214,6 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
             npiv = K + 1;
         }
         __syncthreads();                                  // last round's updates, before the next batch re-uses tb / reads rowpiv
-        QD_TICK(6)
     }
     if (!done && !hard && ncols < g.n) {
         // out of sorted columns: finished only if the syndrome happens to be resolved already or no row is left
@@ -257,7 +248,6 @@ __device__ int qd_osd_eliminate(const OsdGraphDev &g, const OsdLds &S, uint64_t 
             atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
         }
     __syncthreads();
-    QD_TICK(7)
     *npiv_out = npiv;
     *inconsistent_out = inconsistent;
     return 0;
@@ -277,110 +267,418 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
     S.outw = reinterpret_cast<uint32_t *>(smem + off[9]);
 }
 
-// ---- fast path: head of the order only --------------------------------------------------------------------------------
-// `cap` = number of columns to sort (<= QD_OSD_FAST_CAP).  Reads the shots to do from in_list (or the BP fail list
-// itself when in_list is null) and appends the ones it cannot finish to out_list.
-#define QD_OSD_KPT 24     // monotone keys a thread keeps in registers (covers n <= 24 * T; larger windows re-read the LLRs)
+// ---- register-resident path ------------------------------------------------------------------------------------------------
+// One kernel, no restarts: the column order is produced lazily in TIERS of <= QD_OSD_TIER columns (the next-smallest keys,
+// found by bisecting on the key value), each tier is bitonic-sorted and eliminated before the next one is drawn; the
+// elimination state survives between tiers.  A thread owns RPT rows and keeps their batch image, syndrome bit, pivot flag
+// and the first QD_OSD_KWR Q planes in registers; LDS holds a write-through mirror that other threads read when one of
+// those rows becomes the pivot row.  Q planes beyond the LDS budget spill to HBM (rare: > 64 * f_kw pivots).
+#define QD_OSD_TIER 1024
+#define QD_OSD_KWR 6
+#define QD_OSD_KPT 20     // monotone keys a thread keeps in registers while a tier is drawn (n <= 20 * T; else re-read)
+
+// Sum of v over the workgroup; one barrier; `buf` = 2 x 64 words alternating with `phase` (entries beyond the wave count must be zero).
 template <int T>
-__global__ void __launch_bounds__(T, T / 256) qd_osd0_fast_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a, int cap,
-                                                                  const int32_t *in_list, const int32_t *in_count,
-                                                                  int32_t *out_list, int32_t *out_count)
+__device__ __forceinline__ uint32_t qd_block_sum(uint32_t v, uint32_t *buf, int &phase)
+{
+    constexpr int NW = T / 64;
+    v = qd_wave_add(v);
+    if ((threadIdx.x & 63) == 0) buf[phase * 64 + (threadIdx.x >> 6)] = v;     // 64-word stride: the 3-way counter of the tier search shares these buffers
+    __syncthreads();
+    const uint4 *p4 = reinterpret_cast<const uint4 *>(buf + phase * 64);
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < (NW + 3) / 4; ++w) { const uint4 x = p4[w]; tot += x.x + x.y + x.z + x.w; }
+    phase ^= 1;
+    return tot;
+}
+
+// Only what this kernel needs, so the scalar registers are not flooded with three full descriptor structs.
+struct OsdRegArgs {
+    int m, n, m_pad, n_pad, max_cdeg, mw, f_kw, out_words, upd_rows;
+    int off[10], off_sort, off_order;
+    const uint32_t *csc_ptr;
+    const uint16_t *csc_row;
+    const uint32_t *bit_orig;
+    const uint8_t *det, *upd;
+    int64_t det_stride, det_offset, upd_stride;
+    const float *llr_ws;
+    const int32_t *fail_list, *fail_count;
+    uint64_t *q_spill_fast;
+    uint32_t *err_bits;
+    int32_t *status;
+    unsigned long long *dbg;
+};
+
+struct TierState { uint32_t lo_key, lo_idx; int sphase, exhausted; };
+
+// Draws the next tier: the <= QD_OSD_TIER not yet consumed columns with the smallest (key, fault index), sorted, as fault
+// indices in order[0..cnt).  State: every column with (key, index) < (lo_key, lo_idx) has been consumed.
+template <int T>
+__device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *llr, uint64_t *sortbuf, uint16_t *order,
+                                             uint32_t *red, uint32_t *sumbuf, TierState &ts)
+{
+    const int tid = threadIdx.x;
+    const int n = a.n;
+    const bool in_regs = n <= QD_OSD_KPT * T;
+    uint32_t lo_key = ts.lo_key, lo_idx = ts.lo_idx;
+    int sphase = ts.sphase;
+    bool exhausted = false;
+    int cnt = 0;
+    {
+            uint32_t kreg[QD_OSD_KPT];
+            if (in_regs) {
+#pragma unroll
+                for (int i = 0; i < QD_OSD_KPT; ++i) {
+                    const int b = tid + i * T;
+                    kreg[i] = (b < n) ? qd_mono_key(llr[b]) : 0xFFFFFFFFu;
+                }
+            }
+            // tie group at key == lo_key that is only partly consumed (or too big for one tier): ordered by fault index;
+            // rare, so it simply re-reads the LLRs and fault indices
+            auto count_ties = [&](uint32_t key, uint32_t ilo, uint32_t ihi) -> uint32_t {
+                uint32_t c = 0;
+                for (int b = tid; b < n; b += T)
+                    if (qd_mono_key(llr[b]) == key) { const uint32_t j = a.bit_orig[b]; c += (j >= ilo && j < ihi) ? 1u : 0u; }
+                return qd_block_sum<T>(c, sumbuf, sphase);
+            };
+            bool by_index = false;
+            uint32_t t_lo = lo_key, t_hi = lo_key, i_lo = 0, i_hi = 0;
+            if (lo_idx > 0) {
+                if (count_ties(lo_key, lo_idx, 0xFFFFFFFFu) > 0) by_index = true;
+                else { lo_key += 1; lo_idx = 0; }
+            }
+            if (!by_index) {
+                // largest t_hi with  #{lo_key <= key < t_hi} <= TIER   (key 0xFFFFFFFF is reserved for "no column").
+                // 4-ary search, three thresholds per barrier: first on the top 12 key bits (6 rounds); the low 20 bits
+                // are only resolved when that coarse cut would yield a thin tier.
+                auto count3 = [&](uint32_t h1, uint32_t h2, uint32_t h3, uint32_t &c1, uint32_t &c2, uint32_t &c3) {
+                    uint32_t x1 = 0, x2 = 0, x3 = 0;
+                    const uint32_t lo = lo_key;
+                    if (in_regs) {
+#pragma unroll
+                        for (int i = 0; i < QD_OSD_KPT; ++i) {
+                            const uint32_t u = kreg[i];
+                            const uint32_t ge = (u >= lo) ? 1u : 0u;
+                            x1 += ge & ((u < h1) ? 1u : 0u); x2 += ge & ((u < h2) ? 1u : 0u); x3 += ge & ((u < h3) ? 1u : 0u);
+                        }
+                    } else {
+                        for (int b = tid; b < n; b += T) {
+                            const uint32_t u = qd_mono_key(llr[b]);
+                            const uint32_t ge = (u >= lo) ? 1u : 0u;
+                            x1 += ge & ((u < h1) ? 1u : 0u); x2 += ge & ((u < h2) ? 1u : 0u); x3 += ge & ((u < h3) ? 1u : 0u);
+                        }
+                    }
+                    x1 = qd_wave_add(x1); x2 = qd_wave_add(x2); x3 = qd_wave_add(x3);
+                    uint32_t *buf = sumbuf + sphase * 64;                      // per phase: 3 x 16 partials
+                    if ((tid & 63) == 0) { buf[tid >> 6] = x1; buf[16 + (tid >> 6)] = x2; buf[32 + (tid >> 6)] = x3; }
+                    __syncthreads();
+                    c1 = c2 = c3 = 0;
+                    constexpr int NWv = (T / 64 + 3) / 4;
+                    const uint4 *p4 = reinterpret_cast<const uint4 *>(buf);
+#pragma unroll
+                    for (int w = 0; w < NWv; ++w) {
+                        const uint4 a1 = p4[w], a2 = p4[4 + w], a3 = p4[8 + w];
+                        c1 += a1.x + a1.y + a1.z + a1.w; c2 += a2.x + a2.y + a2.z + a2.w; c3 += a3.x + a3.y + a3.z + a3.w;
+                    }
+                    sphase ^= 1;
+                };
+                // search over v in [vlo, vhi] (units of `unit` keys) for the largest v with count(lo_key, v * unit) <= TIER
+                auto search = [&](uint64_t vlo, uint64_t vhi, int shift, uint32_t &cnt_at) -> uint64_t {
+                    uint64_t L = vlo, H = vhi;
+                    while (L < H) {
+                        const uint64_t span = H - L;
+                        uint64_t m1 = L + (span + 3) / 4, m2 = L + (span + 1) / 2, m3 = L + (3 * span + 3) / 4;
+                        if (m2 < m1) m2 = m1;
+                        if (m3 < m2) m3 = m2;
+                        auto thr = [&](uint64_t v) -> uint32_t { const uint64_t t = v << shift; return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t; };
+                        uint32_t c1, c2, c3;
+                        count3(thr(m1), thr(m2), thr(m3), c1, c2, c3);
+                        if (c3 <= (uint32_t)QD_OSD_TIER) { L = m3; cnt_at = c3; }
+                        else if (c2 <= (uint32_t)QD_OSD_TIER) { L = m2; cnt_at = c2; H = m3 - 1; }
+                        else if (c1 <= (uint32_t)QD_OSD_TIER) { L = m1; cnt_at = c1; H = m2 - 1; }
+                        else H = m1 - 1;
+                    }
+                    return L;
+                };
+                uint32_t cntL = 0;
+                // coarse: thresholds that are multiples of 2^20, never below lo_key's own bin boundary above it
+                const uint64_t b_lo = ((uint64_t)lo_key + 0xFFFFFull) >> 20;        // first bin boundary >= lo_key
+                uint64_t Lb = search(b_lo > 0 ? b_lo - 1 : 0, 4096, 20, cntL);      // v = b_lo - 1 stands for "nothing" (threshold <= lo_key)
+                uint64_t Lfine;
+                if (Lb >= b_lo && cntL >= (uint32_t)(QD_OSD_TIER / 4)) Lfine = (Lb << 20) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (Lb << 20);
+                else {
+                    // resolve the low bits between the coarse cut and the next bin boundary
+                    const uint64_t f_lo = (Lb >= b_lo) ? ((Lb << 20) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (Lb << 20)) : (uint64_t)lo_key;
+                    uint64_t f_hi = (Lb + 1) << 20;
+                    if (f_hi > 0xFFFFFFFFull) f_hi = 0xFFFFFFFFull;
+                    if (Lb < b_lo) cntL = 0;
+                    Lfine = search(f_lo, f_hi, 0, cntL);
+                }
+                t_lo = lo_key; t_hi = (uint32_t)Lfine;
+                cnt = (int)cntL;
+                if (cnt == 0) {
+                    if (t_hi == 0xFFFFFFFFu) exhausted = true;                 // nothing at or above lo_key
+                    else { lo_key = t_hi; lo_idx = 0; by_index = true; }       // more than TIER columns share the next key value
+                } else lo_key = t_hi;
+            }
+            if (by_index) {
+                uint64_t L = lo_idx, H = (uint64_t)n;
+                uint32_t cntL = 0;
+                while (L < H) {
+                    const uint64_t mid = (L + H + 1) >> 1;
+                    const uint32_t c = count_ties(lo_key, lo_idx, (uint32_t)mid);
+                    if (c <= (uint32_t)QD_OSD_TIER) { L = mid; cntL = c; } else H = mid - 1;
+                }
+                i_lo = lo_idx; i_hi = (uint32_t)L;
+                cnt = (int)cntL;
+                t_lo = lo_key;
+                if (i_hi >= (uint32_t)n) { lo_key += 1; lo_idx = 0; } else lo_idx = i_hi;
+            }
+            if (exhausted) { ts.lo_key = lo_key; ts.lo_idx = lo_idx; ts.sphase = sphase; ts.exhausted = 1; return 0; }
+            // gather (one LDS counter bump per wavefront) and sort the tier
+            if (tid == 0) red[80] = 0u;
+            __syncthreads();
+            for (int i = 0; i * T < n; ++i) {
+                const int b = tid + i * T;
+                uint32_t u = 0xFFFFFFFFu, j = 0;
+                bool take = false;
+                if (b < n) {
+                    u = qd_mono_key(llr[b]);
+                    if (by_index) { if (u == t_lo) { j = a.bit_orig[b]; take = (j >= i_lo && j < i_hi); } }
+                    else if (u >= t_lo && u < t_hi) { j = a.bit_orig[b]; take = true; }
+                }
+                const unsigned long long bal = __ballot(take);
+                uint32_t wbase = 0;
+                if ((tid & 63) == 0 && bal) wbase = atomicAdd(&red[80], (uint32_t)__popcll(bal));
+                wbase = (uint32_t)__shfl((int)wbase, 0);
+                if (take) sortbuf[wbase + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull))] = ((uint64_t)u << 32) | j;
+            }
+            __syncthreads();
+            int P = 64;
+            while (P < cnt) P <<= 1;
+            for (int i = cnt + tid; i < P; i += T) sortbuf[i] = ~0ull;
+            __syncthreads();
+            qd_bitonic_u64<T>(sortbuf, P, tid);
+            for (int i = tid; i < cnt; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
+            __syncthreads();
+    }
+    ts.lo_key = lo_key; ts.lo_idx = lo_idx; ts.sphase = sphase; ts.exhausted = 0;
+    return cnt;
+}
+
+template <int T, int RPT>
+__global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
-    const int nlist = *in_count;
+    constexpr int NW = T / 64;
+    constexpr int KWR = QD_OSD_KWR;
+    const int nfail = *a.fail_count;
     OsdLds S;
-    qd_osd_carve(smem, g.f_off, S);
-    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + g.f_off_sort);     // [QD_OSD_FAST_CAP], overlaps the Q planes
-    uint16_t *order = reinterpret_cast<uint16_t *>(smem + g.f_off_order);      // [QD_OSD_FAST_CAP]
-    uint32_t *red = S.red;
-    const bool in_regs = g.n <= QD_OSD_KPT * T;
-    for (int li = blockIdx.x; li < nlist; li += gridDim.x) {
-        const int slot = in_list ? in_list[li] : li;
+    qd_osd_carve(smem, a.off, S);
+    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + a.off_sort);       // [QD_OSD_TIER]
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem + a.off_order);        // [QD_OSD_TIER]
+    uint32_t *red = S.red;            // [0..31] pivot keys A/B, [32..63] flags A/B, [64] pair counter, [96..127] block sums A/B, [80] gather counter
+    uint32_t *sumbuf = red + 96;
+    const int m = a.m, m_pad = a.m_pad, n = a.n, kw_lds = a.f_kw;
+    uint64_t *qglb = a.q_spill_fast ? a.q_spill_fast + (int64_t)blockIdx.x * (int64_t)(a.mw - kw_lds) * m_pad : nullptr;
+    const bool in_regs = n <= QD_OSD_KPT * T;
+
+    for (int slot = blockIdx.x; slot < nfail; slot += gridDim.x) {
         const int64_t shot = a.fail_list[slot];
-        const float *llr = a.llr_ws + (int64_t)slot * bg.n_pad;
-#ifdef QD_OSD_TIMING
-        unsigned long long *a_dbg = a.dbg;
-        unsigned long long tick_ = wall_clock64();
-#endif
-        uint32_t kreg[QD_OSD_KPT];
-        if (in_regs) {
-#pragma unroll
-            for (int i = 0; i < QD_OSD_KPT; ++i) {
-                const int b = tid + i * T;
-                kreg[i] = (b < g.n) ? qd_mono_key(llr[b]) : 0xFFFFFFFFu;
-            }
-        }
-        // ---- 1a. hi = largest number of leading key bins (top 12 bits) whose population fits `cap`.
-        //      Bisection on counts: 12 rounds of (compare, wave sum, one LDS add per wave, one barrier).
-        uint32_t lo_b = 0, hi_b = 4096;                      // invariant: count(bin < lo_b) <= cap
-        if (tid < 16) red[64 + tid] = 0u;
-        __syncthreads();
-        for (int it = 0; it < 12; ++it) {
-            const uint32_t mid = (lo_b + hi_b + 1) >> 1;
-            uint32_t c = 0;
-            if (in_regs) {
-#pragma unroll
-                for (int i = 0; i < QD_OSD_KPT; ++i) c += ((kreg[i] >> 20) < mid) ? 1u : 0u;
-            } else {
-                for (int b = tid; b < g.n; b += T) c += ((qd_mono_key(llr[b]) >> 20) < mid) ? 1u : 0u;
-            }
-            c = qd_wave_add(c);
-            if ((tid & 63) == 0) atomicAdd(&red[64 + it], c);
-            __syncthreads();
-            if (red[64 + it] <= (uint32_t)cap) lo_b = mid; else hi_b = mid - 1;
-        }
-        const uint32_t hi = lo_b;
-        QD_TICK(0)
-        // ---- 1b. gather and sort the head (one LDS counter bump per wavefront)
-        if (tid == 0) red[80] = 0u;
-        __syncthreads();
-        for (int i = 0; i * T < g.n; ++i) {
-            const int b = tid + i * T;
-            uint32_t u = 0xFFFFFFFFu;
-            if (in_regs) {
-                // kreg is indexed with a compile-time constant only when the loop is unrolled; re-derive instead
-                u = (b < g.n) ? qd_mono_key(llr[b]) : 0xFFFFFFFFu;
-            } else if (b < g.n) u = qd_mono_key(llr[b]);
-            const bool take = (b < g.n) && (u >> 20) < hi;
-            const unsigned long long bal = __ballot(take);
-            uint32_t wbase = 0;
-            if ((tid & 63) == 0 && bal) wbase = atomicAdd(&red[80], (uint32_t)__popcll(bal));
-            wbase = (uint32_t)__shfl((int)wbase, 0);
-            if (take) sortbuf[wbase + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull))] = ((uint64_t)u << 32) | bg.bit_orig[b];
-        }
-        __syncthreads();
-        const int cnt = (int)red[80];
-        int P = 64;
-        while (P < cnt) P <<= 1;
-        for (int i = cnt + tid; i < P; i += T) sortbuf[i] = ~0ull;
-        __syncthreads();
-        QD_TICK(1)
-        qd_bitonic_u64<T>(sortbuf, P, tid);
-        for (int i = tid; i < cnt; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
-        __syncthreads();
-        QD_TICK(2)
-        // ---- 2./3. elimination on the head
+        const float *llr = a.llr_ws + (int64_t)slot * a.n_pad;
         const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
         const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
-        int npiv = 0, inconsistent = 0;
 #ifdef QD_OSD_TIMING
-        const int rc = qd_osd_eliminate<T, false>(g, S, nullptr, g.f_kw, g.f_kw * 64, order, cnt, det, upd, a.upd_rows,
-                                                  bg.out_words, &npiv, &inconsistent, a_dbg);
-        tick_ = wall_clock64();
-#else
-        const int rc = qd_osd_eliminate<T, false>(g, S, nullptr, g.f_kw, g.f_kw * 64, order, cnt, det, upd, a.upd_rows,
-                                                  bg.out_words, &npiv, &inconsistent);
+        unsigned long long *a_dbg = a.dbg;
+        unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long tick_ = wall_clock64();
 #endif
-#ifdef QD_OSD_TIMING
-        if (tid == 0) { atomicAdd(&a_dbg[8], 1ull); atomicAdd(&a_dbg[9], (unsigned long long)npiv); atomicAdd(&a_dbg[10], (unsigned long long)cnt); atomicAdd(&a_dbg[11], (unsigned long long)rc); }
-#endif
-        if (rc) {
-            if (tid == 0) out_list[atomicAdd(out_count, 1)] = slot;
-        } else {
-            for (int w = tid; w < bg.out_words; w += T) a.err_bits[shot * bg.out_words + w] = S.outw[w];
-            if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
+        // ---- elimination state: registers + LDS mirror
+        uint64_t my_tb[RPT], my_q[RPT][KWR];
+        uint32_t my_sp = 0, my_piv = 0;              // bit i: row tid + i*T
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = tid + i * T;
+            uint32_t sbit = 0;
+            if (r < m) {
+                sbit = det[r] & 1u;
+                if (upd && r < a.upd_rows) sbit ^= upd[r] & 1u;
+            }
+            my_sp |= sbit << i;
+            my_tb[i] = 0ull;
+#pragma unroll
+            for (int w = 0; w < KWR; ++w) my_q[i][w] = 0ull;
+            if (r < m_pad) {
+                S.sp[r] = (uint8_t)sbit; S.rowpiv[r] = -1;
+#pragma unroll
+                for (int w = 0; w < KWR; ++w)
+                    if (w < kw_lds) S.q[(size_t)w * m_pad + r] = 0ull;      // the register planes' mirror; later planes are cleared when first used
+            }
         }
+        for (int w = tid; w < a.out_words; w += T) S.outw[w] = 0u;
+        if (tid < 64) red[tid] = ((tid & 16) == 0) ? QD_NOKEY : 0u;      // per phase: 16 keys then 16 flags
+        __syncthreads();
+
+        int npiv = 0, done = 0, phase = 0, sphase = 0;
+        uint32_t lo_key = 0, lo_idx = 0;             // every column with (key, fault index) < (lo_key, lo_idx) has been consumed
+        while (!done) {
+            // =============== draw the next tier of the column order (kept out of line: its 20 key registers and unrolled
+            // compares must not push the elimination state of this loop into scratch)
+            TierState ts{lo_key, lo_idx, sphase, 0};
+            const int cnt = qd_osd_draw_tier<T>(a, llr, sortbuf, order, red, sumbuf, ts);
+            lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
+            if (ts.exhausted) break;
+            QD_TICK(0)
+
+            // =============== eliminate over this tier, 64 columns at a time
+            for (int base = 0; base < cnt && !done; base += 64) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) { const int r = tid + i * T; if (r < m_pad) S.tb[r] = 0ull; }
+                if (tid == 0) red[64] = 0u;
+                if (tid < 64) S.bcols[tid] = (base + tid < cnt) ? (uint32_t)order[base + tid] : 0xFFFFFFFFu;
+                __syncthreads();
+                for (int x = tid; x < 64 * a.max_cdeg; x += T) {
+                    const int c = x / a.max_cdeg, q = x - c * a.max_cdeg;
+                    const uint32_t col = S.bcols[c];
+                    if (col != 0xFFFFFFFFu) {
+                        const uint32_t e0 = a.csc_ptr[col], e1 = a.csc_ptr[col + 1];
+                        if (e0 + q < e1) {
+                            const int r = a.csc_row[e0 + q];
+                            atomicXor(reinterpret_cast<unsigned long long *>(&S.tb[r]), 1ull << c);
+                            const int k = S.rowpiv[r];
+                            if (k >= 0) S.pairs[atomicAdd(&red[64], 1u)] = (uint32_t)c | ((uint32_t)k << 8);
+                        }
+                    }
+                }
+                __syncthreads();
+                const int np = (int)red[64];
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = tid + i * T;
+                    uint64_t x = 0ull;
+                    if (r < m) {
+                        x = S.tb[r];
+                        for (int pi = 0; pi < np; ++pi) {
+                            const uint32_t pr = S.pairs[pi];
+                            const int k = (int)(pr >> 8);
+                            const uint64_t qw = qd_q_load<true>(S, qglb, kw_lds, m_pad, k >> 6, r);
+                            x ^= ((qw >> (k & 63)) & 1ull) << (pr & 63u);
+                        }
+                        if (np) S.tb[r] = x;
+                    }
+                    my_tb[i] = x;
+                }
+                QD_TICK(1)
+                // ---- pivots of this batch, one barrier per round
+                for (;;) {
+                    uint32_t key = QD_NOKEY;
+                    uint32_t resid = 0;
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + i * T;
+                        if (r < m && !((my_piv >> i) & 1u)) {
+                            if (my_tb[i]) key = min(key, ((uint32_t)__builtin_ctzll(my_tb[i]) << 16) | (uint32_t)r);
+                            resid |= (my_sp >> i) & 1u;
+                        }
+                    }
+                    key = qd_wave_umin(key);
+                    const unsigned long long bal = __ballot(resid != 0u);
+                    if ((tid & 63) == 0) { red[phase * 32 + (tid >> 6)] = key; red[phase * 32 + 16 + (tid >> 6)] = (bal != 0ull); }
+                    QD_TICK(4)
+                    __syncthreads();
+                    QD_TICK(5)
+                    key = QD_NOKEY;
+                    uint32_t anyres = 0;
+                    {
+                        // partial keys and flags sit in one 128-byte record per phase: [0..15] keys, [16..31] flags
+                        const uint4 *kv = reinterpret_cast<const uint4 *>(red + phase * 32);
+                        uint4 k4[(NW + 3) / 4], f4[(NW + 3) / 4];
+#pragma unroll
+                        for (int w = 0; w < (NW + 3) / 4; ++w) { k4[w] = kv[w]; f4[w] = kv[4 + w]; }
+#pragma unroll
+                        for (int w = 0; w < (NW + 3) / 4; ++w) {
+                            key = min(key, min(min(k4[w].x, k4[w].y), min(k4[w].z, k4[w].w)));
+                            anyres |= f4[w].x | f4[w].y | f4[w].z | f4[w].w;
+                        }
+                    }
+                    phase ^= 1;
+                    // every lane holds the same values; tell the compiler, so that the round runs on scalar control flow
+                    key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+                    anyres = (uint32_t)__builtin_amdgcn_readfirstlane((int)anyres);
+                    if (!anyres) { done = 1; break; }        // syndrome already in the span of the pivots found
+                    if (key == QD_NOKEY) break;               // rest of the batch depends on earlier pivots
+                    const int c = (int)(key >> 16), p = (int)(key & 0xFFFFu);
+                    const int K = npiv, kw = K >> 6;
+                    const uint64_t kb = 1ull << (K & 63);
+                    // pivot row, from the LDS mirror (its owner does not touch it this round)
+                    const uint64_t tp = S.tb[p];
+                    const uint32_t spp = S.sp[p];
+                    uint64_t qp[KWR];
+#pragma unroll
+                    for (int w = 0; w < KWR; ++w) qp[w] = (w <= kw) ? S.q[(size_t)w * m_pad + p] : 0ull;   // wave-uniform guards: most shots stay in plane 0..1
+                    // The host guarantees f_kw >= min(KWR, mw) LDS planes; planes >= mw (tiny windows) read past the Q
+                    // region: the values are never stored nor used because a pivot index never reaches such a plane.
+                    QD_TICK(6)
+                    const bool fresh = (K & 63) == 0 && kw >= KWR;     // first pivot of a memory-only plane: still uninitialised
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + i * T;
+                        if (r >= m) continue;
+                        if (fresh) qd_q_store<true>(S, qglb, kw_lds, m_pad, kw, r, 0ull);
+                        if (r == p) {
+                            my_piv |= 1u << i;
+                            S.rowpiv[r] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = S.bcols[c];      // the owner records the pivot
+                        } else if ((my_tb[i] >> c) & 1ull) {
+                            my_tb[i] ^= tp;
+                            S.tb[r] = my_tb[i];
+                            if (spp) { my_sp ^= 1u << i; S.sp[r] = (uint8_t)((my_sp >> i) & 1u); }
+#pragma unroll
+                            for (int w = 0; w < KWR; ++w)
+                                if (w <= kw) {
+                                    uint64_t v = my_q[i][w] ^ qp[w];
+                                    if (w == kw) v ^= kb;
+                                    my_q[i][w] = v;
+                                    S.q[(size_t)w * m_pad + r] = v;
+                                }
+                            for (int w = KWR; w <= kw; ++w) {       // beyond the register planes: memory only
+                                uint64_t v = qd_q_load<true>(S, qglb, kw_lds, m_pad, w, r);
+                                if (!(fresh && w == kw)) v ^= qd_q_load<true>(S, qglb, kw_lds, m_pad, w, p);
+                                if (w == kw) v ^= kb;
+                                qd_q_store<true>(S, qglb, kw_lds, m_pad, w, r, v);
+                            }
+                        }
+                    }
+                    npiv = K + 1;
+                    QD_TICK(7)
+                }
+                __syncthreads();          // last round's mirror updates, before the next batch re-uses tb / reads rowpiv
+                QD_TICK(2)
+            }
+        }
+        // ---- residual left on a non-pivot row <=> syndrome outside the column space
+        uint32_t resid = 0;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i)
+            if (tid + i * T < m && !((my_piv >> i) & 1u)) resid |= (my_sp >> i) & 1u;
+        const int inconsistent = qd_block_sum<T>(resid, sumbuf, sphase) != 0u;
+        // ---- OSD-0 solution: e[pivot column k] = transformed syndrome at pivot row k
+        for (int k = tid; k < npiv; k += T)
+            if (S.sp[S.prow[k]]) {
+                const uint32_t j = S.pcol[k];
+                atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
+            }
+        __syncthreads();
+        for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = S.outw[w];
+        if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
+        QD_TICK(3)
+#ifdef QD_OSD_TIMING
+        if (tid == 0) {
+            for (int i = 0; i < 8; ++i) atomicAdd(&a_dbg[i], acc_[i]);
+            atomicAdd(&a_dbg[8], 1ull); atomicAdd(&a_dbg[9], (unsigned long long)npiv);
+        }
+#endif
         __syncthreads();   // LDS is recycled by the next shot
     }
 }
@@ -423,39 +721,52 @@ __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphD
     }
 }
 
-// Three passes over ever shorter lists: head of 512 columns, head of 2048 columns, everything.
-template <int TF, int T>
-static hipError_t launch_osd_t(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
-                               int blocks_full, hipStream_t s)
+template <int TF, int RPT>
+static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s)
 {
-    hipError_t e;
-    auto kf = qd_osd0_full_kernel<T>;
-    e = hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
+    auto k = qd_osd0_reg_kernel<TF, RPT>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.f_lds_bytes);
     if (e != hipSuccess) return e;
-    if (g.f_lds_bytes > 0) {
-        auto kq = qd_osd0_fast_kernel<TF>;
-        e = hipFuncSetAttribute((const void *)kq, hipFuncAttributeMaxDynamicSharedMemorySize, g.f_lds_bytes);
-        if (e != hipSuccess) return e;
-        int32_t *cnt = a.hard_count;            // [0] after pass 1, [1] after pass 2
-        hipLaunchKernelGGL(kq, dim3((unsigned)blocks_fast), dim3(TF), g.f_lds_bytes, s, g, bg, a, 512,
-                           (const int32_t *)nullptr, (const int32_t *)a.fail_count, a.hard_list, cnt);
-        hipLaunchKernelGGL(kq, dim3((unsigned)blocks_fast), dim3(TF), g.f_lds_bytes, s, g, bg, a, QD_OSD_FAST_CAP,
-                           (const int32_t *)a.hard_list, (const int32_t *)cnt, a.hard_list2, cnt + 1);
-        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, (const int32_t *)a.hard_list2,
-                           (const int32_t *)(cnt + 1));
-    } else {
-        hipLaunchKernelGGL(kf, dim3((unsigned)blocks_full), dim3(T), g.lds_bytes, s, g, bg, a, (const int32_t *)nullptr,
-                           (const int32_t *)a.fail_count);
-    }
+    OsdRegArgs r{};
+    r.m = g.m; r.n = g.n; r.m_pad = g.m_pad; r.n_pad = bg.n_pad; r.max_cdeg = g.max_cdeg; r.mw = g.mw; r.f_kw = g.f_kw;
+    r.out_words = bg.out_words; r.upd_rows = a.upd_rows;
+    for (int i = 0; i < 10; ++i) r.off[i] = g.f_off[i];
+    r.off_sort = g.f_off_sort; r.off_order = g.f_off_order;
+    r.csc_ptr = g.csc_ptr; r.csc_row = g.csc_row; r.bit_orig = bg.bit_orig;
+    r.det = a.det; r.upd = a.upd; r.det_stride = a.det_stride; r.det_offset = a.det_offset; r.upd_stride = a.upd_stride;
+    r.llr_ws = a.llr_ws; r.fail_list = a.fail_list; r.fail_count = a.fail_count; r.q_spill_fast = a.q_spill_fast;
+    r.err_bits = a.err_bits; r.status = a.status; r.dbg = a.dbg;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TF), g.f_lds_bytes, s, r);
+    return hipGetLastError();
+}
+
+template <int T>
+static hipError_t launch_full(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s)
+{
+    auto kf = qd_osd0_full_kernel<T>;
+    hipError_t e = hipFuncSetAttribute((const void *)kf, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(T), g.lds_bytes, s, g, bg, a, (const int32_t *)nullptr,
+                       (const int32_t *)a.fail_count);
     return hipGetLastError();
 }
 
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s)
 {
+    if (g.f_lds_bytes > 0) {
+        const int rpt = (g.m + g.f_threads - 1) / g.f_threads;
+        if (g.f_threads == 256) return launch_reg<256, 1>(g, bg, a, blocks_fast, s);
+        switch (rpt) {
+        case 1: return launch_reg<512, 1>(g, bg, a, blocks_fast, s);
+        case 2: return launch_reg<512, 2>(g, bg, a, blocks_fast, s);
+        case 3: return launch_reg<512, 3>(g, bg, a, blocks_fast, s);
+        default: return launch_reg<512, 4>(g, bg, a, blocks_fast, s);
+        }
+    }
     switch (g.threads) {
-    case 256: return launch_osd_t<256, 256>(g, bg, a, blocks_fast, blocks_full, s);
-    case 512: return launch_osd_t<512, 512>(g, bg, a, blocks_fast, blocks_full, s);
-    default: return launch_osd_t<512, 1024>(g, bg, a, blocks_fast, blocks_full, s);
+    case 256: return launch_full<256>(g, bg, a, blocks_full, s);
+    case 512: return launch_full<512>(g, bg, a, blocks_full, s);
+    default: return launch_full<1024>(g, bg, a, blocks_full, s);
     }
 }

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -75,7 +76,7 @@ struct qd_decoder {
     float *llr_ws = nullptr;
     int32_t *fail_list = nullptr, *fail_count = nullptr;
     uint16_t *order_ws = nullptr;
-    uint64_t *q_spill = nullptr;
+    uint64_t *q_spill = nullptr, *q_spill_fast = nullptr;
     int32_t *hard_list = nullptr, *hard_list2 = nullptr;
     int osd_blocks_fast = 0;
     int profiling = 0;
@@ -279,7 +280,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         offs[5] = o; o += align16(m_pad * 4);          // pcol
         offs[6] = o; o += align16(64 * max_cdeg * 4);  // pairs
         offs[7] = o; o += 256;                         // cols
-        offs[8] = o; o += 1024;                        // red
+        offs[8] = o; o += 1024;                        // red: 96 words of pivot/flag/counter scratch + 2 x 64 words of block sums
         offs[9] = o; o += align16(bp.out_words * 4);   // out
         return o;
     };
@@ -295,18 +296,18 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     } else {
         od.kw_lds = std::min(od.mw, q_budget / (m_pad * 8));
         od.lds_bytes = carve(od.off, std::max(sort_bytes, od.kw_lds * m_pad * 8), 0);
-        // fast kernel: aim at two workgroups per CU
-        const int head = 4096 * 4 + QD_OSD_FAST_CAP * 8;                       // histogram + sort buffer
-        const int order_bytes = align16(QD_OSD_FAST_CAP * 2);
-        const int f_budget = QD_LDS_BYTES / 2 - 256 - small - order_bytes;
+        // register kernel: aim at two workgroups per CU; tier sort buffer and order live beside the Q mirror
+        const int tier = 1024;
+        const int sort_b = tier * 8, order_b = align16(tier * 2);
+        const int f_budget = QD_LDS_BYTES / 2 - 256 - small - sort_b - order_b;
         od.f_kw = std::min(od.mw, std::max(1, f_budget / (m_pad * 8)));
-        const int ubytes = std::max(head, od.f_kw * m_pad * 8);
-        int o = carve(od.f_off, ubytes, 0);
-        od.f_off_hist = od.f_off[0];
-        od.f_off_sort = od.f_off[0] + 4096 * 4;
-        od.f_off_order = o; o += order_bytes;
+        int o = carve(od.f_off, od.f_kw * m_pad * 8, 0);
+        od.f_off_hist = 0;
+        od.f_off_sort = o; o += sort_b;
+        od.f_off_order = o; o += order_b;
         od.f_lds_bytes = o;
-        if (od.f_lds_bytes > QD_LDS_BYTES) od.f_lds_bytes = 0;                // cannot happen for m the BP kernel accepts
+        // the register kernel mirrors its 6 register planes in LDS: needs f_kw >= min(6, mw); rows per thread <= 4
+        if (od.f_lds_bytes > QD_LDS_BYTES || (m + od.f_threads - 1) / od.f_threads > 4 || od.f_kw < std::min(6, od.mw)) od.f_lds_bytes = 0;
     }
     if (bp.lds_bytes > QD_LDS_BYTES) {
         g->mem.release();
@@ -390,6 +391,8 @@ static void free_ws(qd_decoder *d)
     if (d->fail_count) (void)hipFree(d->fail_count);
     if (d->order_ws) (void)hipFree(d->order_ws);
     if (d->q_spill) (void)hipFree(d->q_spill);
+    if (d->q_spill_fast) (void)hipFree(d->q_spill_fast);
+    d->q_spill_fast = nullptr;
     if (d->hard_list) (void)hipFree(d->hard_list);
     if (d->hard_list2) (void)hipFree(d->hard_list2);
     d->hard_list = nullptr; d->hard_list2 = nullptr;
@@ -425,6 +428,13 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         d->osd_blocks = ncu * std::min(per_cu, 2048 / g->osd.threads);
         const int per_cu_fast = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.f_lds_bytes));
         d->osd_blocks_fast = ncu * std::min(per_cu_fast, 2048 / std::max(1, g->osd.f_threads));
+        if (const char *ev = std::getenv("QD_OSD_BLOCKS_PER_CU")) {       // tuning knob
+            const int v = std::atoi(ev);
+            if (v > 0) d->osd_blocks_fast = ncu * v;
+        }
+        const int spill_fast = g->osd.mw - g->osd.f_kw;
+        if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
+            HIP_TRY(hipMalloc((void **)&d->q_spill_fast, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * spill_fast * g->osd.m_pad));
         HIP_TRY(hipMalloc((void **)&d->hard_list, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->hard_list2, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->llr_ws, sizeof(float) * (size_t)max_batch * g->bp.n_pad));
@@ -485,7 +495,7 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
     a.max_iter = d->prm.max_iter; a.ms_scale = (float)d->prm.ms_scaling_factor; a.want_llr = osd ? 1 : 0;
     a.err_bits = d_err_bits; a.status = d_status;
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
-    a.order_ws = d->order_ws; a.q_spill = d->q_spill;
+    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;   // bytes 16..143 of the counter block
     HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));

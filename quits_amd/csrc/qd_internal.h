@@ -36,7 +36,6 @@ struct BpGraphDev {
     int threads;
 };
 
-#define QD_OSD_FAST_CAP 2048   // columns the fast OSD kernel sorts (the head of the order)
 
 // Elimination (OSD) view: original indexing.
 struct OsdGraphDev {
@@ -70,6 +69,7 @@ struct DecodeArgs {
     int32_t *fail_count;        // [1]
     uint16_t *order_ws;         // [blocks][n]   sorted column order (full OSD kernel)
     uint64_t *q_spill;          // [blocks][(mw - kw_lds)][m_pad]
+    uint64_t *q_spill_fast;     // [blocks_fast][(mw - f_kw)][m_pad]   register kernel
     int32_t *hard_list;         // [cap]         fail-list slots the first fast OSD pass could not finish
     int32_t *hard_list2;        // [cap]         ... and the second
     int32_t *hard_count;        // [2]

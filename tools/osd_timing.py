@@ -11,10 +11,10 @@ g = WindowGraph(H, pri); d = BatchDecoder(g, max_iter=50, osd_method="osd_0")
 d.decode(det); torch.cuda.synchronize(); d.debug_counters()
 d.set_profiling(True); d.decode(det); torch.cuda.synchronize()
 c = d.debug_counters(); pr = d.profile()
-names = ["bisect", "gather", "sort", "-", "elim.init", "elim.batch-load", "elim.pivots", "elim.finish"]
+names = ["tier(select+sort)", "batch-load", "pivots(rest)", "finish", "round: key+reduce", "round: barrier", "round: read partials+pivot row", "round: update"]
 tot = sum(c[:8]) or 1
-print("hard after this pass(es):", c[11], "batches/shot", c[12] / max(c[8], 1))
-print("osd kernel ms", pr["osd_ms"], "shots", c[8], "mean pivots", c[9] / max(c[8], 1), "mean head cols", c[10] / max(c[8], 1))
+
+print("osd kernel ms", pr["osd_ms"], "shots", c[8], "mean pivots", c[9] / max(c[8], 1))
 for i, nme in enumerate(names):
     print("%-10s %6.1f %%   %8.0f ticks/shot" % (nme, 100.0 * c[i] / tot, c[i] / max(c[8], 1)))
 
