@@ -94,6 +94,13 @@ int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int
                     const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
                     uint32_t *d_err_bits, int32_t *d_status, void *stream);
 
+/* OSD-0 alone, on caller-supplied soft information: every shot of the batch is post-processed as if BP had failed with
+ * posterior LLRs d_llr[b][j] (float, fault order, row stride n).  Same syndrome arguments as qd_decode_batch.  This is
+ * ldpc's OsdDecoder.decode(syndrome, log_prob_ratios) (osd.hpp), which BpOsdDecoder.decode calls after a failed BP. */
+int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset, const uint8_t *d_upd,
+                  int64_t upd_stride, int32_t upd_rows, int64_t B, const float *d_llr, uint32_t *d_err_bits,
+                  int32_t *d_status, void *stream);
+
 /* Posterior LLRs of the last qd_decode_batch call for shots whose BP did not converge are kept in the decoder's
  * workspace; this copies shot b's (float[n], fault order) to d_out, or returns QD_EINVAL if b converged.
  * Synchronises.  Test/diagnostic hook (ldpc exposes `log_prob_ratios` the same way). */

@@ -98,6 +98,28 @@ __global__ void qd_sample_dem_kernel(SpmatDev Ht, SpmatDev Lt, const uint32_t *_
     for (int i = tid; i < nobs; i += T) obs[b * obs_stride + i] = (uint8_t)((obits[i >> 5] >> (i & 31)) & 1u);
 }
 
+// Stage caller-supplied LLRs (fault order) as if the BP kernel had published them: slot order rows, identity fail list.
+__global__ void qd_stage_llr_kernel(const float *__restrict__ llr_in, int n, int n_pad, const uint32_t *__restrict__ bit_orig,
+                                    int64_t B, float *llr_ws, int32_t *fail_list, int32_t *fail_count, int32_t *status)
+{
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) *fail_count = (int32_t)B;
+    if (idx < B) { fail_list[idx] = (int32_t)idx; status[idx] = 0; }
+    if (idx >= B * n) return;
+    const int64_t b = idx / n;
+    const int slot = (int)(idx - b * n);
+    llr_ws[b * n_pad + slot] = llr_in[b * n + bit_orig[slot]];
+}
+
+hipError_t qd_launch_stage_llr(const float *llr_in, int n, int n_pad, const uint32_t *bit_orig, int64_t B, float *llr_ws,
+                               int32_t *fail_list, int32_t *fail_count, int32_t *status, hipStream_t s)
+{
+    const int64_t total = B * n;
+    hipLaunchKernelGGL(qd_stage_llr_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, llr_in, n, n_pad, bit_orig,
+                       B, llr_ws, fail_list, fail_count, status);
+    return hipGetLastError();
+}
+
 // ---- launch wrappers
 hipError_t qd_launch_spmv(const SpmatDev &A, const uint32_t *err, int64_t err_stride, int64_t B, uint8_t *out,
                           int64_t out_stride, int accumulate, hipStream_t s)

@@ -14,6 +14,8 @@
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s);
+hipError_t qd_launch_stage_llr(const float *llr_in, int n, int n_pad, const uint32_t *bit_orig, int64_t B, float *llr_ws,
+                               int32_t *fail_list, int32_t *fail_count, int32_t *status, hipStream_t s);
 hipError_t qd_launch_spmv(const SpmatDev &A, const uint32_t *err, int64_t err_stride, int64_t B, uint8_t *out,
                           int64_t out_stride, int accumulate, hipStream_t s);
 hipError_t qd_launch_unpack(const uint32_t *bits, int64_t stride_words, int nbits, int64_t B, uint8_t *out,
@@ -511,6 +513,38 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
         HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                (int)std::min<int64_t>(B, d->osd_blocks), s));
     if (d->profiling) HIP_TRY(hipEventRecord(e2, s));
+    return QD_OK;
+}
+
+extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset,
+                             const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B, const float *d_llr,
+                             uint32_t *d_err_bits, int32_t *d_status, void *stream)
+{
+    if (!d || !d_det || !d_llr || !d_err_bits || !d_status) return fail(QD_EINVAL, "null argument");
+    if (d->prm.osd_method == QD_OSD_OFF) return fail(QD_EINVAL, "decoder was created with osd_method = off");
+    if (B < 0 || B > 0x7FFFFFFF) return fail(QD_EINVAL, "batch size out of range");
+    if (B == 0) return QD_OK;
+    if (det_offset < 0 || det_stride < det_offset + d->g->m) return fail(QD_EINVAL, "detector slice exceeds the row stride");
+    if (d_upd && (upd_rows < 0 || upd_rows > d->g->m || upd_stride < upd_rows)) return fail(QD_EINVAL, "bad syndrome-update shape");
+    HIP_TRY(hipSetDevice(d->g->device));
+    if (B > d->cap) {
+        int rc = qd_decoder_reserve(d, B);
+        if (rc) return rc;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DecodeArgs a{};
+    a.det = d_det; a.det_stride = det_stride; a.det_offset = det_offset;
+    a.upd = d_upd; a.upd_stride = upd_stride; a.upd_rows = d_upd ? upd_rows : 0;
+    a.max_iter = d->prm.max_iter; a.ms_scale = (float)d->prm.ms_scaling_factor; a.want_llr = 1;
+    a.err_bits = d_err_bits; a.status = d_status;
+    a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
+    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast;
+    a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
+    a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;
+    HIP_TRY(qd_launch_stage_llr(d_llr, d->g->n, d->g->bp.n_pad, d->g->bp.bit_orig, B, d->llr_ws, d->fail_list, d->fail_count,
+                                d_status, s));
+    HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
+                           (int)std::min<int64_t>(B, d->osd_blocks), s));
     return QD_OK;
 }
 

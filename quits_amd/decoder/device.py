@@ -104,6 +104,22 @@ class BatchDecoder:
                                            _ptr(err_bits), _ptr(status), _stream_ptr()))
         return err_bits, status
 
+    def osd0(self, det, llr, det_offset: int = 0, upd=None):
+        """OSD-0 alone on caller-supplied posteriors llr: cuda float32 [B, n] (fault order).  Returns (err_bits, status)."""
+        torch = _torch()
+        assert det.is_cuda and det.dtype == torch.uint8 and det.dim() == 2 and det.stride(1) == 1
+        assert llr.is_cuda and llr.dtype == torch.float32 and llr.shape == (det.shape[0], self.graph.n) and llr.is_contiguous()
+        B = det.shape[0]
+        err_bits = torch.empty((B, self.graph.words), dtype=torch.int32, device=det.device)
+        status = torch.empty((B,), dtype=torch.int32, device=det.device)
+        if upd is not None:
+            up, us, ur = _ptr(upd), upd.stride(0), upd.shape[1]
+        else:
+            up, us, ur = C.c_void_p(0), 0, 0
+        _lib.check(self._L.qd_osd0_batch(self._h, _ptr(det), det.stride(0), int(det_offset), up, us, ur, B, _ptr(llr),
+                                         _ptr(err_bits), _ptr(status), _stream_ptr()))
+        return err_bits, status
+
     def failed_llr(self, b: int):
         torch = _torch()
         out = torch.empty((self.graph.n,), dtype=torch.float32, device="cuda")

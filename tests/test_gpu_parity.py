@@ -193,3 +193,45 @@ def test_headline_scale_properties(gpu):
     assert np.array_equal(ref, np.unpackbits(bits[:n_ref].cpu().numpy().view(np.uint8), axis=1, bitorder="little")[:, :H.shape[1]])
     p = fails / N
     assert 0.01 < p < 0.12, p
+
+
+def _osd_only(H, pri, synd, llr):
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    g = WindowGraph(H, pri)
+    d = BatchDecoder(g, max_iter=1, osd_method="osd_0")
+    bits, status = d.osd0(torch.from_numpy(np.ascontiguousarray(synd)).cuda(),
+                          torch.from_numpy(np.ascontiguousarray(llr, dtype=np.float32)).cuda())
+    return unpack_bits(bits, g.n).cpu().numpy(), status.cpu().numpy()
+
+
+@pytest.mark.parametrize("case", ["ties", "few_values", "deep", "negzero"])
+def test_osd_alone_on_crafted_llrs(gpu, case):
+    """OSD-0 through qd_osd0_batch on soft information chosen to hit the rare paths of the kernel:
+    ties   -- every LLR equal: > 1024 columns share one key, the order is purely by fault index (tier-by-index path);
+    few_values -- LLRs from a 3-value alphabet: huge tie groups split across tiers;
+    deep   -- random syndromes + random LLRs: elimination runs to full rank (1002 pivots -> Q planes spill to HBM);
+    negzero -- +0.0 / -0.0 / tiny values must tie exactly like the oracle's '<' on doubles."""
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    m, n = H.shape
+    rng = np.random.default_rng({"ties": 1, "few_values": 2, "deep": 3, "negzero": 4}[case])
+    B = 24
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=77, shot0=0, B=B)
+    if case == "ties":
+        llr = np.full((B, n), 2.5, np.float32)
+    elif case == "few_values":
+        llr = rng.choice(np.array([-1.0, 0.25, 3.0], np.float32), size=(B, n))
+    elif case == "deep":
+        synd = (rng.random((B, m)) < 0.3).astype(np.uint8)
+        llr = rng.normal(size=(B, n)).astype(np.float32)
+    else:
+        llr = rng.choice(np.array([0.0, -0.0, 1e-30, -1e-30, 1.0], np.float32), size=(B, n))
+    err, status = _osd_only(H, pri, synd, llr)
+    g = orc.Graph(H, pri)
+    for b in range(B):
+        ref, st = g.osd0(synd[b], llr[b].astype(np.float64), stop_early=True)
+        assert np.array_equal(err[b], ref), (case, b)
+        assert ((status[b] >> 20) & 0xFFF) == min(st["pivots"], 4095)
+        assert bool(status[b] & (1 << 18)) == st["inconsistent"]
+    if case == "deep":
+        assert ((status >> 20) & 0xFFF).max() > 900
