@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--p", type=float, default=0.003)
-    ap.add_argument("--code", default="bb144", choices=["bb144", "bb72", "hgp225"],
+    ap.add_argument("--code", default="bb144", choices=["bb144", "bb72", "hgp225", "qlp1020"],
                     help="bb144 = the headline (BASELINE configs[2]); bb72 = configs[1]; hgp225 = configs[0] (their circuits at their p)")
     ap.add_argument("--window", type=int, nargs=2, default=None, metavar=("W", "F"))
     ap.add_argument("--cpu-shots", type=int, default=2000, help="bounded CPU-baseline sample (rank 0, N=1 only)")
@@ -64,6 +64,8 @@ def main():
         R, cname = 12, "bb144_custom_r12_p%g" % args.p
     elif args.code == "bb72":
         R, cname = 6, "bb72_custom_r6_p0.003"
+    elif args.code == "qlp1020":
+        R, cname = 20, "qlp1020_cardinal_r20_p0.003"          # BASELINE configs[4]: ~1000 qubits, W=3 F=1 (pass --window 3 1)
     else:
         R, cname = 3, "hgp225_cardinal_r3_p0.01"
     circ = Circuit(helpers.circuit_text(cname))
@@ -168,7 +170,7 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s circuit %s, R=%d, Z basis; DEM %dx%d (E=%d); "
                                "min-sum flooding BP max_iter=%d ms_scaling=1.0 + OSD-0; W=%d F=%d (%d window%s)"
-                               % ({"bb144": "BB [[144,12,12]]", "bb72": "BB [[72,12,6]]", "hgp225": "HGP [[225,9,6]]"}[args.code],
+                               % ({"bb144": "BB [[144,12,12]]", "bb72": "BB [[72,12,6]]", "hgp225": "HGP [[225,9,6]]", "qlp1020": "QLP [[1020,136]]"}[args.code],
                                   cname, R, m, n, E, args.max_iter, W, F, len(plan.windows), "" if len(plan.windows) == 1 else "s"),
                    "shots_per_step_per_gpu": args.shots, "parallelism": "shots sharded over %d GPU(s), no data-path collective" % world},
         "logical_error_rate": pl, "ler_sigma": float(np.sqrt(max(pl * (1 - pl), 1e-30) / n_shots)),

@@ -292,25 +292,30 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int sort_bytes = np2 * 8;
     od.threads = m <= 256 ? 256 : (m <= 512 ? 512 : 1024);
     od.f_threads = m <= 256 ? 256 : 512;
-    if (sort_bytes > q_budget) {
-        // BP still runs; the full OSD kernel needs its sort buffer in LDS
-        od.lds_bytes = 0; od.kw_lds = 0; od.f_lds_bytes = 0; od.f_kw = 0;
-    } else {
+    od.lds_bytes = 0; od.kw_lds = 0; od.f_lds_bytes = 0; od.f_kw = 0;
+    if (sort_bytes <= q_budget) {
         od.kw_lds = std::min(od.mw, q_budget / (m_pad * 8));
         od.lds_bytes = carve(od.off, std::max(sort_bytes, od.kw_lds * m_pad * 8), 0);
-        // register kernel: aim at two workgroups per CU; tier sort buffer and order live beside the Q mirror
+    }
+    {
+        // register kernel: aim at two workgroups per CU, settle for one; the tier sort buffer and the order live beside the
+        // Q mirror, which must hold the kernel's 6 register planes (or all mw planes of a small window)
         const int tier = 1024;
         const int sort_b = tier * 8, order_b = align16(tier * 2);
-        const int f_budget = QD_LDS_BYTES / 2 - 256 - small - sort_b - order_b;
-        od.f_kw = std::min(od.mw, std::max(1, f_budget / (m_pad * 8)));
-        int o = carve(od.f_off, od.f_kw * m_pad * 8, 0);
-        od.f_off_hist = 0;
-        od.f_off_sort = o; o += sort_b;
-        od.f_off_order = o; o += order_b;
-        od.f_lds_bytes = o;
-        // the register kernel mirrors its 6 register planes in LDS: needs f_kw >= min(6, mw); rows per thread <= 4
-        if (od.f_lds_bytes > QD_LDS_BYTES || (m + od.f_threads - 1) / od.f_threads > 4 || od.f_kw < std::min(6, od.mw)) od.f_lds_bytes = 0;
+        od.f_lds_bytes = 0;
+        for (int per_cu = 2; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu) {
+            const int f_budget = QD_LDS_BYTES / per_cu - 256 - small - sort_b - order_b;
+            od.f_kw = std::min(od.mw, std::max(0, f_budget / (m_pad * 8)));
+            if (od.f_kw < std::min(6, od.mw) || (m + od.f_threads - 1) / od.f_threads > 4) continue;
+            int o = carve(od.f_off, od.f_kw * m_pad * 8, 0);
+            od.f_off_hist = 0;
+            od.f_off_sort = o; o += sort_b;
+            od.f_off_order = o; o += order_b;
+            if (o <= QD_LDS_BYTES) od.f_lds_bytes = o;
+        }
     }
+    // the full kernel sorts all n columns in LDS; windows too large for that rely on the register kernel alone
+    if (od.lds_bytes == 0 && od.f_lds_bytes == 0) od.threads = 0;
     if (bp.lds_bytes > QD_LDS_BYTES) {
         g->mem.release();
         const int need_lds = bp.lds_bytes;
@@ -375,8 +380,8 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     const bool osd0 = p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
     if (p->osd_method != QD_OSD_OFF && !osd0)
         return fail(QD_EUNSUPPORTED, "osd_method %d with osd_order %d: only OSD-0 (osd_0, or osd_cs/osd_e with order 0) is implemented on the device path", p->osd_method, p->osd_order);
-    if (p->osd_method != QD_OSD_OFF && g->osd.lds_bytes == 0)
-        return fail(QD_ECAPACITY, "n = %d faults: the OSD column sort needs %d bytes of LDS", g->n, g->osd.npow2 * 8);
+    if (p->osd_method != QD_OSD_OFF && g->osd.lds_bytes == 0 && g->osd.f_lds_bytes == 0)
+        return fail(QD_ECAPACITY, "window %d x %d does not fit either OSD kernel's LDS layout", g->m, g->n);
     if (p->max_iter < 0 || p->ms_scaling_factor < 0) return fail(QD_EINVAL, "negative max_iter / ms_scaling_factor");
     qd_decoder *d = new qd_decoder();
     d->g = g; d->prm = *p;
@@ -427,7 +432,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, g->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount;
         const int per_cu = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.lds_bytes));
-        d->osd_blocks = ncu * std::min(per_cu, 2048 / g->osd.threads);
+        d->osd_blocks = g->osd.lds_bytes > 0 ? ncu * std::min(per_cu, 2048 / std::max(1, g->osd.threads)) : 0;
         const int per_cu_fast = std::max(1, QD_LDS_BYTES / std::max(1, g->osd.f_lds_bytes));
         d->osd_blocks_fast = ncu * std::min(per_cu_fast, 2048 / std::max(1, g->osd.f_threads));
         if (const char *ev = std::getenv("QD_OSD_BLOCKS_PER_CU")) {       // tuning knob
@@ -441,9 +446,10 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         HIP_TRY(hipMalloc((void **)&d->hard_list2, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->llr_ws, sizeof(float) * (size_t)max_batch * g->bp.n_pad));
         HIP_TRY(hipMalloc((void **)&d->fail_list, sizeof(int32_t) * (size_t)max_batch));
-        HIP_TRY(hipMalloc((void **)&d->order_ws, sizeof(uint16_t) * (size_t)d->osd_blocks * g->n));
+        if (d->osd_blocks > 0)
+            HIP_TRY(hipMalloc((void **)&d->order_ws, sizeof(uint16_t) * (size_t)d->osd_blocks * g->n));
         const int spill_planes = g->osd.mw - g->osd.kw_lds;
-        if (spill_planes > 0)
+        if (d->osd_blocks > 0 && spill_planes > 0)
             HIP_TRY(hipMalloc((void **)&d->q_spill, sizeof(uint64_t) * (size_t)d->osd_blocks * spill_planes * g->osd.m_pad));
     }
     d->cap = max_batch;
