@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--p", type=float, default=0.003)
+    ap.add_argument("--p-override", type=float, default=None, help="physical error rate for the non-headline codes")
     ap.add_argument("--code", default="bb144", choices=["bb144", "bb72", "hgp225", "qlp1020"],
                     help="bb144 = the headline (BASELINE configs[2]); bb72 = configs[1]; hgp225 = configs[0] (their circuits at their p)")
     ap.add_argument("--window", type=int, nargs=2, default=None, metavar=("W", "F"))
@@ -68,7 +69,12 @@ def main():
         R, cname = 20, "qlp1020_cardinal_r20_p0.003"          # BASELINE configs[4]: ~1000 qubits, W=3 F=1 (pass --window 3 1)
     else:
         R, cname = 3, "hgp225_cardinal_r3_p0.01"
-    circ = Circuit(helpers.circuit_text(cname))
+    text = helpers.circuit_text(cname)
+    fixture_p = {"bb144": args.p, "bb72": 0.003, "hgp225": 0.01, "qlp1020": 0.003}[args.code]
+    if args.code != "bb144" and args.p_override is not None and args.p_override != fixture_p:
+        text = helpers.circuit_text_at_p(cname, fixture_p, args.p_override)      # same text the reference emits at that rate
+        cname += "@p=%g" % args.p_override
+    circ = Circuit(text)
     code = helpers.code(args.code)
     hz, lz = code["hz"], code["lz"]
     H, Lobs, pri = detector_error_model_to_matrix(circ)

@@ -14,6 +14,16 @@ def circuit_text(name):
         return f.read().decode()
 
 
+def circuit_text_at_p(name, p_from, p_to):
+    """The circuit the reference emits for ErrorModel(p_to, p_to, p_to, p_to), derived from the fixture made at p_from.
+    With one rate on all four channels every noise argument is printed as the same '%.10f' literal (circuit.py:96-246),
+    so the two texts differ by exactly that literal (tests/test_dem.py checks this on the six bb144 fixtures)."""
+    old, new = "%.10f" % p_from, "%.10f" % p_to
+    text = circuit_text(name)
+    assert old in text
+    return text.replace(old, new)
+
+
 def circuit_index():
     return json.load(open(os.path.join(GOLD, "circuits", "index.json")))
 

@@ -176,3 +176,9 @@ def test_circuit_wrapper_api():
     assert inst.type == "error" and len(inst.args_copy()) == 1
     t = inst.targets_copy()
     assert t[0].is_relative_detector_id() and not t[0].is_logical_observable_id()
+
+
+def test_rate_substitution_reproduces_the_reference_circuit():
+    base = "bb144_custom_r12_p0.003"
+    for p in (0.001, 0.002, 0.004, 0.005, 0.006):
+        assert helpers.circuit_text_at_p(base, 0.003, p) == helpers.circuit_text("bb144_custom_r12_p%g" % p)
