@@ -50,6 +50,9 @@ def lib():
         L.oq_gf2_rank.argtypes = [C.c_void_p]
         L.oq_osd0.argtypes = [C.c_void_p, u8p, f64p, C.c_int, u8p, i32p]
         L.oq_osd_w.argtypes = [C.c_void_p, u8p, f64p, C.c_int, C.c_int, u8p]
+        L.oq_osd_w_fixed.argtypes = [C.c_void_p, u8p, f64p, C.c_int, C.c_int, u8p, i32p]
+        L.oq_fixed_weight.restype = C.c_uint32
+        L.oq_fixed_weight.argtypes = [C.c_double]
         L.oq_bposd_decode_batch.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_int64, u8p, i32p]
         L.oq_csr_create.restype = C.c_void_p
         L.oq_csr_create.argtypes = [C.c_int, C.c_int, i32p, i32p]
@@ -118,9 +121,15 @@ class Graph:
         lib().oq_osd0(self._h, s, np.ascontiguousarray(llr, dtype=np.float64), int(stop_early), err, st)
         return err, {"pivots": int(st[0]), "cols_examined": int(st[1]), "inconsistent": bool(st[2])}
 
-    def osd_w(self, syndrome, llr, osd_method="osd_cs", osd_order=1):
+    def osd_w(self, syndrome, llr, osd_method="osd_cs", osd_order=1, fixed=False):
+        """OSD-CS / OSD-E.  fixed=True: integer candidate costs (the HIP kernel's arithmetic); returns (err, stats)."""
         s = np.ascontiguousarray(np.asarray(syndrome) % 2, dtype=np.uint8)
         err = np.zeros(self.n, np.uint8)
+        if fixed:
+            st = np.zeros(4, np.int32)
+            lib().oq_osd_w_fixed(self._h, s, np.ascontiguousarray(llr, dtype=np.float64), OSD_METHOD[osd_method],
+                                 int(osd_order), err, st)
+            return err, {"pivots": int(st[0]), "winner": int(st[2]), "candidates": int(st[3])}
         lib().oq_osd_w(self._h, s, np.ascontiguousarray(llr, dtype=np.float64),
                        OSD_METHOD[osd_method], int(osd_order), err)
         return err

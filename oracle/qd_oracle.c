@@ -312,10 +312,22 @@ int oq_osd0(oq_graph *g, const uint8_t *synd, const double *llr, int stop_early,
     return 0;
 }
 
+/* Candidate cost.  ldpc sums log(1/p_j) in double (osd.hpp).  `fixed` != 0 switches to the integer weights the HIP
+ * kernel uses -- round(log(1/p_j) * 2^18) -- so that sums are exact and independent of summation order; the two only
+ * differ on candidates whose costs tie to within ~1e-5. */
+uint32_t oq_fixed_weight(double p)
+{
+    double w = log(1.0 / p) * 262144.0;
+    if (w < 0) w = 0;
+    if (w > 4294967295.0) w = 4294967295.0;
+    return (uint32_t)llround(w);
+}
+
 /* OSD-CS / OSD-E of order `osd_order` (osd.hpp: osd_setup + decode).  Candidate strings live on the k = n - rank
  * non-pivot columns taken in the sorted order; cost of a candidate = sum over its 1s of log(1/p_j) (channel
  * probabilities, not Hamming weight); strict '<' keeps the earliest minimum, OSD-0 first. */
-int oq_osd_w(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method, int osd_order, uint8_t *err)
+static int osd_w_impl(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method, int osd_order, int fixed,
+                      uint8_t *err, int32_t *stats)
 {
     const int m = g->m, n = g->n;
     int rank = oq_gf2_rank(g);
@@ -325,6 +337,7 @@ int oq_osd_w(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method
     elim_run(g, order, synd, 0, rank, &E);
     memset(err, 0, (size_t)n);
     for (int k = 0; k < E.npiv; k++) err[E.pcol[k]] = E.sp[E.prow[k]];
+    if (stats) { stats[0] = E.npiv; stats[1] = E.ncols_examined; stats[2] = 0; stats[3] = 0; }
     if (osd_order <= 0 || osd_method == OQ_OSD_0 || osd_method == OQ_OSD_OFF) { elim_free(&E); free(order); return 0; }
     /* non-pivot columns in sorted order */
     uint8_t *ispiv = (uint8_t *)calloc((size_t)n + 1, 1);
@@ -332,10 +345,12 @@ int oq_osd_w(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method
     int kk = n - E.npiv;
     int *npc = (int *)malloc(sizeof(int) * (size_t)(kk > 0 ? kk : 1));
     for (int c = 0, q = 0; c < n; c++) if (!ispiv[order[c]]) npc[q++] = order[c];
+    double *wd = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    for (int j = 0; j < n; j++) wd[j] = fixed ? (double)oq_fixed_weight(g->prior[j]) : log(1.0 / g->prior[j]);
     /* (T c)[pivot rows] for a non-pivot column c, via the final Q: flipping column c on changes the pivot
-     * coefficients by exactly that vector. */
+     * coefficients by exactly that vector.  With `fixed` the costs are integers < 2^53, exact in double. */
     double best = 0;
-    for (int j = 0; j < n; j++) if (err[j]) best += log(1.0 / g->prior[j]);
+    for (int j = 0; j < n; j++) if (err[j]) best += wd[j];
     uint8_t *cand = (uint8_t *)malloc((size_t)n + 1);
     uint8_t *tc = (uint8_t *)malloc((size_t)m + 1);
     uint8_t *base = (uint8_t *)malloc((size_t)n + 1);
@@ -344,6 +359,7 @@ int oq_osd_w(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method
     int w = osd_order > kk ? kk : osd_order;
     if (osd_method == OQ_OSD_E) ncand = (1L << w) - 1;
     else ncand = (long)kk + (long)w * (w - 1) / 2;
+    long best_ic = -1;
     for (long ic = 0; ic < ncand; ic++) {
         int sel[64], nsel = 0;
         if (osd_method == OQ_OSD_E) {
@@ -376,11 +392,24 @@ int oq_osd_w(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method
             cand[col] = 1;
         }
         double wgt = 0;
-        for (int j = 0; j < n; j++) if (cand[j]) wgt += log(1.0 / g->prior[j]);
-        if (wgt < best) { best = wgt; memcpy(err, cand, (size_t)n); }
+        for (int j = 0; j < n; j++) if (cand[j]) wgt += wd[j];
+        if (wgt < best) { best = wgt; best_ic = ic; memcpy(err, cand, (size_t)n); }
     }
-    free(cand); free(tc); free(base); free(npc); free(ispiv); elim_free(&E); free(order);
+    if (stats) { stats[2] = (int32_t)(best_ic + 1); stats[3] = (int32_t)ncand; }
+    free(cand); free(tc); free(base); free(npc); free(ispiv); free(wd); elim_free(&E); free(order);
     return 0;
+}
+
+int oq_osd_w(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method, int osd_order, uint8_t *err)
+{
+    return osd_w_impl(g, synd, llr, osd_method, osd_order, 0, err, NULL);
+}
+
+/* stats: pivots, columns examined, 1 + index of the winning candidate (0 = OSD-0 kept), number of candidates */
+int oq_osd_w_fixed(oq_graph *g, const uint8_t *synd, const double *llr, int osd_method, int osd_order, uint8_t *err,
+                   int32_t *stats)
+{
+    return osd_w_impl(g, synd, llr, osd_method, osd_order, 1, err, stats);
 }
 
 /* BpOsdDecoder.decode (bposd_decoder.pyx): BP; if converged return the BP decision, else OSD on the posteriors.
@@ -394,7 +423,7 @@ int oq_bposd_decode(oq_graph *g, const oq_params *prm, const uint8_t *synd, uint
     if (conv < 0) { free(llr); return -1; }
     if (!conv && prm->osd_method != OQ_OSD_OFF) {
         if (prm->osd_method == OQ_OSD_0 || prm->osd_order == 0) oq_osd0(g, synd, llr, 1, err, st);
-        else oq_osd_w(g, synd, llr, prm->osd_method, prm->osd_order, err);
+        else osd_w_impl(g, synd, llr, prm->osd_method, prm->osd_order, prm->form == OQ_FORM_COMPRESSED_F32, err, NULL);
     }
     if (flags_out) { flags_out[0] = conv; flags_out[1] = iters; flags_out[2] = st[0]; flags_out[3] = st[2]; }
     free(llr);

@@ -296,7 +296,11 @@ __device__ __forceinline__ uint32_t qd_block_sum(uint32_t v, uint32_t *buf, int 
 // Only what this kernel needs, so the scalar registers are not flooded with three full descriptor structs.
 struct OsdRegArgs {
     int m, n, m_pad, n_pad, max_cdeg, mw, f_kw, out_words, upd_rows;
-    int off[10], off_sort, off_order;
+    int off[10], off_sort, off_order, off_pivmask, off_npl;
+    int osd_w;                  // 0 = OSD-0 (early stop), 1 = combination sweep, 2 = exhaustive
+    int osd_order, rank;
+    const uint32_t *wfix;       // [n] round(log(1/p_j) * 2^18): candidate cost per fault
+    const uint32_t *bit_slot_of;// [n] fault -> bit slot (row of llr_ws)
     const uint32_t *csc_ptr;
     const uint16_t *csc_row;
     const uint32_t *bit_orig;
@@ -467,6 +471,221 @@ __device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *l
     return cnt;
 }
 
+// ---- higher-order OSD: candidate sweep after a FULL-rank elimination (ldpc osd.hpp, OsdDecoder::decode) ----------------
+// Flipping a non-pivot column c on changes the pivot coefficients by t_c[k] = (T H_c)[p_k] = [p_k in c] xor parity(Q[p_k] &
+// {pivot order of c's pivoted rows}); cost change = w_c + sum_k t_c[k] * (+-w_{pcol k}).  Thread k-owner accumulates 32
+// candidates at a time in registers; one workgroup reduction per 32 candidates.  Costs are integers (wfix), so the result
+// does not depend on summation order; ties go to the earliest candidate in ldpc's enumeration order (OSD-0, then single
+// columns in sorted order, then pairs / patterns), expressed as the lexicographic minimum of (cost change, class, order key).
+struct SweepBest { long long delta; uint32_t cls; unsigned long long tie, what; };
+
+__device__ __forceinline__ bool qd_sweep_less(long long d1, uint32_t c1, unsigned long long t1, long long d2, uint32_t c2,
+                                              unsigned long long t2)
+{
+    if (d1 != d2) return d1 < d2;
+    if (c1 != c2) return c1 < c2;
+    return t1 < t2;
+}
+
+template <int T>
+__device__ __noinline__ void qd_osd_sweep(const OsdRegArgs &a, unsigned char *smem, const float *llr, uint64_t *qglb,
+                                          int npiv, int nnp)
+{
+    const int tid = threadIdx.x;
+    constexpr int NW = T / 64;
+    constexpr int KP = 4;                                  // pivots per thread: npiv <= m <= 4 * T for this kernel
+    OsdLds S;
+    qd_osd_carve(smem, a.off, S);
+    const uint32_t *pivmask = reinterpret_cast<const uint32_t *>(smem + a.off_pivmask);
+    const uint32_t *npl = reinterpret_cast<const uint32_t *>(smem + a.off_npl);
+    unsigned char *scr = smem + a.off_sort;                // 8 KB, dead after the elimination
+    uint16_t *J = reinterpret_cast<uint16_t *>(scr);                        // [32][16] pivot orders touched by candidate q
+    int32_t *wsum = reinterpret_cast<int32_t *>(scr + 1024);                // [NW][32]
+    SweepBest *bests = reinterpret_cast<SweepBest *>(scr + 1024 + NW * 128);// [32]
+    uint32_t *maskw = reinterpret_cast<uint32_t *>(scr + 4096);             // [2][npiv <= 4T ... ] not used: masks stay in registers
+    (void)maskw;
+    const int m_pad = a.m_pad, kw_lds = a.f_kw, n = a.n;
+
+    int32_t sw[KP];
+    uint32_t rowk[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int k = tid + i * T;
+        sw[i] = 0; rowk[i] = 0;
+        if (k < npiv) {
+            const uint32_t row = S.prow[k];
+            const int32_t w = (int32_t)a.wfix[S.pcol[k]];
+            rowk[i] = row;
+            sw[i] = S.sp[row] ? -w : w;                    // a pivot that is on in the OSD-0 solution gets cheaper when flipped
+        }
+    }
+    auto qbit = [&](uint32_t row, uint32_t kk) -> uint32_t {
+        const uint32_t w = kk >> 6;
+        const uint64_t word = (w < (uint32_t)kw_lds) ? S.q[(size_t)w * m_pad + row] : qglb[(size_t)(w - kw_lds) * m_pad + row];
+        return (uint32_t)(word >> (kk & 63u)) & 1u;
+    };
+    // bits[i] bit q = t_{candidate q}[k_i] for the 32 candidates whose pivot lists sit in J
+    auto eval_bits = [&](uint32_t bits[KP]) {
+#pragma unroll
+        for (int i = 0; i < KP; ++i) {
+            bits[i] = 0u;
+            const int k = tid + i * T;
+            if (k < npiv)
+                for (int q = 0; q < 32; ++q) {
+                    uint32_t b = 0u;
+                    for (int e = 0; e < a.max_cdeg; ++e) {
+                        const uint32_t kk = J[q * 16 + e];
+                        if (kk != 0xFFFFu) b ^= ((kk == (uint32_t)k) ? 1u : 0u) ^ qbit(rowk[i], kk);
+                    }
+                    bits[i] |= b << q;
+                }
+        }
+    };
+    auto fill_J = [&](auto col_of) {            // col_of(q) -> fault index or 0xFFFFFFFF
+        for (int x = tid; x < 32 * 16; x += T) {
+            const int q = x >> 4, e = x & 15;
+            uint16_t v = 0xFFFFu;
+            const uint32_t col = col_of(q);
+            if (col != 0xFFFFFFFFu && e < a.max_cdeg) {
+                const uint32_t e0 = a.csc_ptr[col], e1 = a.csc_ptr[col + 1];
+                if (e0 + e < e1) { const int kk = S.rowpiv[a.csc_row[e0 + e]]; if (kk >= 0) v = (uint16_t)kk; }
+            }
+            J[x] = v;
+        }
+    };
+    // workgroup sums of 32 per-thread accumulators -> every thread q < 32 returns the total of accumulator q
+    auto reduce32 = [&](const int32_t acc[32]) -> long long {
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const uint32_t v = qd_wave_add((uint32_t)acc[q]);
+            if ((tid & 63) == 0) wsum[(tid >> 6) * 32 + q] = (int32_t)v;
+        }
+        __syncthreads();
+        long long tot = 0;
+        if (tid < 32)
+            for (int w = 0; w < NW; ++w) tot += (long long)wsum[w * 32 + tid];
+        __syncthreads();
+        return tot;
+    };
+
+    SweepBest best{0x7FFFFFFFFFFFFFFFll, 3u, ~0ull, 0ull};     // lane q < 32 tracks the best candidate it has seen
+    if (a.osd_w == 1) {
+        // ---- singles: every non-pivot column, 32 consecutive fault indices at a time
+        for (int w0 = 0; w0 < a.out_words; ++w0) {
+            const uint32_t pm = pivmask[w0];
+            auto col_of = [&](int q) -> uint32_t {
+                const uint32_t j = (uint32_t)(w0 * 32 + q);
+                return (j < (uint32_t)n && !((pm >> q) & 1u)) ? j : 0xFFFFFFFFu;
+            };
+            if (__builtin_amdgcn_readfirstlane(pm) == 0xFFFFFFFFu) continue;
+            fill_J(col_of);
+            __syncthreads();
+            uint32_t bits[KP];
+            eval_bits(bits);
+            int32_t acc[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                int32_t s = 0;
+#pragma unroll
+                for (int i = 0; i < KP; ++i) s += ((bits[i] >> q) & 1u) ? sw[i] : 0;
+                acc[q] = s;
+            }
+            const long long tot = reduce32(acc);
+            if (tid < 32) {
+                const uint32_t col = col_of(tid);
+                if (col != 0xFFFFFFFFu) {
+                    const long long d = tot + (long long)a.wfix[col];
+                    const unsigned long long tie = ((unsigned long long)qd_mono_key(llr[a.bit_slot_of[col]]) << 32) | col;
+                    if (qd_sweep_less(d, 1u, tie, best.delta, best.cls, best.tie)) best = SweepBest{d, 1u, tie, (unsigned long long)col};
+                }
+            }
+        }
+    }
+    // ---- patterns over the first lam non-pivot columns of the order: pairs (combination sweep) or all subsets (exhaustive)
+    const int lam = min(min(a.osd_order, nnp), 64);
+    if (lam >= (a.osd_w == 1 ? 2 : 1)) {
+        unsigned long long mask[KP];
+#pragma unroll
+        for (int i = 0; i < KP; ++i) mask[i] = 0ull;
+        for (int h = 0; h * 32 < lam; ++h) {
+            auto col_of = [&](int q) -> uint32_t { return (h * 32 + q < lam) ? npl[h * 32 + q] : 0xFFFFFFFFu; };
+            fill_J(col_of);
+            __syncthreads();
+            uint32_t bits[KP];
+            eval_bits(bits);
+#pragma unroll
+            for (int i = 0; i < KP; ++i) mask[i] |= (unsigned long long)bits[i] << (32 * h);
+            __syncthreads();
+        }
+        const unsigned long long npat = (a.osd_w == 1) ? (unsigned long long)lam * (lam - 1) / 2 : ((1ull << lam) - 1ull);
+        for (unsigned long long p0 = 0; p0 < npat; p0 += 32) {
+            // pattern of candidate q = tid & 31 (all threads need all 32 patterns: recompute per q)
+            auto pat_of = [&](unsigned long long ic) -> unsigned long long {
+                if (ic >= npat) return 0ull;
+                if (a.osd_w == 2) return ic + 1ull;
+                unsigned long long qq = ic; int x = 0;                 // pairs (x, y), x < y < lam, lexicographic
+                while (qq >= (unsigned long long)(lam - 1 - x)) { qq -= (unsigned long long)(lam - 1 - x); ++x; }
+                return (1ull << x) | (1ull << (x + 1 + (int)qq));
+            };
+            int32_t acc[32];
+#pragma unroll
+            for (int q = 0; q < 32; ++q) {
+                const unsigned long long pat = pat_of(p0 + q);
+                int32_t s = 0;
+#pragma unroll
+                for (int i = 0; i < KP; ++i) s += (__popcll(mask[i] & pat) & 1) ? sw[i] : 0;
+                acc[q] = s;
+            }
+            const long long tot = reduce32(acc);
+            if (tid < 32 && p0 + tid < npat) {
+                const unsigned long long pat = pat_of(p0 + tid);
+                long long d = tot;
+                for (int b = 0; b < lam; ++b) if ((pat >> b) & 1ull) d += (long long)a.wfix[npl[b]];
+                const unsigned long long tie = p0 + tid;
+                if (qd_sweep_less(d, 2u, tie, best.delta, best.cls, best.tie)) best = SweepBest{d, 2u, tie, pat};
+            }
+        }
+    }
+    // ---- winner over the 32 lanes; keep OSD-0 unless a candidate is strictly cheaper
+    if (tid < 32) bests[tid] = best;
+    __syncthreads();
+    SweepBest win = bests[0];
+    for (int q = 1; q < 32; ++q) { const SweepBest c = bests[q]; if (qd_sweep_less(c.delta, c.cls, c.tie, win.delta, win.cls, win.tie)) win = c; }
+    __syncthreads();
+    unsigned long long wpat = 0ull;                         // winner as a pattern over (<= 64) columns listed in J rows
+    int wcols = 0;
+    uint32_t wcol[64];
+    if (win.delta < 0) {
+        if (win.cls == 1u) { wcol[0] = (uint32_t)win.what; wcols = 1; }
+        else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) wcol[wcols++] = npl[b];
+    }
+    (void)wpat;
+    // ---- solution: pivots = OSD-0 coefficients xor t_winner; winner columns on
+    for (int w = tid; w < a.out_words; w += T) S.outw[w] = 0u;
+    uint32_t flip[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) flip[i] = 0u;
+    for (int h = 0; h * 32 < wcols; ++h) {
+        auto col_of = [&](int q) -> uint32_t { return (h * 32 + q < wcols) ? wcol[h * 32 + q] : 0xFFFFFFFFu; };
+        __syncthreads();
+        fill_J(col_of);
+        __syncthreads();
+        uint32_t bits[KP];
+        eval_bits(bits);
+#pragma unroll
+        for (int i = 0; i < KP; ++i) flip[i] ^= (uint32_t)__popc(bits[i]) & 1u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int k = tid + i * T;
+        if (k < npiv && ((uint32_t)S.sp[rowk[i]] ^ flip[i])) { const uint32_t j = S.pcol[k]; atomicOr(&S.outw[j >> 5], 1u << (j & 31u)); }
+    }
+    if (tid == 0)
+        for (int c = 0; c < wcols; ++c) atomicOr(&S.outw[wcol[c] >> 5], 1u << (wcol[c] & 31u));
+    __syncthreads();
+}
+
 template <int T, int RPT>
 __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
 {
@@ -481,6 +700,10 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
     uint16_t *order = reinterpret_cast<uint16_t *>(smem + a.off_order);        // [QD_OSD_TIER]
     uint32_t *red = S.red;            // [0..31] pivot keys A/B, [32..63] flags A/B, [64] pair counter, [96..127] block sums A/B, [80] gather counter
     uint32_t *sumbuf = red + 96;
+    uint32_t *pivmask = reinterpret_cast<uint32_t *>(smem + a.off_pivmask);    // [out_words] bit j: fault j is a pivot column (higher-order OSD)
+    uint32_t *npl = reinterpret_cast<uint32_t *>(smem + a.off_npl);            // [64] first non-pivot columns of the order
+    const bool want_full = a.osd_w != 0;                                        // OSD-CS / OSD-E need the complete factorisation
+    const int lam_max = want_full ? min(a.osd_order, 64) : 0;
     const int m = a.m, m_pad = a.m_pad, n = a.n, kw_lds = a.f_kw;
     uint64_t *qglb = a.q_spill_fast ? a.q_spill_fast + (int64_t)blockIdx.x * (int64_t)(a.mw - kw_lds) * m_pad : nullptr;
     const bool in_regs = n <= QD_OSD_KPT * T;
@@ -517,11 +740,11 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                     if (w < kw_lds) S.q[(size_t)w * m_pad + r] = 0ull;      // the register planes' mirror; later planes are cleared when first used
             }
         }
-        for (int w = tid; w < a.out_words; w += T) S.outw[w] = 0u;
+        for (int w = tid; w < a.out_words; w += T) { S.outw[w] = 0u; if (want_full) pivmask[w] = 0u; }
         if (tid < 64) red[tid] = ((tid & 16) == 0) ? QD_NOKEY : 0u;      // per phase: 16 keys then 16 flags
         __syncthreads();
 
-        int npiv = 0, done = 0, phase = 0, sphase = 0;
+        int npiv = 0, done = 0, phase = 0, sphase = 0, nnp = 0;
         uint32_t lo_key = 0, lo_idx = 0;             // every column with (key, fault index) < (lo_key, lo_idx) has been consumed
         while (!done) {
             // =============== draw the next tier of the column order (kept out of line: its 20 key registers and unrolled
@@ -531,6 +754,15 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
             lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
             if (ts.exhausted) break;
             QD_TICK(0)
+            if (want_full && npiv >= a.rank) {
+                // factorisation complete: every further column of the order is a non-pivot column
+                if (tid == 0)
+                    for (int i = 0; i < cnt && nnp + i < lam_max; ++i) npl[nnp + i] = order[i];
+                nnp = min(lam_max, nnp + cnt);
+                __syncthreads();
+                if (nnp >= lam_max) break;
+                continue;
+            }
 
             // =============== eliminate over this tier, 64 columns at a time
             for (int base = 0; base < cnt && !done; base += 64) {
@@ -571,6 +803,8 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                     my_tb[i] = x;
                 }
                 QD_TICK(1)
+                int bpos = 0;                               // batch columns before bpos have been classified
+                const int nb = min(64, cnt - base);
                 // ---- pivots of this batch, one barrier per round
                 for (;;) {
                     uint32_t key = QD_NOKEY;
@@ -607,7 +841,18 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                     // every lane holds the same values; tell the compiler, so that the round runs on scalar control flow
                     key = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
                     anyres = (uint32_t)__builtin_amdgcn_readfirstlane((int)anyres);
-                    if (!anyres) { done = 1; break; }        // syndrome already in the span of the pivots found
+                    if (!anyres && !want_full) { done = 1; break; }   // syndrome already in the span of the pivots found
+                    if (want_full && npiv >= a.rank) key = QD_NOKEY;  // rank reached: the rest of the batch is non-pivot
+                    {
+                        // batch columns [bpos, c) depend on earlier pivots: record the first lam_max of them in order
+                        const int cend = (key == QD_NOKEY) ? nb : (int)(key >> 16);
+                        if (want_full && nnp < lam_max) {
+                            if (tid == 0)
+                                for (int x = bpos; x < cend && nnp + (x - bpos) < lam_max; ++x) npl[nnp + (x - bpos)] = S.bcols[x];
+                            nnp = min(lam_max, nnp + max(0, cend - bpos));
+                        }
+                        bpos = cend + 1;
+                    }
                     if (key == QD_NOKEY) break;               // rest of the batch depends on earlier pivots
                     const int c = (int)(key >> 16), p = (int)(key & 0xFFFFu);
                     const int K = npiv, kw = K >> 6;
@@ -629,7 +874,9 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                         if (fresh) qd_q_store<true>(S, qglb, kw_lds, m_pad, kw, r, 0ull);
                         if (r == p) {
                             my_piv |= 1u << i;
-                            S.rowpiv[r] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = S.bcols[c];      // the owner records the pivot
+                            const uint32_t pc = S.bcols[c];
+                            S.rowpiv[r] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = pc;      // the owner records the pivot
+                            if (want_full) atomicOr(&pivmask[pc >> 5], 1u << (pc & 31u));
                         } else if ((my_tb[i] >> c) & 1ull) {
                             my_tb[i] ^= tp;
                             S.tb[r] = my_tb[i];
@@ -655,7 +902,17 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                 }
                 __syncthreads();          // last round's mirror updates, before the next batch re-uses tb / reads rowpiv
                 QD_TICK(2)
+                if (want_full && npiv >= a.rank) {
+                    // the rest of this tier is non-pivot as well
+                    const int rest0 = base + 64;
+                    if (tid == 0)
+                        for (int i = rest0; i < cnt && nnp + (i - rest0) < lam_max; ++i) npl[nnp + (i - rest0)] = order[i];
+                    nnp = min(lam_max, nnp + max(0, cnt - rest0));
+                    __syncthreads();
+                    break;
+                }
             }
+            if (want_full && npiv >= a.rank && nnp >= lam_max) break;
         }
         // ---- residual left on a non-pivot row <=> syndrome outside the column space
         uint32_t resid = 0;
@@ -663,13 +920,17 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
         for (int i = 0; i < RPT; ++i)
             if (tid + i * T < m && !((my_piv >> i) & 1u)) resid |= (my_sp >> i) & 1u;
         const int inconsistent = qd_block_sum<T>(resid, sumbuf, sphase) != 0u;
-        // ---- OSD-0 solution: e[pivot column k] = transformed syndrome at pivot row k
-        for (int k = tid; k < npiv; k += T)
-            if (S.sp[S.prow[k]]) {
-                const uint32_t j = S.pcol[k];
-                atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
-            }
-        __syncthreads();
+        if (want_full) {
+            qd_osd_sweep<T>(a, smem, llr, qglb, npiv, nnp);     // writes the winning candidate (or OSD-0) into outw
+        } else {
+            // ---- OSD-0 solution: e[pivot column k] = transformed syndrome at pivot row k
+            for (int k = tid; k < npiv; k += T)
+                if (S.sp[S.prow[k]]) {
+                    const uint32_t j = S.pcol[k];
+                    atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
+                }
+            __syncthreads();
+        }
         for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = S.outw[w];
         if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
         QD_TICK(3)
@@ -736,6 +997,8 @@ static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const D
     r.det = a.det; r.upd = a.upd; r.det_stride = a.det_stride; r.det_offset = a.det_offset; r.upd_stride = a.upd_stride;
     r.llr_ws = a.llr_ws; r.fail_list = a.fail_list; r.fail_count = a.fail_count; r.q_spill_fast = a.q_spill_fast;
     r.err_bits = a.err_bits; r.status = a.status; r.dbg = a.dbg;
+    r.off_pivmask = g.f_off_pivmask; r.off_npl = g.f_off_npl;
+    r.osd_w = a.osd_w; r.osd_order = a.osd_order; r.rank = a.rank; r.wfix = g.wfix; r.bit_slot_of = bg.bit_slot_of;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TF), g.f_lds_bytes, s, r);
     return hipGetLastError();
 }

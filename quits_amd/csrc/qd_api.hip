@@ -81,6 +81,7 @@ struct qd_decoder {
     uint64_t *q_spill = nullptr, *q_spill_fast = nullptr;
     int32_t *hard_list = nullptr, *hard_list2 = nullptr;
     int osd_blocks_fast = 0;
+    int osd_w = 0;
     int profiling = 0;
     std::vector<hipEvent_t> ev;        // triples (bp start, bp end / osd start, osd end)
     double acc_ms[4] = {0, 0, 0, 0};
@@ -246,6 +247,15 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     rc |= g->mem.upload(chk_orig_u, &bp.chk_orig);
     rc |= g->mem.upload(bit_rec, &bp.bit_rec);
     rc |= g->mem.upload(bit_orig_u, &bp.bit_orig);
+    {
+        std::vector<uint32_t> slot_of(bit_slot_of.begin(), bit_slot_of.end()), wfix((size_t)n);
+        for (int j = 0; j < n; ++j) {
+            double w = std::log(1.0 / priors[j]) * 262144.0;
+            wfix[j] = (uint32_t)std::llround(std::min(std::max(w, 0.0), 4294967295.0));
+        }
+        rc |= g->mem.upload(slot_of, &bp.bit_slot_of);
+        rc |= g->mem.upload(wfix, &g->osd.wfix);
+    }
     // LDS carve-up for BP
     int off = 0;
     bp.off_chk = off; off += (m_pad + 4) * 16;                 // + the dummy check
@@ -304,13 +314,15 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         const int sort_b = tier * 8, order_b = align16(tier * 2);
         od.f_lds_bytes = 0;
         for (int per_cu = 2; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu) {
-            const int f_budget = QD_LDS_BYTES / per_cu - 256 - small - sort_b - order_b;
+            const int f_budget = QD_LDS_BYTES / per_cu - 512 - small - sort_b - order_b - align16(bp.out_words * 4);
             od.f_kw = std::min(od.mw, std::max(0, f_budget / (m_pad * 8)));
             if (od.f_kw < std::min(6, od.mw) || (m + od.f_threads - 1) / od.f_threads > 4) continue;
             int o = carve(od.f_off, od.f_kw * m_pad * 8, 0);
             od.f_off_hist = 0;
             od.f_off_sort = o; o += sort_b;
             od.f_off_order = o; o += order_b;
+            od.f_off_pivmask = o; o += align16(bp.out_words * 4);
+            od.f_off_npl = o; o += 256;
             if (o <= QD_LDS_BYTES) od.f_lds_bytes = o;
         }
     }
@@ -378,13 +390,23 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     if (p->schedule != QD_SCHEDULE_PARALLEL)
         return fail(QD_EUNSUPPORTED, "schedule: only 'parallel' (flooding) runs on the device path; 'serial' is sequential over bits");
     const bool osd0 = p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
-    if (p->osd_method != QD_OSD_OFF && !osd0)
-        return fail(QD_EUNSUPPORTED, "osd_method %d with osd_order %d: only OSD-0 (osd_0, or osd_cs/osd_e with order 0) is implemented on the device path", p->osd_method, p->osd_order);
+    if (p->osd_method != QD_OSD_OFF && !osd0) {
+        if (p->osd_method != QD_OSD_CS && p->osd_method != QD_OSD_E) return fail(QD_EINVAL, "unknown osd_method %d", p->osd_method);
+        if (p->osd_order < 0) return fail(QD_EINVAL, "negative osd_order");
+        if (g->osd.f_lds_bytes == 0)
+            return fail(QD_EUNSUPPORTED, "osd_cs / osd_e need the register OSD kernel, which this window (%d detectors) does not fit", g->m);
+        if (p->osd_method == QD_OSD_CS && p->osd_order > 64)
+            return fail(QD_EUNSUPPORTED, "osd_cs: osd_order %d > 64 is not implemented on the device path", p->osd_order);
+        if (p->osd_method == QD_OSD_E && p->osd_order > 15)
+            return fail(QD_EUNSUPPORTED, "osd_e: osd_order %d > 15 is not implemented on the device path", p->osd_order);
+    }
     if (p->osd_method != QD_OSD_OFF && g->osd.lds_bytes == 0 && g->osd.f_lds_bytes == 0)
         return fail(QD_ECAPACITY, "window %d x %d does not fit either OSD kernel's LDS layout", g->m, g->n);
     if (p->max_iter < 0 || p->ms_scaling_factor < 0) return fail(QD_EINVAL, "negative max_iter / ms_scaling_factor");
     qd_decoder *d = new qd_decoder();
     d->g = g; d->prm = *p;
+    d->osd_w = osd0 || p->osd_method == QD_OSD_OFF ? 0 : (p->osd_method == QD_OSD_CS ? 1 : 2);
+    if (d->osd_w) host_rank(const_cast<qd_graph *>(g));     // the sweep needs the complete factorisation: rank pivots
     if (d->prm.max_iter == 0) d->prm.max_iter = g->n;       // ldpc: max_iter = 0 -> number of bits
     if (d->prm.max_iter > 0xFFFF) d->prm.max_iter = 0xFFFF;
     *out = d;
@@ -506,6 +528,7 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
     a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;   // bytes 16..143 of the counter block
+    a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
     HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (d->profiling) {
@@ -547,6 +570,7 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;
+    a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
     HIP_TRY(qd_launch_stage_llr(d_llr, d->g->n, d->g->bp.n_pad, d->g->bp.bit_orig, B, d->llr_ws, d->fail_list, d->fail_count,
                                 d_status, s));
     HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),

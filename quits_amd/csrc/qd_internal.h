@@ -30,6 +30,7 @@ struct BpGraphDev {
                                 //                        sign (mode 0/1: bit index 0..63 into {w, z}; mode 2: word index << 5 | bit index)
                                 //                        for the q-th check of the fault (q ascending = original row order)
     const uint32_t *bit_orig;   // [n_pad]                fault index of the bit slot
+    const uint32_t *bit_slot_of;// [n]                    bit slot of a fault (inverse of bit_orig)
     int bit_thr[QD_MAX_COL_DEG];// bit_thr[q] = number of bit slots (multiple of 64) whose wavefront has a fault of degree > q
     // LDS carve-up (byte offsets, 16-byte aligned)
     int off_chk, off_cneg, off_llr, off_out, off_misc, lds_bytes;   // off_misc: 64 ints of reduction scratch
@@ -48,7 +49,8 @@ struct OsdGraphDev {
     // LDS carve-up of the full kernel: off[] = q, tb, sp, rowpiv, prow, pcol, pairs, cols, red, out
     int off[10], lds_bytes;
     // ... and of the fast kernel (Q planes overlap the histogram + sort buffer); f_lds_bytes = 0 disables it
-    int f_off[10], f_off_hist, f_off_sort, f_off_order, f_kw, f_lds_bytes, f_threads;
+    int f_off[10], f_off_hist, f_off_sort, f_off_order, f_off_pivmask, f_off_npl, f_kw, f_lds_bytes, f_threads;
+    const uint32_t *wfix;       // [n] integer candidate costs round(log(1/p) * 2^18) for OSD-CS / OSD-E
     int threads;
 };
 
@@ -74,6 +76,7 @@ struct DecodeArgs {
     int32_t *hard_list2;        // [cap]         ... and the second
     int32_t *hard_count;        // [2]
     unsigned long long *dbg;    // [16] phase cycle counters (only written by -DQD_OSD_TIMING builds)
+    int osd_w, osd_order, rank; // higher-order OSD: 0 = OSD-0, 1 = combination sweep, 2 = exhaustive; GF(2) rank of the window matrix
 };
 
 // Workgroup-wide OR without static LDS (a static __shared__ object in front of the dynamic region can knock the

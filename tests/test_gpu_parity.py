@@ -159,7 +159,8 @@ def test_plugin_class_in_host_loop(gpu):
 def test_unsupported_options_fail_loudly(gpu):
     from quits_amd.decoder import BpOsdDecoder
     H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
-    for kw in (dict(bp_method="product_sum"), dict(schedule="serial"), dict(osd_method="osd_cs", osd_order=2)):
+    for kw in (dict(bp_method="product_sum"), dict(schedule="serial"), dict(osd_method="osd_cs", osd_order=65),
+               dict(osd_method="osd_e", osd_order=16)):
         with pytest.raises(NotImplementedError):
             BpOsdDecoder(H, channel_probs=pri, max_iter=5, **{**dict(bp_method="minimum_sum", schedule="parallel",
                                                                osd_method="osd_0", osd_order=0), **kw})
@@ -235,3 +236,39 @@ def test_osd_alone_on_crafted_llrs(gpu, case):
         assert bool(status[b] & (1 << 18)) == st["inconsistent"]
     if case == "deep":
         assert ((status >> 20) & 0xFFF).max() > 900
+
+
+@pytest.mark.parametrize("name,method,order,shots", [
+    ("bb72_custom_r6_p0.003", "osd_cs", 1, 40),
+    ("bb72_custom_r6_p0.003", "osd_cs", 7, 40),
+    ("bb72_custom_r6_p0.003", "osd_e", 5, 40),
+    ("hgp225_cardinal_r3_p0.01", "osd_cs", 3, 6),
+    ("bb144_custom_r12_p0.003", "osd_cs", 2, 6),
+])
+def test_higher_order_osd_bit_exact(gpu, name, method, order, shots):
+    """OSD-CS / OSD-E on the device against the oracle with the same integer candidate costs: full-rank elimination,
+    candidate sweep, ldpc's tie rule (earliest candidate wins)."""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    H, L, pri = helpers.dem_matrices(name)
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=31, shot0=0, B=shots)
+    g = orc.Graph(H, pri)
+    prm = orc.make_params("minimum_sum", "parallel", 6, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32)
+    llr = np.zeros((shots, H.shape[1]), np.float32)
+    for b in range(shots):
+        _, _, l, _ = g.bp(synd[b], prm)
+        llr[b] = l.astype(np.float32)
+    wg = WindowGraph(H, pri)
+    dec = BatchDecoder(wg, max_iter=6, osd_method=method, osd_order=order)
+    bits, status = dec.osd0(torch.from_numpy(synd).cuda(), torch.from_numpy(llr).cuda())
+    err = unpack_bits(bits, wg.n).cpu().numpy()
+    improved = 0
+    for b in range(shots):
+        ref, st = g.osd_w(synd[b], llr[b].astype(np.float64), method, order, fixed=True)
+        assert np.array_equal(err[b], ref), (b, st)
+        improved += st["winner"] > 0
+    assert improved > 0, "no candidate ever beat OSD-0: the sweep is not exercised"
+    # end to end (BP + OSD-CS) through the batch decoder
+    bits2, status2 = dec.decode(torch.from_numpy(synd).cuda())
+    ref2, flags2 = g.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 6, method, order, 1.0, orc.FORM_COMPRESSED_F32))
+    assert np.array_equal(unpack_bits(bits2, wg.n).cpu().numpy(), ref2)
