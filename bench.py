@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--p", type=float, default=0.003)
+    ap.add_argument("--osd-method", default="osd_0", choices=["osd_0", "osd_cs", "osd_e", "osd_off"])
+    ap.add_argument("--osd-order", type=int, default=0)
     ap.add_argument("--p-override", type=float, default=None, help="physical error rate for the non-headline codes")
     ap.add_argument("--code", default="bb144", choices=["bb144", "bb72", "hgp225", "qlp1020"],
                     help="bb144 = the headline (BASELINE configs[2]); bb72 = configs[1]; hgp225 = configs[0] (their circuits at their p)")
@@ -81,7 +83,8 @@ def main():
     m, n = H.shape
     E = int(H.nnz)
     W, F = (R + 2, 1) if args.window is None else args.window
-    opts = dict(bp_method="minimum_sum", schedule="parallel", max_iter=args.max_iter, osd_method="osd_0", osd_order=0)
+    opts = dict(bp_method="minimum_sum", schedule="parallel", max_iter=args.max_iter, osd_method=args.osd_method,
+                osd_order=args.osd_order)
     plan = build_circuit_plan(circ, hz, W, F, R, dict(opts), dict(opts))
     decs = []
     for w in plan.windows:
@@ -175,9 +178,10 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s circuit %s, R=%d, Z basis; DEM %dx%d (E=%d); "
-                               "min-sum flooding BP max_iter=%d ms_scaling=1.0 + OSD-0; W=%d F=%d (%d window%s)"
+                               "min-sum flooding BP max_iter=%d ms_scaling=1.0 + %s(%d); W=%d F=%d (%d window%s)"
                                % ({"bb144": "BB [[144,12,12]]", "bb72": "BB [[72,12,6]]", "hgp225": "HGP [[225,9,6]]", "qlp1020": "QLP [[1020,136]]"}[args.code],
-                                  cname, R, m, n, E, args.max_iter, W, F, len(plan.windows), "" if len(plan.windows) == 1 else "s"),
+                                  cname, R, m, n, E, args.max_iter, args.osd_method, args.osd_order, W, F, len(plan.windows),
+                                  "" if len(plan.windows) == 1 else "s"),
                    "shots_per_step_per_gpu": args.shots, "parallelism": "shots sharded over %d GPU(s), no data-path collective" % world},
         "logical_error_rate": pl, "ler_sigma": float(np.sqrt(max(pl * (1 - pl), 1e-30) / n_shots)),
         "lfr_per_round": 1.0 - (1.0 - pl) ** (1.0 / R),
@@ -203,7 +207,7 @@ def main():
         checks, commits, priors, updates = spacetime(circ, hz, W, F, ncr)
         wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None,
                  "row0": F * k * hz.shape[0]} for k in range(len(checks))]
-        prm = orc.make_params("minimum_sum", "parallel", args.max_iter, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)
+        prm = orc.make_params("minimum_sum", "parallel", args.max_iter, args.osd_method, args.osd_order, 1.0, orc.FORM_LDPC_F64)
         t1 = time.perf_counter()
         ref, cstat = orc.sliding_window_decode(wins, hz.shape[0], det_h, prm)
         cpu_s = time.perf_counter() - t1

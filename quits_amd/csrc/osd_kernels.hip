@@ -519,26 +519,34 @@ __device__ __noinline__ void qd_osd_sweep(const OsdRegArgs &a, unsigned char *sm
             sw[i] = S.sp[row] ? -w : w;                    // a pivot that is on in the OSD-0 solution gets cheaper when flipped
         }
     }
-    auto qbit = [&](uint32_t row, uint32_t kk) -> uint32_t {
-        const uint32_t w = kk >> 6;
-        const uint64_t word = (w < (uint32_t)kw_lds) ? S.q[(size_t)w * m_pad + row] : qglb[(size_t)(w - kw_lds) * m_pad + row];
-        return (uint32_t)(word >> (kk & 63u)) & 1u;
-    };
-    // bits[i] bit q = t_{candidate q}[k_i] for the 32 candidates whose pivot lists sit in J
+    // bits[i] bit q = t_{candidate q}[k_i] for the 32 candidates whose pivot lists sit in J.  The Q words of one candidate
+    // are fetched with independent loads (planes beyond the LDS budget, pivot order >= 64 * f_kw, come from HBM)
     auto eval_bits = [&](uint32_t bits[KP]) {
+        const uint4 *J4 = reinterpret_cast<const uint4 *>(J);
 #pragma unroll
-        for (int i = 0; i < KP; ++i) {
-            bits[i] = 0u;
-            const int k = tid + i * T;
-            if (k < npiv)
-                for (int q = 0; q < 32; ++q) {
-                    uint32_t b = 0u;
-                    for (int e = 0; e < a.max_cdeg; ++e) {
-                        const uint32_t kk = J[q * 16 + e];
-                        if (kk != 0xFFFFu) b ^= ((kk == (uint32_t)k) ? 1u : 0u) ^ qbit(rowk[i], kk);
+        for (int i = 0; i < KP; ++i) bits[i] = 0u;
+        for (int q = 0; q < 32; ++q) {
+            const uint4 ja = J4[2 * q], jb = J4[2 * q + 1];
+            const uint32_t jw[8] = {ja.x, ja.y, ja.z, ja.w, jb.x, jb.y, jb.z, jb.w};
+#pragma unroll
+            for (int i = 0; i < KP; ++i) {
+                const int k = tid + i * T;
+                if (k >= npiv) continue;
+                uint32_t b = 0u;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    if (e < a.max_cdeg) {
+                        const uint32_t kk = (e & 1) ? (jw[e >> 1] >> 16) : (jw[e >> 1] & 0xFFFFu);
+                        const bool valid = kk != 0xFFFFu;
+                        const uint32_t w = valid ? (kk >> 6) : 0u;
+                        uint64_t word = S.q[(size_t)min(w, (uint32_t)kw_lds - 1u) * m_pad + rowk[i]];
+                        if (w >= (uint32_t)kw_lds) word = qglb[(size_t)(w - kw_lds) * m_pad + rowk[i]];
+                        const uint32_t t = ((kk == (uint32_t)k) ? 1u : 0u) ^ ((uint32_t)(word >> (kk & 63u)) & 1u);
+                        b ^= valid ? t : 0u;
                     }
-                    bits[i] |= b << q;
                 }
+                bits[i] |= b << q;
+            }
         }
     };
     auto fill_J = [&](auto col_of) {            // col_of(q) -> fault index or 0xFFFFFFFF
@@ -986,20 +994,22 @@ template <int TF, int RPT>
 static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s)
 {
     auto k = qd_osd0_reg_kernel<TF, RPT>;
-    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.f_lds_bytes);
+    const bool wl = a.osd_w != 0;                              // higher-order OSD uses the one-workgroup-per-CU layout
+    const int lds = wl ? g.w_lds_bytes : g.f_lds_bytes;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     OsdRegArgs r{};
-    r.m = g.m; r.n = g.n; r.m_pad = g.m_pad; r.n_pad = bg.n_pad; r.max_cdeg = g.max_cdeg; r.mw = g.mw; r.f_kw = g.f_kw;
+    r.m = g.m; r.n = g.n; r.m_pad = g.m_pad; r.n_pad = bg.n_pad; r.max_cdeg = g.max_cdeg; r.mw = g.mw; r.f_kw = wl ? g.w_kw : g.f_kw;
     r.out_words = bg.out_words; r.upd_rows = a.upd_rows;
-    for (int i = 0; i < 10; ++i) r.off[i] = g.f_off[i];
-    r.off_sort = g.f_off_sort; r.off_order = g.f_off_order;
+    for (int i = 0; i < 10; ++i) r.off[i] = wl ? g.w_off[i] : g.f_off[i];
+    r.off_sort = wl ? g.w_off_sort : g.f_off_sort; r.off_order = wl ? g.w_off_order : g.f_off_order;
     r.csc_ptr = g.csc_ptr; r.csc_row = g.csc_row; r.bit_orig = bg.bit_orig;
     r.det = a.det; r.upd = a.upd; r.det_stride = a.det_stride; r.det_offset = a.det_offset; r.upd_stride = a.upd_stride;
     r.llr_ws = a.llr_ws; r.fail_list = a.fail_list; r.fail_count = a.fail_count; r.q_spill_fast = a.q_spill_fast;
     r.err_bits = a.err_bits; r.status = a.status; r.dbg = a.dbg;
-    r.off_pivmask = g.f_off_pivmask; r.off_npl = g.f_off_npl;
+    r.off_pivmask = wl ? g.w_off_pivmask : g.f_off_pivmask; r.off_npl = wl ? g.w_off_npl : g.f_off_npl;
     r.osd_w = a.osd_w; r.osd_order = a.osd_order; r.rank = a.rank; r.wfix = g.wfix; r.bit_slot_of = bg.bit_slot_of;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TF), g.f_lds_bytes, s, r);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TF), lds, s, r);
     return hipGetLastError();
 }
 

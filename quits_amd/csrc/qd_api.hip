@@ -312,19 +312,22 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         // Q mirror, which must hold the kernel's 6 register planes (or all mw planes of a small window)
         const int tier = 1024;
         const int sort_b = tier * 8, order_b = align16(tier * 2);
-        od.f_lds_bytes = 0;
-        for (int per_cu = 2; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu) {
+        od.f_lds_bytes = 0; od.w_lds_bytes = 0;
+        auto lay = [&](int per_cu, int *offs, int &o_sort, int &o_order, int &o_piv, int &o_npl, int &kw) -> int {
             const int f_budget = QD_LDS_BYTES / per_cu - 512 - small - sort_b - order_b - align16(bp.out_words * 4);
-            od.f_kw = std::min(od.mw, std::max(0, f_budget / (m_pad * 8)));
-            if (od.f_kw < std::min(6, od.mw) || (m + od.f_threads - 1) / od.f_threads > 4) continue;
-            int o = carve(od.f_off, od.f_kw * m_pad * 8, 0);
-            od.f_off_hist = 0;
-            od.f_off_sort = o; o += sort_b;
-            od.f_off_order = o; o += order_b;
-            od.f_off_pivmask = o; o += align16(bp.out_words * 4);
-            od.f_off_npl = o; o += 256;
-            if (o <= QD_LDS_BYTES) od.f_lds_bytes = o;
-        }
+            kw = std::min(od.mw, std::max(0, f_budget / (m_pad * 8)));
+            if (kw < std::min(6, od.mw) || (m + od.f_threads - 1) / od.f_threads > 4) return 0;
+            int o = carve(offs, kw * m_pad * 8, 0);
+            o_sort = o; o += sort_b;
+            o_order = o; o += order_b;
+            o_piv = o; o += align16(bp.out_words * 4);
+            o_npl = o; o += 256;
+            return o <= QD_LDS_BYTES ? o : 0;
+        };
+        od.f_off_hist = 0;
+        for (int per_cu = 2; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu)
+            od.f_lds_bytes = lay(per_cu, od.f_off, od.f_off_sort, od.f_off_order, od.f_off_pivmask, od.f_off_npl, od.f_kw);
+        od.w_lds_bytes = lay(1, od.w_off, od.w_off_sort, od.w_off_order, od.w_off_pivmask, od.w_off_npl, od.w_kw);
     }
     // the full kernel sorts all n columns in LDS; windows too large for that rely on the register kernel alone
     if (od.lds_bytes == 0 && od.f_lds_bytes == 0) od.threads = 0;
@@ -393,7 +396,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     if (p->osd_method != QD_OSD_OFF && !osd0) {
         if (p->osd_method != QD_OSD_CS && p->osd_method != QD_OSD_E) return fail(QD_EINVAL, "unknown osd_method %d", p->osd_method);
         if (p->osd_order < 0) return fail(QD_EINVAL, "negative osd_order");
-        if (g->osd.f_lds_bytes == 0)
+        if (g->osd.w_lds_bytes == 0)
             return fail(QD_EUNSUPPORTED, "osd_cs / osd_e need the register OSD kernel, which this window (%d detectors) does not fit", g->m);
         if (p->osd_method == QD_OSD_CS && p->osd_order > 64)
             return fail(QD_EUNSUPPORTED, "osd_cs: osd_order %d > 64 is not implemented on the device path", p->osd_order);
@@ -461,7 +464,8 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
             const int v = std::atoi(ev);
             if (v > 0) d->osd_blocks_fast = ncu * v;
         }
-        const int spill_fast = g->osd.mw - g->osd.f_kw;
+        if (d->osd_w) d->osd_blocks_fast = ncu;                         // higher-order OSD: one workgroup per CU (w_* layout)
+        const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
             HIP_TRY(hipMalloc((void **)&d->q_spill_fast, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * spill_fast * g->osd.m_pad));
         HIP_TRY(hipMalloc((void **)&d->hard_list, sizeof(int32_t) * (size_t)max_batch));

@@ -48,8 +48,11 @@ struct OsdGraphDev {
     const uint16_t *csc_row;    // [nnz]  detector index, ascending inside a column
     // LDS carve-up of the full kernel: off[] = q, tb, sp, rowpiv, prow, pcol, pairs, cols, red, out
     int off[10], lds_bytes;
-    // ... and of the fast kernel (Q planes overlap the histogram + sort buffer); f_lds_bytes = 0 disables it
+    // ... of the register kernel for OSD-0 (aims at two workgroups per CU; f_lds_bytes = 0 disables it)
     int f_off[10], f_off_hist, f_off_sort, f_off_order, f_off_pivmask, f_off_npl, f_kw, f_lds_bytes, f_threads;
+    // ... and of the register kernel for OSD-CS / OSD-E (one workgroup per CU, as many Q planes in LDS as fit: the
+    //     candidate sweep reads arbitrary Q bits of every pivot row)
+    int w_off[10], w_off_sort, w_off_order, w_off_pivmask, w_off_npl, w_kw, w_lds_bytes;
     const uint32_t *wfix;       // [n] integer candidate costs round(log(1/p) * 2^18) for OSD-CS / OSD-E
     int threads;
 };
