@@ -55,7 +55,7 @@ typedef struct qd_params {
     int32_t bp_method;          /* QD_BP_*        ; device path: MINIMUM_SUM                     */
     int32_t schedule;           /* QD_SCHEDULE_*  ; device path: PARALLEL (flooding)             */
     int32_t max_iter;           /* 0 -> number of faults n (ldpc convention)                     */
-    int32_t osd_method;         /* QD_OSD_*       ; device path: OFF, 0 (and CS/E with order 0)  */
+    int32_t osd_method;         /* QD_OSD_*       ; device path: OFF, 0, CS (order <= 64), E (order <= 15) */
     int32_t osd_order;
     int32_t reserved;
     double ms_scaling_factor;   /* not exposed by the reference wrapper -> ldpc default 1.0; 0 = 1-2^-it */
@@ -94,7 +94,7 @@ int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int
                     const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
                     uint32_t *d_err_bits, int32_t *d_status, void *stream);
 
-/* OSD-0 alone, on caller-supplied soft information: every shot of the batch is post-processed as if BP had failed with
+/* The decoder's OSD stage alone (OSD-0, or OSD-CS / OSD-E when the decoder was created with them), on caller-supplied soft information: every shot of the batch is post-processed as if BP had failed with
  * posterior LLRs d_llr[b][j] (float, fault order, row stride n).  Same syndrome arguments as qd_decode_batch.  This is
  * ldpc's OsdDecoder.decode(syndrome, log_prob_ratios) (osd.hpp), which BpOsdDecoder.decode calls after a failed BP. */
 int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset, const uint8_t *d_upd,

@@ -694,7 +694,7 @@ __device__ __noinline__ void qd_osd_sweep(const OsdRegArgs &a, unsigned char *sm
     __syncthreads();
 }
 
-template <int T, int RPT>
+template <int T, int RPT, bool WFULL>
 __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -710,12 +710,11 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
     uint32_t *sumbuf = red + 96;
     uint32_t *pivmask = reinterpret_cast<uint32_t *>(smem + a.off_pivmask);    // [out_words] bit j: fault j is a pivot column (higher-order OSD)
     uint32_t *npl = reinterpret_cast<uint32_t *>(smem + a.off_npl);            // [64] first non-pivot columns of the order
-    const bool want_full = a.osd_w != 0;                                        // OSD-CS / OSD-E need the complete factorisation
+    constexpr bool want_full = WFULL;                                           // OSD-CS / OSD-E need the complete factorisation (separate instantiation:
+                                                                                // the OSD-0 kernel must not carry the sweep's registers)
     const int lam_max = want_full ? min(a.osd_order, 64) : 0;
     const int m = a.m, m_pad = a.m_pad, n = a.n, kw_lds = a.f_kw;
     uint64_t *qglb = a.q_spill_fast ? a.q_spill_fast + (int64_t)blockIdx.x * (int64_t)(a.mw - kw_lds) * m_pad : nullptr;
-    const bool in_regs = n <= QD_OSD_KPT * T;
-
     for (int slot = blockIdx.x; slot < nfail; slot += gridDim.x) {
         const int64_t shot = a.fail_list[slot];
         const float *llr = a.llr_ws + (int64_t)slot * a.n_pad;
@@ -928,7 +927,7 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
         for (int i = 0; i < RPT; ++i)
             if (tid + i * T < m && !((my_piv >> i) & 1u)) resid |= (my_sp >> i) & 1u;
         const int inconsistent = qd_block_sum<T>(resid, sumbuf, sphase) != 0u;
-        if (want_full) {
+        if constexpr (want_full) {
             qd_osd_sweep<T>(a, smem, llr, qglb, npiv, nnp);     // writes the winning candidate (or OSD-0) into outw
         } else {
             // ---- OSD-0 solution: e[pivot column k] = transformed syndrome at pivot row k
@@ -993,8 +992,8 @@ __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphD
 template <int TF, int RPT>
 static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s)
 {
-    auto k = qd_osd0_reg_kernel<TF, RPT>;
     const bool wl = a.osd_w != 0;                              // higher-order OSD uses the one-workgroup-per-CU layout
+    auto k = wl ? qd_osd0_reg_kernel<TF, RPT, true> : qd_osd0_reg_kernel<TF, RPT, false>;
     const int lds = wl ? g.w_lds_bytes : g.f_lds_bytes;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
@@ -1029,7 +1028,14 @@ hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const Deco
 {
     if (g.f_lds_bytes > 0) {
         const int rpt = (g.m + g.f_threads - 1) / g.f_threads;
-        if (g.f_threads == 256) return launch_reg<256, 1>(g, bg, a, blocks_fast, s);
+        if (g.f_threads == 256) {
+            switch (rpt) {
+            case 1: return launch_reg<256, 1>(g, bg, a, blocks_fast, s);
+            case 2: return launch_reg<256, 2>(g, bg, a, blocks_fast, s);
+            case 3: return launch_reg<256, 3>(g, bg, a, blocks_fast, s);
+            default: return launch_reg<256, 4>(g, bg, a, blocks_fast, s);
+            }
+        }
         switch (rpt) {
         case 1: return launch_reg<512, 1>(g, bg, a, blocks_fast, s);
         case 2: return launch_reg<512, 2>(g, bg, a, blocks_fast, s);

@@ -301,7 +301,11 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int q_budget = QD_LDS_BYTES - small - 64;
     const int sort_bytes = np2 * 8;
     od.threads = m <= 256 ? 256 : (m <= 512 ? 512 : 1024);
-    od.f_threads = m <= 256 ? 256 : 512;
+    od.f_threads = m <= 256 ? 256 : 512;       // (256 threads with 4 rows each measured slower at m = 1008: 20.4 vs 16.3 ms)
+    if (const char *ev = std::getenv("QD_OSD_THREADS")) {          // tuning knob
+        const int v = std::atoi(ev);
+        if ((v == 256 || v == 512) && (m + v - 1) / v <= 4) od.f_threads = v;
+    }
     od.lds_bytes = 0; od.kw_lds = 0; od.f_lds_bytes = 0; od.f_kw = 0;
     if (sort_bytes <= q_budget) {
         od.kw_lds = std::min(od.mw, q_budget / (m_pad * 8));
@@ -313,21 +317,23 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         const int tier = 1024;
         const int sort_b = tier * 8, order_b = align16(tier * 2);
         od.f_lds_bytes = 0; od.w_lds_bytes = 0;
-        auto lay = [&](int per_cu, int *offs, int &o_sort, int &o_order, int &o_piv, int &o_npl, int &kw) -> int {
-            const int f_budget = QD_LDS_BYTES / per_cu - 512 - small - sort_b - order_b - align16(bp.out_words * 4);
+        // `sweep`: higher-order OSD also keeps a pivot-column bit mask and the list of the first non-pivot columns
+        auto lay = [&](int per_cu, bool sweep, int *offs, int &o_sort, int &o_order, int &o_piv, int &o_npl, int &kw) -> int {
+            const int extra = sweep ? align16(bp.out_words * 4) + 256 : 0;
+            const int f_budget = QD_LDS_BYTES / per_cu - 256 - small - sort_b - order_b - extra;
             kw = std::min(od.mw, std::max(0, f_budget / (m_pad * 8)));
             if (kw < std::min(6, od.mw) || (m + od.f_threads - 1) / od.f_threads > 4) return 0;
             int o = carve(offs, kw * m_pad * 8, 0);
             o_sort = o; o += sort_b;
             o_order = o; o += order_b;
-            o_piv = o; o += align16(bp.out_words * 4);
-            o_npl = o; o += 256;
-            return o <= QD_LDS_BYTES ? o : 0;
+            o_piv = o; o_npl = o;                       // unused by OSD-0
+            if (sweep) { o_piv = o; o += align16(bp.out_words * 4); o_npl = o; o += 256; }
+            return o <= QD_LDS_BYTES / per_cu ? o : 0;
         };
         od.f_off_hist = 0;
         for (int per_cu = 2; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu)
-            od.f_lds_bytes = lay(per_cu, od.f_off, od.f_off_sort, od.f_off_order, od.f_off_pivmask, od.f_off_npl, od.f_kw);
-        od.w_lds_bytes = lay(1, od.w_off, od.w_off_sort, od.w_off_order, od.w_off_pivmask, od.w_off_npl, od.w_kw);
+            od.f_lds_bytes = lay(per_cu, false, od.f_off, od.f_off_sort, od.f_off_order, od.f_off_pivmask, od.f_off_npl, od.f_kw);
+        od.w_lds_bytes = lay(1, true, od.w_off, od.w_off_sort, od.w_off_order, od.w_off_pivmask, od.w_off_npl, od.w_kw);
     }
     // the full kernel sorts all n columns in LDS; windows too large for that rely on the register kernel alone
     if (od.lds_bytes == 0 && od.f_lds_bytes == 0) od.threads = 0;

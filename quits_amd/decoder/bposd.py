@@ -7,10 +7,11 @@ where the reference plugs in `ldpc.bposd_decoder.BpOsdDecoder` (bposd.py:5), thi
 `BpOsdDecoder` below, which runs on the MI355X through libquits_amd.so.
 
 Device path coverage (anything else raises NotImplementedError -- never a silent change of algorithm, and there is
-no CPU fallback):  bp_method='minimum_sum', schedule='parallel', osd_method in {'osd_0', 'osd_off'} or
-'osd_cs'/'osd_e' with osd_order=0 (which ldpc also reduces to OSD-0, osd.hpp).  Note that the reference wrapper's
-own defaults ('product_sum', 'serial', 'osd_cs') are therefore NOT runnable here and must be overridden
-explicitly by the caller.
+no CPU fallback):  bp_method='minimum_sum', schedule='parallel', osd_method in {'osd_0', 'osd_off', 'osd_cs' with
+osd_order <= 64, 'osd_e' with osd_order <= 15}.  Note that the reference wrapper's own defaults ('product_sum',
+'serial') are therefore NOT runnable here and must be overridden explicitly by the caller.
+Higher-order OSD compares candidates by integer costs round(log(1/p) * 2^18) (exact, order-independent sums); ldpc
+sums doubles, so the two can only disagree on candidates whose costs tie to ~1e-5.
 """
 from __future__ import annotations
 
