@@ -86,12 +86,9 @@ def main():
     opts = dict(bp_method="minimum_sum", schedule="parallel", max_iter=args.max_iter, osd_method=args.osd_method,
                 osd_order=args.osd_order)
     plan = build_circuit_plan(circ, hz, W, F, R, dict(opts), dict(opts))
-    decs = []
-    for w in plan.windows:
-        if w["dec"] not in decs:
-            decs.append(w["dec"])
+    decs = plan.decoders()
     for d in decs:
-        d.reserve(args.shots)
+        d.reserve(min(args.shots, 1 << 16))
         d.set_profiling(True)
 
     # ---- synthetic inputs, resident in HBM before the timed region
@@ -137,7 +134,7 @@ def main():
         pr = d.profile(reset=True)
         for k in prof:
             prof[k] += pr[k]
-    st = torch.cat(stats)
+    st = torch.cat([t for (_, t) in stats])
     iters = (st & 0xFFFF).to(torch.int64)
     total_iters = int(iters.sum().item())
     conv_frac = float(((st >> 16) & 1).float().mean().item())
@@ -148,12 +145,8 @@ def main():
         info = w["graph"].info()
         b_iter[id(w["dec"])] = (4 * info["nnz"] + 2 * info["n"]) * 4
     algo_bytes = 0
-    # stats holds one status tensor per (chunk, window) in call order
-    idx = 0
-    for s_t in stats:
-        w = plan.windows[idx % len(plan.windows)]
-        algo_bytes += int((s_t & 0xFFFF).to(torch.int64).sum().item()) * b_iter[id(w["dec"])]
-        idx += 1
+    for (k, s_t) in stats:
+        algo_bytes += int((s_t & 0xFFFF).to(torch.int64).sum().item()) * b_iter[id(plan.windows[k]["dec"])]
     bp_s = prof["bp_ms"] / 1e3
     achieved = (algo_bytes / bp_s / 1e9) if bp_s > 0 else 0.0
 

@@ -94,6 +94,14 @@ int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int
                     const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
                     uint32_t *d_err_bits, int32_t *d_status, void *stream);
 
+/* The two stages of qd_decode_batch separately: stage 1 = BP (non-converged shots and their posteriors are parked in
+ * the decoder's workspace), stage 2 = OSD over the shots parked by the preceding stage-1 call with the SAME
+ * arguments, stage 3 = both.  Lets a host overlap the (latency-bound) OSD of one batch with the (ALU-bound) BP of the
+ * next on a second stream, using one decoder per batch in flight. */
+int qd_decode_stage(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset, const uint8_t *d_upd,
+                    int64_t upd_stride, int32_t upd_rows, int64_t B, uint32_t *d_err_bits, int32_t *d_status,
+                    int32_t stage, void *stream);
+
 /* The decoder's OSD stage alone (OSD-0, or OSD-CS / OSD-E when the decoder was created with them), on caller-supplied soft information: every shot of the batch is post-processed as if BP had failed with
  * posterior LLRs d_llr[b][j] (float, fault order, row stride n).  Same syndrome arguments as qd_decode_batch.  This is
  * ldpc's OsdDecoder.decode(syndrome, log_prob_ratios) (osd.hpp), which BpOsdDecoder.decode calls after a failed BP. */

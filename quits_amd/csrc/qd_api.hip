@@ -83,7 +83,8 @@ struct qd_decoder {
     int osd_blocks_fast = 0;
     int osd_w = 0;
     int profiling = 0;
-    std::vector<hipEvent_t> ev;        // triples (bp start, bp end / osd start, osd end)
+    struct Span { int kind; hipEvent_t t0, t1; };   // kind 0 = BP kernel, 1 = OSD kernel(s)
+    std::vector<Span> ev;
     double acc_ms[4] = {0, 0, 0, 0};
 };
 
@@ -443,7 +444,7 @@ extern "C" void qd_decoder_destroy(qd_decoder *d)
     if (!d) return;
     (void)hipSetDevice(d->g->device);
     free_ws(d);
-    for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
+    for (auto &sp : d->ev) { (void)hipEventDestroy(sp.t0); (void)hipEventDestroy(sp.t1); }
     delete d;
 }
 
@@ -499,31 +500,32 @@ extern "C" int qd_decoder_profile(qd_decoder *d, double *out, int32_t reset)
 {
     if (!d || !out) return fail(QD_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(d->g->device));
-    for (size_t i = 0; i + 2 < d->ev.size(); i += 3) {
-        HIP_TRY(hipEventSynchronize(d->ev[i + 2]));
-        float a = 0.f, b = 0.f;
-        HIP_TRY(hipEventElapsedTime(&a, d->ev[i], d->ev[i + 1]));
-        HIP_TRY(hipEventElapsedTime(&b, d->ev[i + 1], d->ev[i + 2]));
-        d->acc_ms[0] += a; d->acc_ms[1] += b; d->acc_ms[2] += 1; d->acc_ms[3] += (d->prm.osd_method != QD_OSD_OFF);
+    for (auto &sp : d->ev) {
+        HIP_TRY(hipEventSynchronize(sp.t1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, sp.t0, sp.t1));
+        d->acc_ms[sp.kind] += ms; d->acc_ms[2 + sp.kind] += 1;
+        (void)hipEventDestroy(sp.t0); (void)hipEventDestroy(sp.t1);
     }
-    for (hipEvent_t e : d->ev) (void)hipEventDestroy(e);
     d->ev.clear();
     for (int i = 0; i < 4; ++i) out[i] = d->acc_ms[i];
     if (reset) for (int i = 0; i < 4; ++i) d->acc_ms[i] = 0;
     return QD_OK;
 }
 
-extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset,
-                               const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
-                               uint32_t *d_err_bits, int32_t *d_status, void *stream)
+static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset, const uint8_t *d_upd,
+                       int64_t upd_stride, int32_t upd_rows, int64_t B, uint32_t *d_err_bits, int32_t *d_status, int stage,
+                       void *stream)
 {
     if (!d || !d_det || !d_err_bits || !d_status) return fail(QD_EINVAL, "null argument");
+    if (stage < 1 || stage > 3) return fail(QD_EINVAL, "stage must be 1 (BP), 2 (OSD) or 3 (both)");
     if (B < 0 || B > 0x7FFFFFFF) return fail(QD_EINVAL, "batch size out of range");
     if (B == 0) return QD_OK;
     if (det_offset < 0 || det_stride < det_offset + d->g->m) return fail(QD_EINVAL, "detector slice [%lld, %lld) exceeds the row stride %lld", (long long)det_offset, (long long)(det_offset + d->g->m), (long long)det_stride);
     if (d_upd && (upd_rows < 0 || upd_rows > d->g->m || upd_stride < upd_rows)) return fail(QD_EINVAL, "bad syndrome-update shape");
     HIP_TRY(hipSetDevice(d->g->device));
     if (B > d->cap) {
+        if (stage == 2) return fail(QD_EINVAL, "OSD stage without a preceding BP stage of this batch size");
         int rc = qd_decoder_reserve(d, B);
         if (rc) return rc;
     }
@@ -539,20 +541,43 @@ extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;   // bytes 16..143 of the counter block
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
-    HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (d->profiling) {
-        HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1)); HIP_TRY(hipEventCreate(&e2));
-        d->ev.push_back(e0); d->ev.push_back(e1); d->ev.push_back(e2);
-        HIP_TRY(hipEventRecord(e0, s));
+    auto span = [&](int kind, hipEvent_t &t0) -> int {
+        if (!d->profiling) return QD_OK;
+        hipEvent_t t1;
+        HIP_TRY(hipEventCreate(&t0)); HIP_TRY(hipEventCreate(&t1));
+        d->ev.push_back({kind, t0, t1});
+        HIP_TRY(hipEventRecord(t0, s));
+        return QD_OK;
+    };
+    if (stage & 1) {
+        HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
+        hipEvent_t t0 = nullptr;
+        if (int rc = span(0, t0)) return rc;
+        HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
+        if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
     }
-    HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
-    if (d->profiling) HIP_TRY(hipEventRecord(e1, s));
-    if (osd)
+    if ((stage & 2) && osd) {
+        hipEvent_t t0 = nullptr;
+        if (int rc = span(1, t0)) return rc;
         HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                (int)std::min<int64_t>(B, d->osd_blocks), s));
-    if (d->profiling) HIP_TRY(hipEventRecord(e2, s));
+        if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
+    }
     return QD_OK;
+}
+
+extern "C" int qd_decode_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset,
+                               const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
+                               uint32_t *d_err_bits, int32_t *d_status, void *stream)
+{
+    return decode_impl(d, d_det, det_stride, det_offset, d_upd, upd_stride, upd_rows, B, d_err_bits, d_status, 3, stream);
+}
+
+extern "C" int qd_decode_stage(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset,
+                               const uint8_t *d_upd, int64_t upd_stride, int32_t upd_rows, int64_t B,
+                               uint32_t *d_err_bits, int32_t *d_status, int32_t stage, void *stream)
+{
+    return decode_impl(d, d_det, det_stride, det_offset, d_upd, upd_stride, upd_rows, B, d_err_bits, d_status, stage, stream);
 }
 
 extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, int64_t det_offset,

@@ -84,8 +84,9 @@ class BatchDecoder:
     def reserve(self, max_batch: int):
         _lib.check(self._L.qd_decoder_reserve(self._h, int(max_batch)))
 
-    def decode(self, det, det_offset: int = 0, upd=None, err_bits=None, status=None):
+    def decode(self, det, det_offset: int = 0, upd=None, err_bits=None, status=None, stage: int = 3, stream=None):
         """det: cuda uint8 [B, stride]; upd: cuda uint8 [B, rows] or None.
+        stage 1 = BP only, 2 = OSD over the shots the preceding stage-1 call parked (same arguments), 3 = both.
         Returns (err_bits int32 [B, words], status int32 [B])."""
         torch = _torch()
         assert det.is_cuda and det.dtype == torch.uint8 and det.dim() == 2 and det.stride(1) == 1
@@ -100,8 +101,9 @@ class BatchDecoder:
             up, us, ur = _ptr(upd), upd.stride(0), upd.shape[1]
         else:
             up, us, ur = C.c_void_p(0), 0, 0
-        _lib.check(self._L.qd_decode_batch(self._h, _ptr(det), det.stride(0), int(det_offset), up, us, ur, B,
-                                           _ptr(err_bits), _ptr(status), _stream_ptr()))
+        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
+        _lib.check(self._L.qd_decode_stage(self._h, _ptr(det), det.stride(0), int(det_offset), up, us, ur, B,
+                                           _ptr(err_bits), _ptr(status), int(stage), sp))
         return err_bits, status
 
     def osd0(self, det, llr, det_offset: int = 0, upd=None):
@@ -163,10 +165,11 @@ class GF2Matrix:
         self._h = h
         self._L = L
 
-    def xor_apply(self, err_bits, out, accumulate: bool):
+    def xor_apply(self, err_bits, out, accumulate: bool, stream=None):
         """out[b, :nrows] (^)= A @ e_b mod 2, e_b = packed bits err_bits[b]."""
+        sp = _stream_ptr() if stream is None else C.c_void_p(stream.cuda_stream)
         _lib.check(self._L.qd_gf2_spmv_batch(self._h, _ptr(err_bits), err_bits.stride(0), err_bits.shape[0], _ptr(out),
-                                             out.stride(0), 1 if accumulate else 0, _stream_ptr()))
+                                             out.stride(0), 1 if accumulate else 0, sp))
         return out
 
     def __del__(self):

@@ -103,8 +103,20 @@ class DeviceWindowPlan:
                 U = GF2Matrix(Uk)
             self.windows.append({"dec": dec, "graph": graph, "L": GF2Matrix(Lk), "U": U, "row0": int(row0[k])})
 
+    def decoders(self):
+        out = []
+        for w in self.windows:
+            if w["dec"] not in out:
+                out.append(w["dec"])
+        return out
+
     def decode(self, det, stats=None):
-        """det: cuda uint8 [N, ndet]  ->  cuda uint8 [N, nobs] logical predictions."""
+        """det: cuda uint8 [N, ndet]  ->  cuda uint8 [N, nobs] logical predictions.
+
+        Windows outer, shots inner, in chunks of `_CHUNK` shots; everything stays on the caller's stream.  `stats`, if
+        given, receives (window index, status tensor) pairs.  (Overlapping the OSD of one sub-batch with the BP of the
+        next on a second stream -- qd_decode_stage exists for that -- was measured and bought nothing: both kernels are
+        bound by vector-ALU issue, so they simply slow each other down)"""
         import torch
         N = det.shape[0]
         pred = torch.zeros((N, self.nobs), dtype=torch.uint8, device=det.device)
@@ -112,14 +124,14 @@ class DeviceWindowPlan:
             chunk = det[c0:c0 + _CHUNK]
             acc = pred[c0:c0 + _CHUNK]
             upd = None
-            for w in self.windows:
+            for k, w in enumerate(self.windows):
                 err_bits, status = w["dec"].decode(chunk, w["row0"], upd)
                 w["L"].xor_apply(err_bits, acc, accumulate=True)
                 if w["U"] is not None:
                     upd = torch.empty((chunk.shape[0], self.nz), dtype=torch.uint8, device=det.device)
                     w["U"].xor_apply(err_bits, upd, accumulate=False)
                 if stats is not None:
-                    stats.append(status)
+                    stats.append((k, status))
         return pred
 
 
