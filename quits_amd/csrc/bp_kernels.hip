@@ -58,34 +58,51 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
 
 // Bit pass, one edge.  rec = (LDS byte offset of the check state) << 16 | where its sign lives.
 //   load:  gather the 16-byte check state (all of a fault's gathers are issued before any is used)
-//   use :  magnitude = min2 if this fault is the check's argmin, else min1; sign = the check's outgoing sign bit
-#define QD_BIT_LOAD(rec) (*reinterpret_cast<const float4 *>(smem + ((rec) >> 16)))
+//   use :  magnitude = min2 if this fault is the check's argmin, else min1; sign = the check's outgoing sign bit.
+//          {z, w} is laid out as one 64-bit value (signs 0..31 | argmin slot | signs 32..46 | syndrome), so the sign
+//          is a single 64-bit shift by the bit index the record carries.
+// The gather is issued as explicit ds_read_b128: left to the compiler, the {z, w} pair is peeled off into its own
+// 64-bit load and the state arrives as ds_read2_b64, which measured 40% slower for the whole kernel.  QD_BIT_WAIT*
+// is the matching s_waitcnt; it names the gathered registers so that nothing reads them early.
+typedef uint32_t qd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ qd_u32x4 qd_lds_gather16(uint32_t lds_addr)
+{
+    qd_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
+    return v;
+}
+#define QD_BIT_LOAD(rec) qd_lds_gather16(lds_base + ((rec) >> 16))
+#define QD_BIT_WAIT1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory")
+#define QD_BIT_WAIT2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
+#define QD_BIT_WAIT3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
+#define QD_BIT_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
 #define QD_BIT_USE(rec, st_)                                                                                 \
     {                                                                                                        \
-        const uint32_t z_ = __float_as_uint((st_).z);                                                        \
-        const float mag_ = ((z_ << 17) == mylabel) ? (st_).y : (st_).x;                                      \
+        const uint32_t meta_ = (st_).w;                                                     \
+        const uint32_t mag_ = ((uint16_t)meta_ == mylabel) ? (st_).y : (st_).x;                                 \
         uint32_t sg_;                                                                                        \
         if (SM == 2) {                                                                                       \
-            uint32_t sw_ = __float_as_uint((st_).w);                                                         \
+            uint32_t sw_ = (st_).z;                                                         \
             if ((rec) & 0xE0u) sw_ = csgn_hi[((((rec) >> 5) & 7u) - 1u) * m_pad + ((rec) >> 20)];            \
             sg_ = sw_ >> ((rec) & 31u);                                                                      \
         } else if (SM == 1) {                                                                                \
-            sg_ = (uint32_t)((((uint64_t)z_ << 32) | __float_as_uint((st_).w)) >> ((rec) & 63u));           \
+            sg_ = (uint32_t)((((uint64_t)meta_ << 32) | (st_).z) >> ((rec) & 63u));         \
         } else {                                                                                             \
-            sg_ = __float_as_uint((st_).w) >> ((rec) & 31u);                                                 \
+            sg_ = (st_).z >> ((rec) & 31u);                                                 \
         }                                                                                                    \
-        acc += __uint_as_float(sg_ << 31 | __float_as_uint(mag_));                                           \
+        acc += __uint_as_float(sg_ << 31 | mag_);                                           \
     }
 
 // State of a check in LDS (16 bytes, one ds_read_b128):  x = min1 * alpha,  y = min2 * alpha,
-//   z = slot of the argmin fault (bits 0..14) | syndrome bit << 15 | (sign mode 1: sign bits of edges 32..47) << 16,
-//   w = SIGN bits of the outgoing messages on edges 0..31; inside a word, edge k sits at bit (edges_in_word - 1 - k)
-//   (sign of check->bit message k = syndrome ^ parity of all incoming signs ^ incoming sign k).
-// Sign mode 2 (checks wider than 48): edges 32.. keep their sign words in `csgn_hi`.
+//   z = SIGN bits of the outgoing messages on edges 0..31; inside a word, edge k sits at bit (edges_in_word - 1 - k)
+//       (sign of check->bit message k = syndrome ^ parity of all incoming signs ^ incoming sign k),
+//   w = slot of the argmin fault (bits 0..15) | (sign mode 1: sign bits of edges 32..46) << 16 | syndrome bit << 31.
+// Sign mode 2 (checks wider than 44): edges 32.. keep their sign words in `csgn_hi`.
 template <int T, int NCH, int SM, typename ADJ4>
 __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraphDev g, DecodeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;   // LDS address of smem[0]
     float4 *chk = reinterpret_cast<float4 *>(smem + g.off_chk);
     uint32_t *csgn_hi = reinterpret_cast<uint32_t *>(smem + g.off_cneg);
     float *llr = reinterpret_cast<float *>(smem + g.off_llr);
@@ -110,7 +127,7 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         uint32_t s = det[o] & 1u;
         if (upd && (int)o < a.upd_rows) s ^= upd[o] & 1u;
         any |= (int)s;
-        chk[c] = make_float4(0.f, 0.f, __uint_as_float(0x7FFFu | (s << 15)), __uint_as_float(0u));   // no message yet
+        chk[c] = make_float4(0.f, 0.f, __uint_as_float(0u), __uint_as_float(0xFFFFu | (s << 31)));   // no message yet
         if (SM == 2)
             for (int w = 1; w < g.neg_words; ++w) csgn_hi[(w - 1) * m_pad + c] = 0u;
     }
@@ -118,7 +135,7 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
     for (int w = tid; w < g.out_words; w += T) outw[w] = 0u;
     if (tid == 0) {
         llr[g.dummy_bit] = __builtin_inff();                                            // padding edge of a short row: |b| = inf, never a minimum, never negative
-        chk[g.dummy_chk] = make_float4(0.f, 0.f, __uint_as_float(0x7FFFu), __uint_as_float(0u));   // padding edge of a short column: message +0
+        chk[g.dummy_chk] = make_float4(0.f, 0.f, __uint_as_float(0u), __uint_as_float(0xFFFFu));     // padding edge of a short column: message +0
     }
     __syncthreads();
     any = qd_block_or(any, misc, NW, 0);
@@ -135,17 +152,17 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         bool unsat = false;
         for (int c = tid; c < g.m; c += T) {
             const float4 st = chk[c];
-            const uint32_t meta = __float_as_uint(st.z);
-            const uint32_t idx_old = llr_base + ((meta & 0x7FFFu) << 2);   // label = LDS offset of the argmin fault's posterior
-            const uint32_t synd = (meta >> 15) & 1u;
+            const uint32_t meta = __float_as_uint(st.w);
+            const uint32_t idx_old = llr_base + ((meta & 0xFFFFu) << 2);   // label = LDS offset of the argmin fault's posterior
+            const uint32_t synd = meta >> 31;
             const int degp = g.chk_degp_w[__builtin_amdgcn_readfirstlane(c) >> 6];     // scalar load; multiple of 4
             bool us = (synd != 0u);
-            uint32_t idx = llr_base + (0x7FFFu << 2);
+            uint32_t idx = llr_base + (0xFFFFu << 2);
             float a1 = FLT_MAX, a2 = FLT_MAX;
             uint32_t neg0 = 0u, neg1 = 0u, npar = 0u;
             for (int k0 = 0; k0 < degp; k0 += 32) {
-                uint32_t sgnw = __float_as_uint(st.w);
-                if (SM == 1 && k0 != 0) sgnw = meta >> 16;
+                uint32_t sgnw = __float_as_uint(st.z);
+                if (SM == 1 && k0 != 0) sgnw = (meta >> 16) & 0x7FFFu;
                 if (SM == 2 && k0 != 0) sgnw = csgn_hi[((k0 >> 5) - 1) * m_pad + c];
                 uint32_t neww = 0u;
                 const int kend = min(degp - k0, 32);                // multiple of 4
@@ -171,9 +188,9 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             const uint32_t flip = 0u - ((synd ^ (uint32_t)__popc(npar)) & 1u);
             if (SM == 2)
                 for (int k0 = 32; k0 < degp; k0 += 32) csgn_hi[((k0 >> 5) - 1) * m_pad + c] ^= flip;
-            uint32_t nmeta = ((idx - llr_base) >> 2) | (synd << 15);
-            if (SM == 1) nmeta |= (neg1 ^ flip) << 16;
-            chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float(nmeta), __uint_as_float(neg0 ^ flip));
+            uint32_t nmeta = ((idx - llr_base) >> 2) | (synd << 31);
+            if (SM == 1) nmeta |= ((neg1 ^ flip) & 0x7FFFu) << 16;
+            chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float(neg0 ^ flip), __uint_as_float(nmeta));
         }
         const int anyun = qd_block_or(unsat ? 1 : 0, misc, NW, phase);
         phase ^= 1;
@@ -184,7 +201,7 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         // (3 | 2 | 2 | 4 | 4 | 1) with one wave-uniform test per group instead of one per edge.
         for (int b = tid; b < g.n; b += T) {
             const int b0 = __builtin_amdgcn_readfirstlane(b);           // first slot of this wavefront
-            const uint32_t mylabel = (uint32_t)b << 17;                 // my slot, where the check keeps its argmin slot after << 17
+            const uint16_t mylabel = (uint16_t)b;                       // my slot; the check keeps its argmin slot in the low 16 bits of w
             const uint4 r0 = rec4[b];
             uint4 r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1, r4 = r1;
             if (NCH > 1 && b0 < g.bit_thr[3]) r1 = rec4[(size_t)n_pad + b];
@@ -193,27 +210,33 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             if (NCH > 4 && b0 < g.bit_thr[15]) r4 = rec4[(size_t)4 * n_pad + b];
             float acc = __uint_as_float(r0.x);
             {
-                const float4 s0 = QD_BIT_LOAD(r0.y), s1 = QD_BIT_LOAD(r0.z), s2 = QD_BIT_LOAD(r0.w);
+                qd_u32x4 s0 = QD_BIT_LOAD(r0.y), s1 = QD_BIT_LOAD(r0.z), s2 = QD_BIT_LOAD(r0.w);
+                QD_BIT_WAIT3(s0, s1, s2);
                 QD_BIT_USE(r0.y, s0) QD_BIT_USE(r0.z, s1) QD_BIT_USE(r0.w, s2)
             }
             if (NCH > 1 && b0 < g.bit_thr[3]) {
-                const float4 s0 = QD_BIT_LOAD(r1.x), s1 = QD_BIT_LOAD(r1.y);
+                qd_u32x4 s0 = QD_BIT_LOAD(r1.x), s1 = QD_BIT_LOAD(r1.y);
+                QD_BIT_WAIT2(s0, s1);
                 QD_BIT_USE(r1.x, s0) QD_BIT_USE(r1.y, s1)
                 if (b0 < g.bit_thr[5]) {
-                    const float4 s2 = QD_BIT_LOAD(r1.z), s3 = QD_BIT_LOAD(r1.w);
+                    qd_u32x4 s2 = QD_BIT_LOAD(r1.z), s3 = QD_BIT_LOAD(r1.w);
+                    QD_BIT_WAIT2(s2, s3);
                     QD_BIT_USE(r1.z, s2) QD_BIT_USE(r1.w, s3)
                 }
             }
             if (NCH > 2 && b0 < g.bit_thr[7]) {
-                const float4 s0 = QD_BIT_LOAD(r2.x), s1 = QD_BIT_LOAD(r2.y), s2 = QD_BIT_LOAD(r2.z), s3 = QD_BIT_LOAD(r2.w);
+                qd_u32x4 s0 = QD_BIT_LOAD(r2.x), s1 = QD_BIT_LOAD(r2.y), s2 = QD_BIT_LOAD(r2.z), s3 = QD_BIT_LOAD(r2.w);
+                QD_BIT_WAIT4(s0, s1, s2, s3);
                 QD_BIT_USE(r2.x, s0) QD_BIT_USE(r2.y, s1) QD_BIT_USE(r2.z, s2) QD_BIT_USE(r2.w, s3)
             }
             if (NCH > 3 && b0 < g.bit_thr[11]) {
-                const float4 s0 = QD_BIT_LOAD(r3.x), s1 = QD_BIT_LOAD(r3.y), s2 = QD_BIT_LOAD(r3.z), s3 = QD_BIT_LOAD(r3.w);
+                qd_u32x4 s0 = QD_BIT_LOAD(r3.x), s1 = QD_BIT_LOAD(r3.y), s2 = QD_BIT_LOAD(r3.z), s3 = QD_BIT_LOAD(r3.w);
+                QD_BIT_WAIT4(s0, s1, s2, s3);
                 QD_BIT_USE(r3.x, s0) QD_BIT_USE(r3.y, s1) QD_BIT_USE(r3.z, s2) QD_BIT_USE(r3.w, s3)
             }
             if (NCH > 4 && b0 < g.bit_thr[15]) {
-                const float4 s0 = QD_BIT_LOAD(r4.x);
+                qd_u32x4 s0 = QD_BIT_LOAD(r4.x);
+                QD_BIT_WAIT1(s0);
                 QD_BIT_USE(r4.x, s0)
             }
             llr[b] = acc;

@@ -155,11 +155,11 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         delete g;
         return fail(QD_ECAPACITY, "m = %d detectors per window: check-state offsets exceed 16 bits", m);
     }
-    if (n_pad + 1 > 32767) {
+    if (n_pad + 1 > 65535) {
         delete g;
-        return fail(QD_ECAPACITY, "n = %d faults per window: fault slots exceed 15 bits", n);
+        return fail(QD_ECAPACITY, "n = %d faults per window: fault slots exceed 16 bits", n);
     }
-    const int sign_mode = max_rdeg_pad <= 32 ? 0 : (max_rdeg_pad <= 48 ? 1 : 2);
+    const int sign_mode = max_rdeg_pad <= 32 ? 0 : (max_rdeg_pad <= 44 ? 1 : 2);    // mode 1: 15 spare bits of the state word hold signs 32..46
     const int neg_words_ = (max_rdeg_pad + 31) / 32;
     const int off_chk_ = 0, off_cneg_ = (m_pad + 4) * 16;
     const int off_llr_ = off_cneg_ + (sign_mode == 2 ? align16((neg_words_ - 1) * m_pad * 4) : 0);
@@ -219,7 +219,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             const int degp = chk_degp_w[cs / 64];
             const int w = k >> 5, kend = std::min(degp - 32 * w, 32);
             const int sbit = kend - 1 - (k & 31);              // the check pass shifts signs in from bit 0 (v_alignbit)
-            // mode 0/1: bit index into the 64-bit value {z : w} of the state (signs 32..47 sit in z's bits 16..31)
+            // mode 0/1: bit index into the 64-bit value {w : z} of the state (signs 32..46 sit in w's bits 16..30)
             const uint32_t where = sign_mode == 2 ? (((uint32_t)w << 5) | (uint32_t)sbit)
                                                   : (uint32_t)(w == 0 ? sbit : 32 + 16 + sbit);
             bit_rec[rec_at(s, 1 + q)] = ((uint32_t)(off_chk_ + cs * 16) << 16) | where;

@@ -18,7 +18,7 @@ struct BpGraphDev {
     int max_rdeg_pad;           // max_rdeg rounded up to a multiple of 4
     int dummy_bit, dummy_chk;   // LDS slots that pad short rows/columns: llr[dummy_bit] = +inf, chk[dummy_chk] = zero message
     int rec_words;              // uint32 words per fault record (multiple of 4)
-    int sign_mode;              // 0: every check has <= 32 (padded) edges; 1: <= 48, signs 32..47 ride in the state's meta word;
+    int sign_mode;              // 0: every check has <= 32 (padded) edges; 1: <= 44, signs 32..46 ride in the state's meta word;
                                 // 2: wider, signs 32.. live in separate LDS words
     int adj32;                  // 1: chk_adj holds uint32 entries (windows with more than 16379 fault slots), else uint16
     const void *chk_adj;        // [max_rdeg_pad/4][m_pad][4] absolute LDS byte offset (off_llr + slot * 4) of the posterior of the k-th
