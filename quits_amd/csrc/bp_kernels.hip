@@ -32,19 +32,25 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
 #ifndef QD_ABLATE
 #define QD_ABLATE 0        // timing experiments only (tools/ablate_bp.sh); any value but 0 breaks the results
 #endif
+#ifdef QD_BP_TIMING   // phase cycle counters of wavefront 0 (tools/bp_timing.py); slots: 0 check pass, 1 block-OR, 2 bit pass, 3 barrier, 4 prologue, 5 epilogue
+#define QD_BP_TICK(slot) { const unsigned long long now_ = clock64(); acc_[slot] += now_ - tick_; tick_ = now_; }
+#else
+#define QD_BP_TICK(slot)
+#endif
 #ifndef QD_BP_MINWAVES
 #define QD_BP_MINWAVES 8   // waves per SIMD the register allocator must leave room for (8 = two 1024-thread workgroups per CU)
 #endif
 
 // One edge of the check pass.
-//   off  = absolute LDS byte offset of the fault's posterior (doubles as the edge's label for the argmin bookkeeping)
+//   off  = LDS address of the fault's posterior (doubles as the edge's label for the argmin bookkeeping); the kernel's
+//          dynamic LDS starts at address 0 (checked on entry), so the packed 16-bit offsets are used as addresses as they are
 //   sb   = bit of `sgnw` that holds the sign of the previous check->bit message on this edge
 // Branch-free: the second minimum is the median of (min1, min2, |b|); the new sign bits are shifted in from bit 0.
 // (b <= 0) is taken as the sign bit of (bits(b) - 1): exact for every float except -0.0, which cannot occur here -- a
 // posterior is a sum that starts from a non-zero prior, and x - y only yields -0 from (-0) - (+0).
 #define QD_CHECK_EDGE(off, sb)                                                                               \
     {                                                                                                        \
-        const float L_ = *reinterpret_cast<const float *>(smem + (off));                                     \
+        const float L_ = *(const __attribute__((address_space(3))) float *)(uintptr_t)(uint32_t)(off);       \
         us ^= (L_ <= 0.f);                                                                                   \
         const float mag_ = ((off) == idx_old) ? st.y : st.x;                                                 \
         const float prev_ = __uint_as_float(((sgnw >> (sb)) & 1u) << 31 | __float_as_uint(mag_));            \
@@ -71,7 +77,7 @@ __device__ __forceinline__ qd_u32x4 qd_lds_gather16(uint32_t lds_addr)
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
     return v;
 }
-#define QD_BIT_LOAD(rec) qd_lds_gather16(lds_base + ((rec) >> 16))
+#define QD_BIT_LOAD(rec) qd_lds_gather16((rec) >> 16)
 #define QD_BIT_WAIT1(a) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory")
 #define QD_BIT_WAIT2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
 #define QD_BIT_WAIT3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
@@ -103,6 +109,7 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;   // LDS address of smem[0]
+    if (lds_base != 0u) __builtin_trap();   // no static LDS in this kernel: byte offsets into smem are LDS addresses
     float4 *chk = reinterpret_cast<float4 *>(smem + g.off_chk);
     uint32_t *csgn_hi = reinterpret_cast<uint32_t *>(smem + g.off_cneg);
     float *llr = reinterpret_cast<float *>(smem + g.off_llr);
@@ -111,6 +118,7 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
     constexpr int NW = T / 64;
 
     const int tid = threadIdx.x;
+    const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);   // first thread of this wavefront
     const int64_t shot = blockIdx.x;
     const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
     const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
@@ -119,6 +127,10 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
     const ADJ4 *adj4 = reinterpret_cast<const ADJ4 *>(g.chk_adj);
     const uint32_t llr_base = (uint32_t)g.off_llr;
 
+#ifdef QD_BP_TIMING
+    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tick_ = clock64();
+#endif
     // ---- load the window syndrome (sliding_window.py:168-169) and reset the state
     int any = 0;
     if (tid < 64) misc[tid] = 0;
@@ -146,6 +158,7 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
     }
 
     int t = 0, converged = 0, phase = 1;
+    QD_BP_TICK(4)
     for (;;) {
         const float alpha = (a.ms_scale == 0.f) ? (1.0f - ldexpf(1.0f, -(t + 1))) : a.ms_scale;
         // ---- check pass t+1; its parity test is the convergence test of iteration t
@@ -192,22 +205,28 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             if (SM == 1) nmeta |= ((neg1 ^ flip) & 0x7FFFu) << 16;
             chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float(neg0 ^ flip), __uint_as_float(nmeta));
         }
+        QD_BP_TICK(0)
         const int anyun = qd_block_or(unsat ? 1 : 0, misc, NW, phase);
+        QD_BP_TICK(1)
         phase ^= 1;
         if (t >= 1 && !anyun) { converged = 1; break; }
         if (t == a.max_iter) break;
         // ---- bit pass t+1: posterior = prior + sum of check->bit messages, in ascending detector order.
         // Records beyond a fault's degree point at the dummy check (message +0), so edges are handled in fixed groups
         // (3 | 2 | 2 | 4 | 4 | 1) with one wave-uniform test per group instead of one per edge.
-        for (int b = tid; b < g.n; b += T) {
-            const int b0 = __builtin_amdgcn_readfirstlane(b);           // first slot of this wavefront
+        // (the trip count and everything derived from it stay in scalar registers; only the last trip is partial)
+        for (int base = 0; base < g.n; base += T) {
+            const int b = base + tid;
+            if (base + T > g.n && b >= g.n) break;
+            const int b0 = base + wave0;                                // first slot of this wavefront
             const uint16_t mylabel = (uint16_t)b;                       // my slot; the check keeps its argmin slot in the low 16 bits of w
-            const uint4 r0 = rec4[b];
-            uint4 r1 = make_uint4(0, 0, 0, 0), r2 = r1, r3 = r1, r4 = r1;
-            if (NCH > 1 && b0 < g.bit_thr[3]) r1 = rec4[(size_t)n_pad + b];
-            if (NCH > 2 && b0 < g.bit_thr[7]) r2 = rec4[(size_t)2 * n_pad + b];
-            if (NCH > 3 && b0 < g.bit_thr[11]) r3 = rec4[(size_t)3 * n_pad + b];
-            if (NCH > 4 && b0 < g.bit_thr[15]) r4 = rec4[(size_t)4 * n_pad + b];
+            const uint4 *rp = rec4 + base;
+            const uint4 r0 = rp[tid];
+            uint4 r1, r2, r3, r4;
+            if (NCH > 1 && b0 < g.bit_thr[3]) r1 = rp[(size_t)n_pad + tid];
+            if (NCH > 2 && b0 < g.bit_thr[7]) r2 = rp[(size_t)2 * n_pad + tid];
+            if (NCH > 3 && b0 < g.bit_thr[11]) r3 = rp[(size_t)3 * n_pad + tid];
+            if (NCH > 4 && b0 < g.bit_thr[15]) r4 = rp[(size_t)4 * n_pad + tid];
             float acc = __uint_as_float(r0.x);
             {
                 qd_u32x4 s0 = QD_BIT_LOAD(r0.y), s1 = QD_BIT_LOAD(r0.z), s2 = QD_BIT_LOAD(r0.w);
@@ -241,7 +260,9 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             }
             llr[b] = acc;
         }
+        QD_BP_TICK(2)
         __syncthreads();
+        QD_BP_TICK(3)
         ++t;
     }
 
@@ -261,6 +282,13 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
         if (tid == 0) a.fail_list[slot] = (int32_t)shot;
     }
     if (tid == 0) a.status[shot] = t | (converged << 16);
+#ifdef QD_BP_TIMING
+    QD_BP_TICK(5)
+    if (tid == 0) {
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg[i], acc_[i]);
+        atomicAdd(&a.dbg[6], 1ull); atomicAdd(&a.dbg[7], (unsigned long long)t);
+    }
+#endif
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------------

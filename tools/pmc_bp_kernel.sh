@@ -1,0 +1,28 @@
+#!/bin/bash
+# SQ counters of single BP launches (32768 headline shots each, BP stage only).  usage (through gpurun): tools/pmc_bp_kernel.sh <tag>
+TAG=${1:-x}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/pmcbp_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_INSTS_VMEM_WR SQ_CYCLES SQ_BUSY_CU_CYCLES"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set -f csv -d $OUT/p$i -o p$i -- python $REPO/tools/bp_timing.py > $OUT/p$i.log 2> $OUT/p$i.err || tail -3 $OUT/p$i.err
+done
+python - <<PY
+import csv, glob, collections
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ","")[:40]
+        if not k.startswith("qd_bp"): continue
+        per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+lines=[]
+for k, d in per.items():
+    lines.append("== " + k + "   (per launch: last launch | number of launches)")
+    for c, v in sorted(d.items()): lines.append("   %-28s %18.0f   %d" % (c, v[-1], len(v)))
+txt="\n".join(lines); print(txt); open("$OUT/summary.txt","w").write(txt+"\n")
+PY
