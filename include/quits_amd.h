@@ -50,14 +50,18 @@ typedef struct qd_graph qd_graph;       /* one window's Tanner graph + priors, r
 typedef struct qd_decoder qd_decoder;   /* graph + parameters + device workspace                      */
 typedef struct qd_spmat qd_spmat;       /* sparse GF(2) matrix on the device (L_k, U_k, H for sampling) */
 
+/* qd_params.reserved: run flooding min-sum in the one-message-per-edge kernel too (ldpc's own update order, prefix sums
+ * instead of "total minus own"; differs from the compressed kernel only in float rounding).  Validation aid. */
+#define QD_FLAG_EDGE_MESSAGES 1
+
 /* Keyword arguments the reference hands to BpOsdDecoder (decoder/bposd.py:38-49,74-83). */
 typedef struct qd_params {
-    int32_t bp_method;          /* QD_BP_*        ; device path: MINIMUM_SUM                     */
-    int32_t schedule;           /* QD_SCHEDULE_*  ; device path: PARALLEL (flooding)             */
+    int32_t bp_method;          /* QD_BP_*        ; MINIMUM_SUM + PARALLEL runs in the compressed LDS kernel,        */
+    int32_t schedule;           /* QD_SCHEDULE_*  ; every other pair in the one-message-per-edge kernel (HBM)        */
     int32_t max_iter;           /* 0 -> number of faults n (ldpc convention)                     */
     int32_t osd_method;         /* QD_OSD_*       ; device path: OFF, 0, CS (order <= 64), E (order <= 15) */
     int32_t osd_order;
-    int32_t reserved;
+    int32_t reserved;           /* flag bits, QD_FLAG_*; 0 for the reference's behaviour                           */
     double ms_scaling_factor;   /* not exposed by the reference wrapper -> ldpc default 1.0; 0 = 1-2^-it */
 } qd_params;
 

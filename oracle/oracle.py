@@ -66,6 +66,9 @@ def lib():
         L.oq_philox.argtypes = [C.c_uint32] * 6 + [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]
         L.oq_prob_threshold.restype = C.c_uint32
         L.oq_prob_threshold.argtypes = [C.c_double]
+        f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+        L.oq_math_f32.argtypes = [C.c_int, f32p, f32p, C.c_int64]
+        L.oq_math_f32.restype = None
         _LIB = L
     return _LIB
 
@@ -221,3 +224,11 @@ def sample_dem(H_csc, L_csc, priors, seed, shot0, B):
                         Lc.indptr.astype(np.int32), Lc.indices.astype(np.int32),
                         np.ascontiguousarray(priors, dtype=np.float64), int(seed), int(shot0), int(B), synd, obs, nf)
     return synd, obs, nf
+
+
+def math_f32(kind: str, x):
+    """The float tanh(x/2) ('tanh_half') / log((1+c)/(1-c)) ('log_ratio') the f32 product-sum forms evaluate."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    lib().oq_math_f32(0 if kind == "tanh_half" else 1, x, y, x.size)
+    return y

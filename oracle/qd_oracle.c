@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include "qd_math.h"   /* quits_amd/csrc: the float tanh(x/2) and log((1+c)/(1-c)) shared with the HIP kernel (see its header) */
 
 #define OQ_PRODUCT_SUM 0
 #define OQ_MINIMUM_SUM 1
@@ -42,7 +43,7 @@
 #define OQ_FORM_LDPC_F64 0      /* per-edge messages, double, ldpc's update order              */
 #define OQ_FORM_COMPRESSED_F32 1 /* compressed min-sum state, float: bit-exact mirror of the HIP kernel */
 #define OQ_FORM_COMPRESSED_F64 2
-#define OQ_FORM_LDPC_F32 3
+#define OQ_FORM_LDPC_F32 3       /* per-edge messages, float: bit-exact mirror of the general HIP kernel (bp_general.hip) */
 #define OQ_MAX_COL_DEG 64
 
 typedef struct {
@@ -65,6 +66,12 @@ typedef struct {
     double *llr0;            /* log((1-p)/p) in double; cast to float by the f32 forms */
     int rank;                /* -1 until computed */
 } oq_graph;
+
+/* the shared float functions, exposed so that tests can compare them with libm in double */
+void oq_math_f32(int kind, const float *x, float *y, int64_t count)
+{
+    for (int64_t i = 0; i < count; i++) y[i] = kind == 0 ? qd_tanh_half(x[i]) : qd_log_ratio(x[i]);
+}
 
 /* ---------------------------------------------------------------------------------------------------------- */
 oq_graph *oq_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const double *priors)
@@ -114,29 +121,29 @@ void oq_graph_destroy(oq_graph *g)
 #define SFX _f64
 #define REAL_MAX DBL_MAX
 #define REAL_ABS fabs
-#define REAL_TANH tanh
-#define REAL_LOG log
+#define REAL_TANH_HALF(x) tanh((x) / 2)
+#define REAL_LOG_RATIO(c) log((1 + (c)) / (1 - (c)))
 #include "bp_core.inc"
 #undef REAL
 #undef SFX
 #undef REAL_MAX
 #undef REAL_ABS
-#undef REAL_TANH
-#undef REAL_LOG
+#undef REAL_TANH_HALF
+#undef REAL_LOG_RATIO
 
 #define REAL float
 #define SFX _f32
 #define REAL_MAX FLT_MAX
 #define REAL_ABS fabsf
-#define REAL_TANH tanhf
-#define REAL_LOG logf
+#define REAL_TANH_HALF(x) qd_tanh_half(x)
+#define REAL_LOG_RATIO(c) qd_log_ratio(c)
 #include "bp_core.inc"
 #undef REAL
 #undef SFX
 #undef REAL_MAX
 #undef REAL_ABS
-#undef REAL_TANH
-#undef REAL_LOG
+#undef REAL_TANH_HALF
+#undef REAL_LOG_RATIO
 
 /* BP only.  llr_out receives the posterior LLRs as double (exact widening for the float forms).
  * Returns 1 if converged.  ldpc's BpOsdDecoder.decode short-circuits the all-zero syndrome

@@ -12,6 +12,8 @@
 #include <vector>
 
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
+hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
+                                int schedule, int64_t shot0, int nshots, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s);
 hipError_t qd_launch_stage_llr(const float *llr_in, int n, int n_pad, const uint32_t *bit_orig, int64_t B, float *llr_ws,
@@ -65,6 +67,7 @@ struct qd_graph {
     int device = 0;
     int m = 0, n = 0, nnz = 0, max_rdeg = 0, max_cdeg = 0, rank = -1;
     BpGraphDev bp{};
+    GenGraphDev gen{};
     OsdGraphDev osd{};
     DevAllocs mem;
     std::vector<int32_t> h_cp, h_ri;   // host CSC, for the rank
@@ -82,6 +85,8 @@ struct qd_decoder {
     int32_t *hard_list = nullptr, *hard_list2 = nullptr;
     int osd_blocks_fast = 0;
     int osd_w = 0;
+    int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
+    GenWs gws{};
     int profiling = 0;
     struct Span { int kind; hipEvent_t t0, t1; };   // kind 0 = BP kernel, 1 = OSD kernel(s)
     std::vector<Span> ev;
@@ -226,6 +231,19 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         }
     }
     g->h_cp = cp; g->h_ri = ri;
+    {
+        GenGraphDev &gg = g->gen;
+        gg.m = m; gg.n = n; gg.nnz = nnz; gg.out_words = (n + 31) / 32;
+        std::vector<int32_t> rp_v(row_ptr, row_ptr + m + 1), ci_v(col_idx, col_idx + nnz), c2r(nnz);
+        for (int e = 0; e < nnz; ++e) c2r[e] = row_ptr[ri[e]] + pos[e];
+        std::vector<float> l0(n);
+        for (int j = 0; j < n; ++j) l0[j] = (float)std::log((1.0 - priors[j]) / priors[j]);
+        int rcg = 0;
+        rcg |= g->mem.upload(rp_v, &gg.rp); rcg |= g->mem.upload(ci_v, &gg.ci);
+        rcg |= g->mem.upload(cp, &gg.cp); rcg |= g->mem.upload(ri, &gg.ri);
+        rcg |= g->mem.upload(c2r, &gg.c2r); rcg |= g->mem.upload(l0, &gg.llr0);
+        if (rcg) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while building the graph"); }
+    }
 
     BpGraphDev &bp = g->bp;
     bp.m = m; bp.n = n; bp.m_pad = m_pad; bp.n_pad = n_pad; bp.max_rdeg = max_rdeg; bp.max_cdeg = max_cdeg;
@@ -395,10 +413,9 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
 {
     if (!g || !p || !out) return fail(QD_EINVAL, "null argument");
     *out = nullptr;
-    if (p->bp_method != QD_BP_MINIMUM_SUM)
-        return fail(QD_EUNSUPPORTED, "bp_method: only 'minimum_sum' runs on the device path (got %d); product_sum is not implemented", p->bp_method);
-    if (p->schedule != QD_SCHEDULE_PARALLEL)
-        return fail(QD_EUNSUPPORTED, "schedule: only 'parallel' (flooding) runs on the device path; 'serial' is sequential over bits");
+    if (p->bp_method != QD_BP_MINIMUM_SUM && p->bp_method != QD_BP_PRODUCT_SUM) return fail(QD_EINVAL, "unknown bp_method %d", p->bp_method);
+    if (p->schedule != QD_SCHEDULE_PARALLEL && p->schedule != QD_SCHEDULE_SERIAL) return fail(QD_EINVAL, "unknown schedule %d", p->schedule);
+    if (p->reserved & ~QD_FLAG_EDGE_MESSAGES) return fail(QD_EINVAL, "unknown flag bits 0x%x", p->reserved);
     const bool osd0 = p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
     if (p->osd_method != QD_OSD_OFF && !osd0) {
         if (p->osd_method != QD_OSD_CS && p->osd_method != QD_OSD_E) return fail(QD_EINVAL, "unknown osd_method %d", p->osd_method);
@@ -415,6 +432,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     if (p->max_iter < 0 || p->ms_scaling_factor < 0) return fail(QD_EINVAL, "negative max_iter / ms_scaling_factor");
     qd_decoder *d = new qd_decoder();
     d->g = g; d->prm = *p;
+    d->general = (p->bp_method != QD_BP_MINIMUM_SUM || p->schedule != QD_SCHEDULE_PARALLEL || (p->reserved & QD_FLAG_EDGE_MESSAGES)) ? 1 : 0;
     d->osd_w = osd0 || p->osd_method == QD_OSD_OFF ? 0 : (p->osd_method == QD_OSD_CS ? 1 : 2);
     if (d->osd_w) host_rank(const_cast<qd_graph *>(g));     // the sweep needs the complete factorisation: rank pivots
     if (d->prm.max_iter == 0) d->prm.max_iter = g->n;       // ldpc: max_iter = 0 -> number of bits
@@ -432,6 +450,13 @@ static void free_ws(qd_decoder *d)
     if (d->q_spill) (void)hipFree(d->q_spill);
     if (d->q_spill_fast) (void)hipFree(d->q_spill_fast);
     d->q_spill_fast = nullptr;
+    if (d->gws.b2c) (void)hipFree(d->gws.b2c);
+    if (d->gws.c2b) (void)hipFree(d->gws.c2b);
+    if (d->gws.th) (void)hipFree(d->gws.th);
+    if (d->gws.llr) (void)hipFree(d->gws.llr);
+    if (d->gws.syn) (void)hipFree(d->gws.syn);
+    if (d->gws.slot) (void)hipFree(d->gws.slot);
+    d->gws = GenWs{};
     if (d->hard_list) (void)hipFree(d->hard_list);
     if (d->hard_list2) (void)hipFree(d->hard_list2);
     d->hard_list = nullptr; d->hard_list2 = nullptr;
@@ -484,6 +509,23 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         const int spill_planes = g->osd.mw - g->osd.kw_lds;
         if (d->osd_blocks > 0 && spill_planes > 0)
             HIP_TRY(hipMalloc((void **)&d->q_spill, sizeof(uint64_t) * (size_t)d->osd_blocks * spill_planes * g->osd.m_pad));
+    }
+    if (d->general) {
+        // [index][shot] message planes for a chunk of S shots; a batch larger than S is decoded chunk by chunk
+        const bool ps = d->prm.bp_method == QD_BP_PRODUCT_SUM;
+        const size_t per_shot = ((size_t)g->nnz * (ps ? 3 : 2) + g->n) * sizeof(float) + g->m + sizeof(int32_t);
+        double budget_gb = 24.0;
+        if (const char *ev = std::getenv("QD_GENERAL_WS_GB")) budget_gb = std::max(0.001, std::atof(ev));
+        int64_t S = (int64_t)(budget_gb * 1073741824.0 / (double)per_shot) & ~(int64_t)255;
+        S = std::max<int64_t>(256, std::min<int64_t>(S, (max_batch + 255) & ~(int64_t)255));
+        GenWs &w = d->gws;
+        w.S = S;
+        HIP_TRY(hipMalloc((void **)&w.b2c, sizeof(float) * (size_t)g->nnz * S));
+        HIP_TRY(hipMalloc((void **)&w.c2b, sizeof(float) * (size_t)g->nnz * S));
+        if (ps) HIP_TRY(hipMalloc((void **)&w.th, sizeof(float) * (size_t)g->nnz * S));
+        HIP_TRY(hipMalloc((void **)&w.llr, sizeof(float) * (size_t)g->n * S));
+        HIP_TRY(hipMalloc((void **)&w.syn, (size_t)g->m * S));
+        HIP_TRY(hipMalloc((void **)&w.slot, sizeof(int32_t) * (size_t)S));
     }
     d->cap = max_batch;
     return QD_OK;
@@ -553,7 +595,12 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
         hipEvent_t t0 = nullptr;
         if (int rc = span(0, t0)) return rc;
-        HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
+        if (d->general) {
+            for (int64_t b0 = 0; b0 < B; b0 += d->gws.S)
+                HIP_TRY(qd_launch_bp_general(d->g->gen, d->g->bp, a, d->gws, d->prm.bp_method, d->prm.schedule, b0,
+                                             (int)std::min<int64_t>(d->gws.S, B - b0), s));
+        } else
+            HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
         if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
     }
     if ((stage & 2) && osd) {

@@ -38,6 +38,22 @@ struct BpGraphDev {
 };
 
 
+// The general (one message per edge) BP kernel's view: plain CSR + CSC in fault / detector order, prior LLRs in float.
+struct GenGraphDev {
+    int m, n, nnz, out_words;
+    const int32_t *rp, *ci;     // [m + 1], [nnz]   CSR, columns ascending in a row
+    const int32_t *cp, *ri;     // [n + 1], [nnz]   CSC, rows ascending in a column
+    const int32_t *c2r;         // [nnz]            CSC edge -> CSR edge
+    const float *llr0;          // [n]              (float)log((1 - p) / p), the log in double
+};
+// ... and its per-chunk workspace, [index][shot] with S shots per row
+struct GenWs {
+    float *b2c, *c2b, *th, *llr;    // [nnz][S] x 3 (th: product-sum only), [n][S]
+    uint8_t *syn;                   // [m][S]
+    int32_t *slot;                  // [S]  fail-list slot of a shot BP could not finish, else -1
+    int64_t S;
+};
+
 // Elimination (OSD) view: original indexing.
 struct OsdGraphDev {
     int m, n, m_pad, max_cdeg;

@@ -7,9 +7,11 @@ where the reference plugs in `ldpc.bposd_decoder.BpOsdDecoder` (bposd.py:5), thi
 `BpOsdDecoder` below, which runs on the MI355X through libquits_amd.so.
 
 Device path coverage (anything else raises NotImplementedError -- never a silent change of algorithm, and there is
-no CPU fallback):  bp_method='minimum_sum', schedule='parallel', osd_method in {'osd_0', 'osd_off', 'osd_cs' with
-osd_order <= 64, 'osd_e' with osd_order <= 15}.  Note that the reference wrapper's own defaults ('product_sum',
-'serial') are therefore NOT runnable here and must be overridden explicitly by the caller.
+no CPU fallback):  bp_method in {'product_sum', 'minimum_sum'}, schedule in {'parallel', 'serial'} (natural fault
+order), osd_method in {'osd_0', 'osd_off', 'osd_cs' with osd_order <= 64, 'osd_e' with osd_order <= 15}: every
+combination the reference wrapper can request, including its defaults ('product_sum', 'serial', 'osd_cs').
+'minimum_sum' + 'parallel' is the fast pair (check state compressed into LDS, csrc/bp_kernels.hip); the other three run
+one lane per shot with per-edge messages in HBM (csrc/bp_general.hip) -- correct, bandwidth-bound, several times slower.
 Higher-order OSD compares candidates by integer costs round(log(1/p) * 2^18) (exact, order-independent sums); ldpc
 sums doubles, so the two can only disagree on candidates whose costs tie to ~1e-5.
 """
@@ -44,6 +46,8 @@ class BpOsdDecoder:
             error_channel = float(error_rate)
         if str(input_vector_type).lower() not in ("syndrome", "auto"):
             raise NotImplementedError("only syndrome input is supported")
+        if serial_schedule_order is not None or random_schedule_seed not in (0, None):
+            raise NotImplementedError("the serial schedule runs in natural fault order only (ldpc's default)")
         self.graph = WindowGraph(pcm, error_channel)
         self._dec = BatchDecoder(self.graph, bp_method=bp_method, schedule=schedule, max_iter=max_iter,
                                  osd_method=osd_method, osd_order=osd_order, ms_scaling_factor=ms_scaling_factor)

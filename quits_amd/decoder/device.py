@@ -64,12 +64,15 @@ class BatchDecoder:
     """qd_decoder: BP(+OSD-0) over a batch of shots for one window."""
 
     def __init__(self, graph: WindowGraph, bp_method="minimum_sum", schedule="parallel", max_iter=0,
-                 osd_method="osd_0", osd_order=0, ms_scaling_factor=1.0):
+                 osd_method="osd_0", osd_order=0, ms_scaling_factor=1.0, edge_messages=False):
+        """bp_method 'minimum_sum' + schedule 'parallel' runs in the compressed LDS kernel; every other pair -- and that one
+        too when `edge_messages` is set -- in the one-message-per-edge kernel (csrc/bp_general.hip)."""
         self.graph = graph
         L = graph._L
         try:
             prm = _lib.QdParams(_lib.QD_BP[_norm(bp_method)], _lib.QD_SCHEDULE[_norm(schedule)], int(max_iter),
-                                _lib.QD_OSD[_norm(osd_method)], int(osd_order), 0, float(ms_scaling_factor))
+                                _lib.QD_OSD[_norm(osd_method)], int(osd_order), 1 if edge_messages else 0,
+                                float(ms_scaling_factor))
         except KeyError as exc:
             raise ValueError("unknown decoder option %s" % exc) from exc
         h = C.c_void_p()

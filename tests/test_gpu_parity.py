@@ -159,8 +159,8 @@ def test_plugin_class_in_host_loop(gpu):
 def test_unsupported_options_fail_loudly(gpu):
     from quits_amd.decoder import BpOsdDecoder
     H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
-    for kw in (dict(bp_method="product_sum"), dict(schedule="serial"), dict(osd_method="osd_cs", osd_order=65),
-               dict(osd_method="osd_e", osd_order=16)):
+    for kw in (dict(serial_schedule_order=list(range(H.shape[1]))), dict(random_schedule_seed=3),
+               dict(osd_method="osd_cs", osd_order=65), dict(osd_method="osd_e", osd_order=16)):
         with pytest.raises(NotImplementedError):
             BpOsdDecoder(H, channel_probs=pri, max_iter=5, **{**dict(bp_method="minimum_sum", schedule="parallel",
                                                                osd_method="osd_0", osd_order=0), **kw})
@@ -272,3 +272,98 @@ def test_higher_order_osd_bit_exact(gpu, name, method, order, shots):
     bits2, status2 = dec.decode(torch.from_numpy(synd).cuda())
     ref2, flags2 = g.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 6, method, order, 1.0, orc.FORM_COMPRESSED_F32))
     assert np.array_equal(unpack_bits(bits2, wg.n).cpu().numpy(), ref2)
+
+
+# ---- the one-message-per-edge kernel (csrc/bp_general.hip): every bp_method x schedule pair the reference wrapper can
+# request, against the oracle's ldpc-form in float (bp_parallel_edge_f32 / bp_serial_edge_f32), bit for bit.
+def _gpu_decode_general(H, pri, synd, method, schedule, max_iter, osd="osd_off", order=0, alpha=1.0):
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    g = WindowGraph(H, pri)
+    d = BatchDecoder(g, bp_method=method, schedule=schedule, max_iter=max_iter, osd_method=osd, osd_order=order,
+                     ms_scaling_factor=alpha, edge_messages=True)
+    bits, status = d.decode(torch.from_numpy(np.ascontiguousarray(synd)).cuda())
+    return unpack_bits(bits, g.n).cpu().numpy(), status.cpu().numpy()
+
+
+@pytest.mark.parametrize("name,shots,method,schedule,max_iter,alpha", [
+    ("bb72_custom_r6_p0.003", 300, "product_sum", "parallel", 20, 1.0),
+    ("bb72_custom_r6_p0.003", 300, "product_sum", "serial", 6, 1.0),
+    ("bb72_custom_r6_p0.003", 300, "minimum_sum", "serial", 6, 1.0),
+    ("bb72_custom_r6_p0.003", 300, "minimum_sum", "serial", 6, 0.0),
+    ("bb72_custom_r6_p0.003", 300, "minimum_sum", "parallel", 20, 0.75),
+    ("hgp225_cardinal_r3_p0.01", 130, "product_sum", "serial", 3, 1.0),
+    ("hgp225_cardinal_r3_p0.01", 130, "product_sum", "parallel", 10, 1.0),
+    ("bb144_custom_r12_p0.003", 70, "product_sum", "serial", 2, 1.0),      # the reference wrapper's defaults (bposd.py:54)
+])
+def test_general_bp_bit_exact(gpu, name, shots, method, schedule, max_iter, alpha):
+    H, L, pri = helpers.dem_matrices(name)
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=21, shot0=0, B=shots)
+    synd[3] = 0
+    err, status = _gpu_decode_general(H, pri, synd, method, schedule, max_iter, alpha=alpha)
+    ref, flags = orc.Graph(H, pri).decode_batch(synd, orc.make_params(method, schedule, max_iter, "osd_off", 0, alpha,
+                                                                     orc.FORM_LDPC_F32))
+    assert np.array_equal((status >> 16) & 1, flags[:, 0]), "convergence flags differ"
+    assert np.array_equal(status & 0xFFFF, flags[:, 1]), "iteration counts differ"
+    assert np.array_equal(err, ref), "hard decisions differ"
+    assert status[3] & (1 << 19) and not err[3].any()
+
+
+@pytest.mark.parametrize("method,schedule,osd,order,max_iter", [
+    ("product_sum", "serial", "osd_cs", 0, 2),       # bposd.py:54 defaults: osd_cs with osd_order 0 is OSD-0
+    ("product_sum", "serial", "osd_cs", 3, 2),
+    ("product_sum", "parallel", "osd_0", 0, 8),
+    ("minimum_sum", "serial", "osd_e", 4, 3),
+])
+def test_general_bposd_bit_exact(gpu, method, schedule, osd, order, max_iter):
+    """BP in the general kernel, its posteriors handed to the OSD kernels (through the [fault][shot] -> fail-slot rows
+    transpose): predictions equal the oracle's ldpc-form float decoder followed by its OSD."""
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=33, shot0=0, B=400)
+    err, status = _gpu_decode_general(H, pri, synd, method, schedule, max_iter, osd=osd, order=order)
+    prm = orc.make_params(method, schedule, max_iter, osd, order, 1.0, orc.FORM_LDPC_F32)
+    ref, flags = orc.Graph(H, pri).decode_batch(synd, prm)
+    used_osd = (status >> 17) & 1
+    assert np.array_equal(used_osd, 1 - flags[:, 0])
+    assert used_osd.sum() > 10, "test does not exercise OSD"
+    assert np.array_equal(err, ref)
+
+
+def test_general_chunking_and_compressed_agreement(gpu, monkeypatch):
+    """A batch larger than the workspace chunk is decoded chunk by chunk with identical results; and flooding min-sum
+    in the edge form agrees with the compressed LDS kernel on nearly every shot (they differ only in float rounding)."""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    det, _ = DemSampler(H, L, pri).sample(1500, seed=8)
+    g = WindowGraph(H, pri)
+    a = BatchDecoder(g, max_iter=20, osd_method="osd_0", edge_messages=True)
+    bits_a, st_a = a.decode(det)
+    monkeypatch.setenv("QD_GENERAL_WS_GB", "0.02")          # ~ 256-shot chunks
+    b = BatchDecoder(g, max_iter=20, osd_method="osd_0", edge_messages=True)
+    bits_b, st_b = b.decode(det)
+    assert torch.equal(bits_a, bits_b) and torch.equal(st_a, st_b)
+    c = BatchDecoder(g, max_iter=20, osd_method="osd_0")
+    bits_c, st_c = c.decode(det)
+    same = (bits_a == bits_c).all(dim=1).float().mean().item()
+    assert same > 0.97, same
+
+
+def test_reference_defaults_run_on_device(gpu):
+    """`sliding_window_bposd_circuit_mem` with the reference's own default options (product_sum, serial, osd_cs,
+    max_iter=2, osd_order=0; bposd.py:54) against the oracle's sliding-window loop in the same float arithmetic."""
+    from quits_amd.decoder import sliding_window_bposd_circuit_mem
+    from quits_amd.dem import Circuit
+    name = "bb72_custom_r6_p0.003"
+    cd = helpers.code("bb72")
+    H, L, pri = helpers.dem_matrices(name)
+    det, obs, _ = orc.sample_dem(H, L, pri, seed=4, shot0=0, B=200)
+    pred = sliding_window_bposd_circuit_mem(det, Circuit(helpers.circuit_text(name)), cd["hz"], cd["lz"], 3, 1)
+    wins = helpers.window_set(name, 3, 1)
+    nz = cd["hz"].shape[0]
+    for k, w in enumerate(wins):
+        w["row0"] = k * nz
+    prm = orc.make_params("product_sum", "serial", 2, "osd_cs", 0, 1.0, orc.FORM_LDPC_F32)
+    ref, stats = orc.sliding_window_decode(wins, nz, det, prm)
+    assert pred.dtype == np.int64 and np.array_equal(pred, ref.astype(np.int64))
+    assert stats["osd_calls"] > 0
