@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--p", type=float, default=0.003)
+    ap.add_argument("--bp-method", default="minimum_sum", choices=["minimum_sum", "product_sum"])
+    ap.add_argument("--schedule", default="parallel", choices=["parallel", "serial"],
+                    help="anything but minimum_sum + parallel runs in the one-message-per-edge kernel (bp_general.hip)")
     ap.add_argument("--osd-method", default="osd_0", choices=["osd_0", "osd_cs", "osd_e", "osd_off"])
     ap.add_argument("--osd-order", type=int, default=0)
     ap.add_argument("--p-override", type=float, default=None, help="physical error rate for the non-headline codes")
@@ -83,7 +86,8 @@ def main():
     m, n = H.shape
     E = int(H.nnz)
     W, F = (R + 2, 1) if args.window is None else args.window
-    opts = dict(bp_method="minimum_sum", schedule="parallel", max_iter=args.max_iter, osd_method=args.osd_method,
+    general = not (args.bp_method == "minimum_sum" and args.schedule == "parallel")
+    opts = dict(bp_method=args.bp_method, schedule=args.schedule, max_iter=args.max_iter, osd_method=args.osd_method,
                 osd_order=args.osd_order)
     plan = build_circuit_plan(circ, hz, W, F, R, dict(opts), dict(opts))
     decs = plan.decoders()
@@ -171,9 +175,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s circuit %s, R=%d, Z basis; DEM %dx%d (E=%d); "
-                               "min-sum flooding BP max_iter=%d ms_scaling=1.0 + %s(%d); W=%d F=%d (%d window%s)"
+                               "%s %s BP max_iter=%d ms_scaling=1.0 + %s(%d); W=%d F=%d (%d window%s)"
                                % ({"bb144": "BB [[144,12,12]]", "bb72": "BB [[72,12,6]]", "hgp225": "HGP [[225,9,6]]", "qlp1020": "QLP [[1020,136]]"}[args.code],
-                                  cname, R, m, n, E, args.max_iter, args.osd_method, args.osd_order, W, F, len(plan.windows),
+                                  cname, R, m, n, E, args.bp_method, args.schedule, args.max_iter, args.osd_method, args.osd_order, W, F, len(plan.windows),
                                   "" if len(plan.windows) == 1 else "s"),
                    "shots_per_step_per_gpu": args.shots, "parallelism": "shots sharded over %d GPU(s), no data-path collective" % world},
         "logical_error_rate": pl, "ler_sigma": float(np.sqrt(max(pl * (1 - pl), 1e-30) / n_shots)),
@@ -181,11 +185,14 @@ def main():
         "bp_converged_frac": conv_frac, "osd_frac": osd_frac, "mean_bp_iters": total_iters / max(1, st.numel()),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "qd_bp_minsum_kernel", "avg_launch_ms": prof["bp_ms"] / max(1, prof["bp_launches"]),
+                     "kernel": "qd_bp_edge_kernel" if general else "qd_bp_minsum_kernel", "avg_launch_ms": prof["bp_ms"] / max(1, prof["bp_launches"]),
                      "algorithmic_bytes_per_launch": algo_bytes / max(1, prof["bp_launches"]),
-                     "note": "algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the kernel "
-                             "keeps this message state in LDS, so the figure is the traffic an HBM-resident formulation "
-                             "would need, not bytes that cross HBM (see DESIGN.md section 5)",
+                     "note": ("algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the general kernel "
+                              "keeps one message per edge in HBM and really moves a multiple of this (ldpc's forward/backward "
+                              "sweeps; the serial schedule re-reads a row per edge), see DESIGN.md") if general else
+                             ("algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the kernel "
+                              "keeps this message state in LDS, so the figure is the traffic an HBM-resident formulation "
+                              "would need, not bytes that cross HBM (see DESIGN.md section 5)"),
                      "osd_kernel_ms_per_launch": prof["osd_ms"] / max(1, prof["osd_launches"])},
     }
 
@@ -200,7 +207,7 @@ def main():
         checks, commits, priors, updates = spacetime(circ, hz, W, F, ncr)
         wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None,
                  "row0": F * k * hz.shape[0]} for k in range(len(checks))]
-        prm = orc.make_params("minimum_sum", "parallel", args.max_iter, args.osd_method, args.osd_order, 1.0, orc.FORM_LDPC_F64)
+        prm = orc.make_params(args.bp_method, args.schedule, args.max_iter, args.osd_method, args.osd_order, 1.0, orc.FORM_LDPC_F64)
         t1 = time.perf_counter()
         ref, cstat = orc.sliding_window_decode(wins, hz.shape[0], det_h, prm)
         cpu_s = time.perf_counter() - t1

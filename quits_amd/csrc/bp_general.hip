@@ -10,8 +10,15 @@
 //   - the adjacency (row_ptr, col_idx, ...) is read with scalar loads and every loop has a uniform trip count;
 //   - message arrays are laid out [edge][shot]: a wavefront's access to one edge is one contiguous 256-byte line;
 //   - the serial schedule, sequential over the faults of ONE shot, still runs 64 shots per wavefront in lockstep.
-// Messages live in HBM (no LDS, no barriers): this is the bandwidth-bound formulation of SURVEY.md 8(d).  A shot that has
-// converged leaves the loop; its lanes idle until the wavefront's slowest shot is done.
+// Messages live in HBM: this is the bandwidth-bound formulation of SURVEY.md 8(d).  A shot that has converged goes idle;
+// its lanes wait until the slowest of the 64 shots is done.
+// Flooding schedule: rows (then columns) are independent, so G wavefronts of one workgroup share the same 64 shots and
+// take every G-th row / column, with a barrier between the passes -- G times the loads in flight for the same memory.
+// Serial schedule: G = 1 (one wavefront per 64 shots, no barriers).
+//
+// The adjacency arrays are separate __restrict__ kernel arguments on purpose: only then can the compiler prove that the
+// kernel's stores do not clobber them and read them with scalar loads (as members of the by-value graph struct they came
+// in through vector loads + readfirstlane, one dependent VMEM round trip each).
 //
 // tanh(x/2) and log((1+c)/(1-c)) are the fixed-operation-order float functions of qd_math.h (shared with the CPU mirror).
 // The serial product-sum schedule keeps tanh(b2c/2) of every edge beside the message (bp.hpp re-evaluates it once per
@@ -20,69 +27,141 @@
 #include "qd_math.h"
 #include "../../include/quits_amd.h"
 
-#define QD_GEN_THREADS 256
+#ifndef QD_GEN_KG
+#define QD_GEN_KG 1           // (6 measured 5-10 % slower: the scans are not what the serial schedule waits for)
+#endif
+//      QD_GEN_KG:          // checks of one fault whose rows the serial schedule scans together
+#define QD_GEN_MLP 8          // loads of one row issued together (the arithmetic that follows keeps bp.hpp's order)
 
-template <int METHOD, int SCHED>
-__global__ void __launch_bounds__(QD_GEN_THREADS) qd_bp_edge_kernel(GenGraphDev g, DecodeArgs a, GenWs w, int64_t shot0, int nshots)
+#ifdef QD_GEN_TIMING   // serial-schedule phase timers: 0 adjacency, 1 row scans, 2 log / posterior, 3 backward sweep
+#define QD_GT(slot) { const unsigned long long now_ = clock64(); gacc_[slot] += now_ - gtick_; gtick_ = now_; }
+#else
+#define QD_GT(slot)
+#endif
+
+// per-lane OR across the G wavefronts of the workgroup (every wavefront gets the result)
+template <int G>
+__device__ __forceinline__ uint32_t qd_lanes_or(uint32_t v, uint32_t (*red)[64], int wv, int lane)
 {
-    const int ls = blockIdx.x * QD_GEN_THREADS + threadIdx.x;       // shot inside this chunk = column of the workspace
-    if (ls >= nshots) return;
-    const int64_t shot = shot0 + ls;
+    if (G == 1) return v;
+    red[wv][lane] = v;
+    __syncthreads();
+    uint32_t r = 0u;
+#pragma unroll
+    for (int k = 0; k < G; ++k) r |= red[k][lane];
+    __syncthreads();
+    return r;
+}
+
+template <int METHOD, int SCHED, int G>
+__global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+                                                            const int32_t *__restrict__ cp, const int32_t *__restrict__ ri,
+                                                            const int32_t *__restrict__ c2r, const float *__restrict__ llr0,
+                                                            DecodeArgs a, GenWs w, int64_t shot0, int nshots)
+{
+    __shared__ uint32_t red[G][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = G > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;    // which rows / columns this wavefront takes
+    const int ls = blockIdx.x * 64 + lane;                           // shot inside this chunk = column of the workspace
+    bool active = ls < nshots;
+    const int64_t shot = shot0 + (active ? ls : 0);
+    // workspace: [index][S shots] -- wavefronts advance through the graph at nearly the same pace, so at any moment they
+    // touch the same few index planes: the pages in use are shared by all of them.  (A per-wavefront tiling
+    // [tile][index][64] keeps each wavefront's data contiguous but multiplies the pages in flight by the number of
+    // wavefronts; it measured 30 % slower in the flooding schedule.)
     const size_t S = (size_t)w.S;
-    float *__restrict__ b2c = w.b2c + ls;                            // [nnz][S], CSR edge order
-    float *__restrict__ c2b = w.c2b + ls;
-    float *__restrict__ th = w.th ? w.th + ls : nullptr;             // product-sum only
-    float *__restrict__ llr = w.llr + ls;                            // [n][S]
-    uint8_t *__restrict__ syn = w.syn + ls;                          // [m][S]
+    const int lsc = active ? ls : 0;
+    float *__restrict__ b2c = w.b2c + lsc;                           // [nnz][S], CSR edge order
+    float *__restrict__ c2b = w.c2b + lsc;
+    float *__restrict__ th = w.th ? w.th + lsc : nullptr;            // product-sum only
+    float *__restrict__ llr = w.llr + lsc;                           // [n][S]
+    uint8_t *__restrict__ syn = w.syn + lsc;                         // [m][S]
     const float BIG = 3.402823466e+38f;
 
     // ---- window syndrome (sliding_window.py:168-169)
     const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
     const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
     uint32_t any = 0;
-    for (int i = 0; i < g.m; ++i) {
-        uint32_t s = det[i] & 1u;
-        if (upd && i < a.upd_rows) s ^= upd[i] & 1u;
-        syn[(size_t)i * S] = (uint8_t)s;
-        any |= s;
-    }
+    if (active)
+        for (int i = wv; i < g.m; i += G) {
+            uint32_t s = det[i] & 1u;
+            if (upd && i < a.upd_rows) s ^= upd[i] & 1u;
+            syn[(size_t)i * S] = (uint8_t)s;
+            any |= s;
+        }
+    any = qd_lanes_or<G>(any, red, wv, lane);
     uint32_t *out = a.err_bits + shot * g.out_words;
-    w.slot[ls] = -1;
-    if (!any) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
-        for (int x = 0; x < g.out_words; ++x) out[x] = 0u;
-        a.status[shot] = (1 << 16) | (1 << 19);
-        return;
+    if (active && wv == 0) w.slot[ls] = -1;
+    if (active && !any) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
+        if (wv == 0) {
+            for (int x = 0; x < g.out_words; ++x) out[x] = 0u;
+            a.status[shot] = (1 << 16) | (1 << 19);
+        }
+        active = false;
     }
+    const bool ran = active;
 
     // ---- every bit->check message starts as the prior LLR
-    for (int j = 0; j < g.n; ++j) {
-        const float l0 = g.llr0[j];
-        for (int e = g.cp[j]; e < g.cp[j + 1]; ++e) {
-            const size_t ce = (size_t)g.c2r[e] * S;
-            b2c[ce] = l0;
-            if (METHOD == QD_BP_PRODUCT_SUM && SCHED == QD_SCHEDULE_SERIAL) th[ce] = qd_tanh_half(l0);
+    if (active)
+        for (int j = wv; j < g.n; j += G) {
+            const float l0 = llr0[j];
+            for (int e = cp[j]; e < cp[j + 1]; ++e) {
+                const size_t ce = (size_t)c2r[e] * S;
+                b2c[ce] = l0;
+                if (METHOD == QD_BP_PRODUCT_SUM && SCHED == QD_SCHEDULE_SERIAL) th[ce] = qd_tanh_half(l0);
+            }
         }
-    }
+    if (G > 1) __syncthreads();
 
     int iters = 0, converged = 0;
+#ifdef QD_GEN_TIMING
+    unsigned long long gacc_[4] = {0, 0, 0, 0}, gtick_ = clock64();
+#endif
     for (int it = 1; it <= a.max_iter; ++it) {
+        if (G > 1) { if (!__syncthreads_or(active ? 1 : 0)) break; }
+        else if (!active) break;
         const float alpha = (a.ms_scale == 0.f) ? (1.0f - ldexpf(1.0f, -it)) : a.ms_scale;
         if (SCHED == QD_SCHEDULE_PARALLEL) {
             // ---- check pass: forward / backward exclusive sweeps over each row (bp.hpp)
-            for (int i = 0; i < g.m; ++i) {
-                const int r0 = g.rp[i], r1 = g.rp[i + 1];
+            for (int i = wv; active && i < g.m; i += G) {
+                const int r0 = rp[i], r1 = rp[i + 1];
                 const uint32_t si = syn[(size_t)i * S];
                 if (METHOD == QD_BP_PRODUCT_SUM) {
                     const float sgn = si ? -1.0f : 1.0f;
                     float temp = 1.0f;
-                    for (int e = r0; e < r1; ++e) {
+                    int e = r0;
+                    for (; e + QD_GEN_MLP <= r1; e += QD_GEN_MLP) {
+                        float v[QD_GEN_MLP];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) v[k] = b2c[(size_t)(e + k) * S];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) {
+                            const float t = qd_tanh_half(v[k]);
+                            th[(size_t)(e + k) * S] = t;
+                            c2b[(size_t)(e + k) * S] = temp;
+                            temp = temp * t;
+                        }
+                    }
+                    for (; e < r1; ++e) {
                         const float t = qd_tanh_half(b2c[(size_t)e * S]);
                         th[(size_t)e * S] = t;
                         c2b[(size_t)e * S] = temp;
                         temp = temp * t;
                     }
                     temp = 1.0f;
-                    for (int e = r1 - 1; e >= r0; --e) {
+                    e = r1 - 1;
+                    for (; e - (QD_GEN_MLP - 1) >= r0; e -= QD_GEN_MLP) {
+                        float vc[QD_GEN_MLP], vt[QD_GEN_MLP];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) { vc[k] = c2b[(size_t)(e - k) * S]; vt[k] = th[(size_t)(e - k) * S]; }
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) {
+                            const float c = vc[k] * temp;
+                            c2b[(size_t)(e - k) * S] = sgn * qd_log_ratio(c);
+                            temp = temp * vt[k];
+                        }
+                    }
+                    for (; e >= r0; --e) {
                         const float c = c2b[(size_t)e * S] * temp;
                         c2b[(size_t)e * S] = sgn * qd_log_ratio(c);
                         temp = temp * th[(size_t)e * S];
@@ -90,7 +169,20 @@ __global__ void __launch_bounds__(QD_GEN_THREADS) qd_bp_edge_kernel(GenGraphDev 
                 } else {
                     int total_sgn = (int)si;
                     float temp = BIG;
-                    for (int e = r0; e < r1; ++e) {
+                    int e = r0;
+                    for (; e + QD_GEN_MLP <= r1; e += QD_GEN_MLP) {
+                        float v[QD_GEN_MLP];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) v[k] = b2c[(size_t)(e + k) * S];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) {
+                            if (v[k] <= 0.f) total_sgn += 1;
+                            c2b[(size_t)(e + k) * S] = temp;
+                            const float av = fabsf(v[k]);
+                            if (av < temp) temp = av;
+                        }
+                    }
+                    for (; e < r1; ++e) {
                         const float v = b2c[(size_t)e * S];
                         if (v <= 0.f) total_sgn += 1;
                         c2b[(size_t)e * S] = temp;
@@ -98,7 +190,24 @@ __global__ void __launch_bounds__(QD_GEN_THREADS) qd_bp_edge_kernel(GenGraphDev 
                         if (av < temp) temp = av;
                     }
                     temp = BIG;
-                    for (int e = r1 - 1; e >= r0; --e) {
+                    e = r1 - 1;
+                    for (; e - (QD_GEN_MLP - 1) >= r0; e -= QD_GEN_MLP) {
+                        float vb[QD_GEN_MLP], vc[QD_GEN_MLP];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) { vb[k] = b2c[(size_t)(e - k) * S]; vc[k] = c2b[(size_t)(e - k) * S]; }
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_MLP; ++k) {
+                            int sgn = total_sgn;
+                            if (vb[k] <= 0.f) sgn += 1;
+                            float c = vc[k];
+                            if (temp < c) c = temp;
+                            const float msign = (sgn % 2 == 0) ? 1.0f : -1.0f;
+                            c2b[(size_t)(e - k) * S] = c * (msign * alpha);
+                            const float av = fabsf(vb[k]);
+                            if (av < temp) temp = av;
+                        }
+                    }
+                    for (; e >= r0; --e) {
                         const float v = b2c[(size_t)e * S];
                         int sgn = total_sgn;
                         if (v <= 0.f) sgn += 1;
@@ -112,82 +221,141 @@ __global__ void __launch_bounds__(QD_GEN_THREADS) qd_bp_edge_kernel(GenGraphDev 
                 }
             }
             // ---- bit pass: posterior, then the prefix / suffix sums that make the outgoing messages
-            for (int j = 0; j < g.n; ++j) {
-                const int c0 = g.cp[j], c1 = g.cp[j + 1];
-                float temp = g.llr0[j];
-                for (int e = c0; e < c1; ++e) {
-                    const size_t ce = (size_t)g.c2r[e] * S;
-                    b2c[ce] = temp;
-                    temp += c2b[ce];
-                }
+            // (a column's messages are gathered together, the two sweeps run in registers in bp.hpp's order, and each
+            //  outgoing message is written once: prefix + suffix is the value bp.hpp reaches with its `+=`)
+            if (G > 1) __syncthreads();
+            for (int j = wv; active && j < g.n; j += G) {
+                const int c0 = cp[j], deg = cp[j + 1] - c0;
+                float cv[QD_MAX_COL_DEG], pre[QD_MAX_COL_DEG];
+#pragma unroll
+                for (int k = 0; k < QD_MAX_COL_DEG; ++k)
+                    if (k < deg) cv[k] = c2b[(size_t)c2r[c0 + k] * S];
+                float temp = llr0[j];
+#pragma unroll
+                for (int k = 0; k < QD_MAX_COL_DEG; ++k)
+                    if (k < deg) { pre[k] = temp; temp += cv[k]; }
                 llr[(size_t)j * S] = temp;
                 temp = 0.f;
-                for (int e = c1 - 1; e >= c0; --e) {
-                    const size_t ce = (size_t)g.c2r[e] * S;
-                    b2c[ce] += temp;
-                    temp += c2b[ce];
-                }
+#pragma unroll
+                for (int k = QD_MAX_COL_DEG - 1; k >= 0; --k)
+                    if (k < deg) { b2c[(size_t)c2r[c0 + k] * S] = pre[k] + temp; temp += cv[k]; }
             }
+            if (G > 1) __syncthreads();
         } else {
             // ---- serial schedule: faults in natural order, each one refreshing its incoming messages first
-            for (int j = 0; j < g.n; ++j) {
-                const int c0 = g.cp[j], c1 = g.cp[j + 1];
-                float lj = g.llr0[j];
-                for (int e = c0; e < c1; ++e) {
-                    const int i = g.ri[e], own = g.c2r[e];
-                    const int r0 = g.rp[i], r1 = g.rp[i + 1];
-                    const uint32_t si = syn[(size_t)i * S];
-                    float c;
-                    if (METHOD == QD_BP_PRODUCT_SUM) {
-                        float t = 1.0f;
-                        for (int f = r0; f < r1; ++f)
-                            if (f != own) t = t * th[(size_t)f * S];
-                        c = (si ? -1.0f : 1.0f) * qd_log_ratio(t);
-                    } else {
-                        int sgn = (int)si;
-                        float t = BIG;
-                        for (int f = r0; f < r1; ++f)
-                            if (f != own) {
-                                const float v = b2c[(size_t)f * S];
-                                const float av = fabsf(v);
-                                if (av < t) t = av;
-                                if (v <= 0.f) sgn += 1;
-                            }
-                        c = alpha * ((sgn % 2 == 0) ? 1.0f : -1.0f) * t;
+            for (int j = 0; active && j < g.n; ++j) {
+                const int c0 = cp[j], c1 = cp[j + 1];
+                float lj = llr0[j];
+                float cv[QD_MAX_COL_DEG], pre[QD_MAX_COL_DEG];
+                const int deg = c1 - c0;
+                QD_GT(3)
+                // The incoming messages of the fault's checks do not depend on one another, only the running posterior
+                // does: the rows of up to QD_GEN_KG checks are scanned together (QD_GEN_KG x QD_GEN_MLP loads in flight),
+                // each check's own product / minimum still in bp.hpp's order.
+#pragma unroll
+                for (int k0 = 0; k0 < QD_MAX_COL_DEG; k0 += QD_GEN_KG) {
+                    if (k0 >= deg) break;
+                    int r0[QD_GEN_KG], r1[QD_GEN_KG], own[QD_GEN_KG], sg[QD_GEN_KG];
+                    float t[QD_GEN_KG];
+                    int maxlen = 0;
+#pragma unroll
+                    for (int k = 0; k < QD_GEN_KG; ++k) {
+                        r0[k] = 0; r1[k] = 0; own[k] = -1; sg[k] = 0;
+                        t[k] = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
+                        if (k0 + k < QD_MAX_COL_DEG && k0 + k < deg) {
+                            const int e = c0 + k0 + k;
+                            const int i = ri[e];
+                            own[k] = c2r[e];
+                            r0[k] = rp[i]; r1[k] = rp[i + 1];
+                            sg[k] = (int)syn[(size_t)i * S];
+                            maxlen = max(maxlen, r1[k] - r0[k]);
+                        }
                     }
-                    c2b[(size_t)own * S] = c;
-                    b2c[(size_t)own * S] = lj;
-                    lj += c;
+                    QD_GT(0)
+                    const float *__restrict__ src = METHOD == QD_BP_PRODUCT_SUM ? th : b2c;
+                    for (int off = 0; off < maxlen; off += QD_GEN_MLP) {
+                        float v[QD_GEN_KG][QD_GEN_MLP];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_KG; ++k)
+#pragma unroll
+                            for (int q = 0; q < QD_GEN_MLP; ++q)
+                                if (r0[k] + off + q < r1[k]) v[k][q] = src[(size_t)(r0[k] + off + q) * S];
+#pragma unroll
+                        for (int k = 0; k < QD_GEN_KG; ++k)
+#pragma unroll
+                            for (int q = 0; q < QD_GEN_MLP; ++q) {
+                                const int f = r0[k] + off + q;
+                                if (f < r1[k] && f != own[k]) {
+                                    if (METHOD == QD_BP_PRODUCT_SUM) t[k] = t[k] * v[k][q];
+                                    else {
+                                        const float av = fabsf(v[k][q]);
+                                        if (av < t[k]) t[k] = av;
+                                        if (v[k][q] <= 0.f) sg[k] += 1;
+                                    }
+                                }
+                            }
+                    }
+                    QD_GT(1)
+#pragma unroll
+                    for (int k = 0; k < QD_GEN_KG; ++k)
+                        if (k0 + k < QD_MAX_COL_DEG && k0 + k < deg) {
+                            float c;
+                            if (METHOD == QD_BP_PRODUCT_SUM) c = ((sg[k] & 1) ? -1.0f : 1.0f) * qd_log_ratio(t[k]);
+                            else c = alpha * ((sg[k] % 2 == 0) ? 1.0f : -1.0f) * t[k];
+                            cv[k0 + k] = c;              // (bp.hpp stores c2b and b2c here; nothing reads them before the
+                            pre[k0 + k] = lj;            //  backward sweep below, which writes the final b2c)
+                            lj += c;
+                        }
                 }
+                QD_GT(2)
                 llr[(size_t)j * S] = lj;
                 float temp = 0.f;
-                for (int e = c1 - 1; e >= c0; --e) {
-                    const size_t ce = (size_t)g.c2r[e] * S;
-                    const float v = b2c[ce] + temp;
-                    b2c[ce] = v;
-                    if (METHOD == QD_BP_PRODUCT_SUM) th[ce] = qd_tanh_half(v);
-                    temp += c2b[ce];
-                }
+#pragma unroll
+                for (int k = QD_MAX_COL_DEG - 1; k >= 0; --k)
+                    if (k < c1 - c0) {               // b2c = prefix (kept in registers) + suffix; c2b likewise
+                        const size_t ce = (size_t)c2r[c0 + k] * S;
+                        const float v = pre[k] + temp;
+                        b2c[ce] = v;
+                        if (METHOD == QD_BP_PRODUCT_SUM) th[ce] = qd_tanh_half(v);
+                        temp += cv[k];
+                    }
             }
         }
         // ---- stop when the hard decision reproduces the syndrome
         uint32_t bad = 0;
-        for (int i = 0; i < g.m; ++i) {
+        for (int i = wv; active && i < g.m; i += G) {
             uint32_t p = syn[(size_t)i * S];
-            for (int e = g.rp[i]; e < g.rp[i + 1]; ++e) p ^= (llr[(size_t)g.ci[e] * S] <= 0.f) ? 1u : 0u;
+            const int r1 = rp[i + 1];
+            int e = rp[i];
+            for (; e + QD_GEN_MLP <= r1; e += QD_GEN_MLP) {
+                float v[QD_GEN_MLP];
+#pragma unroll
+                for (int k = 0; k < QD_GEN_MLP; ++k) v[k] = llr[(size_t)ci[e + k] * S];
+#pragma unroll
+                for (int k = 0; k < QD_GEN_MLP; ++k) p ^= (v[k] <= 0.f) ? 1u : 0u;
+            }
+            for (; e < r1; ++e) p ^= (llr[(size_t)ci[e] * S] <= 0.f) ? 1u : 0u;
             bad |= p;
         }
-        iters = it;
-        if (!bad) { converged = 1; break; }
+        bad = qd_lanes_or<G>(bad, red, wv, lane);
+        if (active) {
+            iters = it;
+            if (!bad) { converged = 1; active = false; }
+        }
     }
 
     // ---- hard decision, packed by fault index
-    for (int x = 0; x < g.out_words; ++x) {
+    if (!ran) return;
+    for (int x = wv; x < g.out_words; x += G) {
         uint32_t word = 0u;
         const int j1 = min(g.n, 32 * x + 32);
         for (int j = 32 * x; j < j1; ++j) word |= ((llr[(size_t)j * S] <= 0.f) ? 1u : 0u) << (j & 31);
         out[x] = word;
     }
+#ifdef QD_GEN_TIMING
+    if (lane == 0 && wv == 0) { for (int i = 0; i < 4; ++i) atomicAdd(&a.dbg[i], gacc_[i]); atomicAdd(&a.dbg[4], (unsigned long long)iters); }
+#endif
+    if (wv != 0) return;
     a.status[shot] = iters | (converged << 16);
     if (!converged && a.want_llr) {
         const int slot = atomicAdd(a.fail_count, 1);
@@ -220,11 +388,13 @@ __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__rest
     }
 }
 
-template <int METHOD, int SCHED>
+#define QD_GEN_G 8            // wavefronts per 64 shots in the flooding schedule
+
+template <int METHOD, int SCHED, int G>
 static hipError_t launch_k(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
 {
-    hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED>), dim3((unsigned)((nshots + QD_GEN_THREADS - 1) / QD_GEN_THREADS)),
-                       dim3(QD_GEN_THREADS), 0, s, g, a, w, shot0, nshots);
+    hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G>), dim3((unsigned)((nshots + 63) / 64)), dim3(64 * G), 0, s, g, g.rp, g.ci,
+                       g.cp, g.ri, g.c2r, g.llr0, a, w, shot0, nshots);
     return hipGetLastError();
 }
 
@@ -233,11 +403,11 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
 {
     hipError_t e;
     if (bp_method == QD_BP_PRODUCT_SUM)
-        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_PARALLEL>(g, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL>(g, a, w, shot0, nshots, s);
+        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, a, w, shot0, nshots, s)
+                                             : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL, 1>(g, a, w, shot0, nshots, s);
     else
-        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_PARALLEL>(g, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL>(g, a, w, shot0, nshots, s);
+        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, a, w, shot0, nshots, s)
+                                             : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL, 1>(g, a, w, shot0, nshots, s);
     if (e != hipSuccess || !a.want_llr) return e;
     hipLaunchKernelGGL(qd_publish_llr_kernel, dim3((unsigned)((g.n + 63) / 64), (unsigned)((nshots + 63) / 64)), dim3(256), 0, s,
                        w.llr, w.slot, w.S, nshots, g.n, bg.n_pad, bg.bit_orig, a.llr_ws);

@@ -514,10 +514,14 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         // [index][shot] message planes for a chunk of S shots; a batch larger than S is decoded chunk by chunk
         const bool ps = d->prm.bp_method == QD_BP_PRODUCT_SUM;
         const size_t per_shot = ((size_t)g->nnz * (ps ? 3 : 2) + g->n) * sizeof(float) + g->m + sizeof(int32_t);
-        double budget_gb = 24.0;
+        // Default budget 48 GB of the 288: the kernel is latency-bound (one wavefront per 64 shots), so a launch costs about
+        // the same for 8 K or 64 K shots and chunks should be as large as memory allows -- and of equal size.
+        double budget_gb = 48.0;
         if (const char *ev = std::getenv("QD_GENERAL_WS_GB")) budget_gb = std::max(0.001, std::atof(ev));
         int64_t S = (int64_t)(budget_gb * 1073741824.0 / (double)per_shot) & ~(int64_t)255;
-        S = std::max<int64_t>(256, std::min<int64_t>(S, (max_batch + 255) & ~(int64_t)255));
+        S = std::max<int64_t>(256, S);
+        const int64_t nchunks = (max_batch + S - 1) / S;
+        S = std::max<int64_t>(256, (((max_batch + nchunks - 1) / nchunks) + 255) & ~(int64_t)255);
         GenWs &w = d->gws;
         w.S = S;
         HIP_TRY(hipMalloc((void **)&w.b2c, sizeof(float) * (size_t)g->nnz * S));
