@@ -166,3 +166,40 @@ def test_oracle_plugin_surface():
     assert e.shape == (H.shape[1],) and np.array_equal(np.asarray(H @ e % 2).ravel(), s[0])
     with pytest.raises(ValueError):
         orc.OracleBpOsdDecoder(csc_matrix(H))
+
+
+def test_float_elementary_functions_against_libm():
+    """tanh(x/2) and log((1+c)/(1-c)) as the float product-sum forms evaluate them (quits_amd/csrc/qd_math.h, shared by
+    the HIP kernel and the oracle's float form) against libm in double: a few ulp, monotone clamp at +-(1 - 2^-24)."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-40, 40, 100000), rng.uniform(-1, 1, 100000), rng.normal(0, 1e-3, 20000),
+                        [0.0, -0.0, 0.5, -0.5, 0.49999997, 17.0, 19.0, 35.0, 50.0, 1e4, 1e-30]]).astype(np.float32)
+    y = orc.math_f32("tanh_half", x)
+    ref = np.clip(np.tanh(x.astype(np.float64) / 2), -0.99999994, 0.99999994)
+    ulp = np.abs(y - ref) / np.spacing(np.maximum(np.abs(ref), 1e-30).astype(np.float32)).astype(np.float64)
+    assert ulp.max() < 8, ulp.max()
+    assert np.all(np.abs(y) <= np.float32(0.99999994)) and np.array_equal(np.signbit(y), np.signbit(x))
+    c = np.concatenate([rng.uniform(-1, 1, 100000), rng.normal(0, 1e-3, 20000), 1 - 10.0 ** rng.uniform(-7.2, -1, 50000),
+                        [0.0, 0.171875, 0.17187501, 0.99999994, -0.99999994, 1e-20]]).astype(np.float32)
+    c = np.clip(c, -0.99999994, 0.99999994)
+    y = orc.math_f32("log_ratio", c)
+    ref = 2 * np.arctanh(c.astype(np.float64))
+    ulp = np.abs(y - ref) / np.spacing(np.maximum(np.abs(ref), 1e-30).astype(np.float32)).astype(np.float64)
+    assert ulp.max() < 8, ulp.max()
+    assert abs(float(orc.math_f32("log_ratio", np.float32([0.99999994]))[0]) - 25 * np.log(2)) < 1e-5
+
+
+@pytest.mark.parametrize("method,schedule,max_iter", [("product_sum", "parallel", 20), ("product_sum", "serial", 6),
+                                                      ("minimum_sum", "serial", 6)])
+def test_float_edge_form_tracks_double(method, schedule, max_iter):
+    """The float per-edge form (what the general HIP kernel computes) against ldpc's arithmetic type: same convergence
+    flags and decisions on nearly every shot."""
+    H, Lm, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    synd, _, _ = orc.sample_dem(H, Lm, pri, seed=21, shot0=0, B=250)
+    g = orc.Graph(H, pri)
+    e32, f32 = g.decode_batch(synd, orc.make_params(method, schedule, max_iter, "osd_0", 0, 1.0, orc.FORM_LDPC_F32))
+    e64, f64 = g.decode_batch(synd, orc.make_params(method, schedule, max_iter, "osd_0", 0, 1.0, orc.FORM_LDPC_F64))
+    assert (f32[:, 0] == f64[:, 0]).mean() > 0.98
+    assert (e32 == e64).all(axis=1).mean() > 0.97
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    assert np.array_equal(e32.astype(np.int64) @ Hd.T % 2, synd)
