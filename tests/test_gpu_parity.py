@@ -367,3 +367,22 @@ def test_reference_defaults_run_on_device(gpu):
     ref, stats = orc.sliding_window_decode(wins, nz, det, prm)
     assert pred.dtype == np.int64 and np.array_equal(pred, ref.astype(np.int64))
     assert stats["osd_calls"] > 0
+
+
+def test_codecap_driver_on_device(gpu):
+    """`get_codecap_pL` with the HIP plug-in (all trials in one batched decode) against the reference's function run with
+    the oracle's float forms (golden G8): identical logical error rates."""
+    import json, os, types
+    from quits_amd.decoder import BpOsdDecoder
+    from quits_amd.simulation import get_codecap_pL
+    seen = 0
+    for ent in json.load(open(os.path.join(helpers.GOLD, "codecap.json"))):
+        if ent["form"] == "f64":
+            continue
+        cd = helpers.code(ent["code"])
+        cobj = types.SimpleNamespace(hz=cd["hz"], hx=cd["hx"], lz=cd["lz"], lx=cd["lx"])
+        pl = get_codecap_pL(cobj, ent["p"], ent["trials"], BpOsdDecoder, dict(ent["opts"], error_rate=ent["p"]),
+                            basis=ent["basis"], seed=ent["seed"])
+        assert pl == ent["pL"], ent
+        seen += 1
+    assert seen == 4

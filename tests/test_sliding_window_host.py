@@ -109,3 +109,20 @@ def test_device_entry_points_fail_loudly_without_gpu():
     with pytest.raises(RuntimeError):
         sliding_window_bposd_phenom_mem(det, hz, lz, 3, 1, eff_error_rate_per_fault=0.01, bp_method="minimum_sum",
                                         schedule="parallel", osd_method="osd_0")
+
+
+def test_codecap_driver_matches_reference():
+    """`get_codecap_pL` (simulation.py:31-61) with the oracle plug-in: same random stream, same logical error rate as the
+    reference's own function run with the same plug-in (golden G8, tools/gen_fixtures.py codecap)."""
+    import json, os, types
+    from quits_amd.simulation import get_codecap_pL
+    for ent in json.load(open(os.path.join(helpers.GOLD, "codecap.json"))):
+        if ent["form"] != "f64" or ent["trials"] > 300:
+            continue
+        cd = helpers.code(ent["code"])
+        cobj = types.SimpleNamespace(hz=cd["hz"], hx=cd["hx"], lz=cd["lz"], lx=cd["lx"])
+        d = dict(ent["opts"], error_rate=ent["p"], form=orc.FORM_LDPC_F64)
+        pl = get_codecap_pL(cobj, ent["p"], ent["trials"], orc.OracleBpOsdDecoder, d, basis=ent["basis"], seed=ent["seed"])
+        assert pl == ent["pL"], ent
+    with pytest.raises(ValueError):
+        get_codecap_pL(cobj, 0.01, 1, orc.OracleBpOsdDecoder, d, basis="Y")

@@ -265,6 +265,33 @@ def gen_loop():
         print("loop:", cname, {k: v.shape for k, v in out.items() if k.startswith(("circ", "phen"))})
 
 
+def gen_codecap():
+    """G8: the reference's code-capacity driver (simulation.py:31-61) run with the oracle decoder as plug-in ->
+    logical error rates for fixed seeds."""
+    import json
+    import types
+    import_reference()
+    from quits.simulation import get_codecap_pL
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    out = []
+    for code, p, trials, seed, basis, opts in (
+            ("hgp225", 0.02, 300, 1, "Z", dict(bp_method="minimum_sum", schedule="parallel", max_iter=20, osd_method="osd_0", osd_order=0)),
+            ("hgp225", 0.03, 200, 5, "X", dict(bp_method="product_sum", schedule="serial", max_iter=4, osd_method="osd_cs", osd_order=2)),
+            ("bb72", 0.04, 300, 2, "Z", dict(bp_method="minimum_sum", schedule="parallel", max_iter=15, osd_method="osd_0", osd_order=0)),
+            ("bb72", 0.05, 200, 9, "Z", dict(bp_method="product_sum", schedule="parallel", max_iter=10, osd_method="osd_0", osd_order=0))):
+        cd = _load_code(code)
+        cobj = types.SimpleNamespace(hz=cd["hz"], hx=cd["hx"], lz=cd["lz"], lx=cd["lx"])
+        for form, ftag in ((orc.FORM_LDPC_F64, "f64"), (orc.FORM_LDPC_F32, "f32")):
+            if opts["bp_method"] == "minimum_sum" and opts["schedule"] == "parallel" and ftag == "f32":
+                form, ftag = orc.FORM_COMPRESSED_F32, "f32c"
+            d = dict(opts, error_rate=p, form=form)
+            pl = get_codecap_pL(cobj, p, trials, orc.OracleBpOsdDecoder, d, basis=basis, seed=seed)
+            out.append(dict(code=code, p=p, trials=trials, seed=seed, basis=basis, opts=opts, form=ftag, pL=pl))
+            print("codecap:", code, p, basis, opts["bp_method"], opts["schedule"], ftag, pl)
+    json.dump(out, open(os.path.join(GOLD, "codecap.json"), "w"), indent=1)
+
+
 def gen_gf2():
     """G6: known answers from the reference's dense GF(2) algebra (gf2_util.py:20,51,146)."""
     import_reference()
@@ -320,5 +347,7 @@ if __name__ == "__main__":
         gen_gf2()
     if what in ("all", "loop"):
         gen_loop()
+    if what in ("all", "codecap"):
+        gen_codecap()
     left = [p for p, _, _ in os.walk(REF) if p.endswith("__pycache__")]
     assert not left, "bytecode was written under /root/reference: %r" % left
