@@ -22,6 +22,43 @@ __global__ void qd_gf2_spmv_kernel(SpmatDev A, const uint32_t *__restrict__ err,
     *o = (uint8_t)((accumulate ? (*o & 1u) : 0u) ^ p);
 }
 
+// The same product driven by the set bits of e: a correction has a few dozen faults, a row of L_k or U_k hundreds of
+// columns.  One wavefront per shot scans the packed error bits and XORs the row mask of every set column (columns beyond
+// A.ncols -- faults of the window that are not committed -- are ignored, as the row form ignores them).
+__global__ void __launch_bounds__(256) qd_gf2_colxor_kernel(SpmatDev A, const uint32_t *__restrict__ err, int64_t err_stride,
+                                                            int64_t B, uint8_t *out, int64_t out_stride, int accumulate)
+{
+    __shared__ uint32_t acc[4][16];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + wv;
+    if (lane < 16) acc[wv][lane] = 0u;
+    __syncthreads();
+    if (b < B) {
+        const uint32_t *e = err + b * err_stride;
+        const int nwords = (A.ncols + 31) >> 5;
+        for (int w = lane; w < nwords; w += 64) {
+            uint32_t bits = e[w];
+            if (w == nwords - 1 && (A.ncols & 31)) bits &= (1u << (A.ncols & 31)) - 1u;
+            while (bits) {
+                const int k = __ffs(bits) - 1;
+                bits &= bits - 1u;
+                const uint32_t *cm = A.colmask + (size_t)(32 * w + k) * A.mask_words;
+                for (int q = 0; q < A.mask_words; ++q) {
+                    const uint32_t mk = cm[q];
+                    if (mk) atomicXor(&acc[wv][q], mk);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (b < B)
+        for (int r = lane; r < A.nrows; r += 64) {
+            uint8_t *o = out + b * out_stride + r;
+            const uint32_t p = (acc[wv][r >> 5] >> (r & 31)) & 1u;
+            *o = (uint8_t)((accumulate ? (*o & 1u) : 0u) ^ p);
+        }
+}
+
 __global__ void qd_unpack_bits_kernel(const uint32_t *__restrict__ bits, int64_t stride_words, int nbits, int64_t B,
                                       uint8_t *out, int64_t out_stride)
 {
@@ -126,6 +163,11 @@ hipError_t qd_launch_spmv(const SpmatDev &A, const uint32_t *err, int64_t err_st
 {
     const int64_t total = B * A.nrows;
     if (total == 0) return hipSuccess;
+    if (A.colmask) {
+        hipLaunchKernelGGL(qd_gf2_colxor_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, s, A, err, err_stride, B, out,
+                           out_stride, accumulate);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(qd_gf2_spmv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, A, err, err_stride, B,
                        out, out_stride, accumulate);
     return hipGetLastError();

@@ -716,6 +716,15 @@ extern "C" int qd_spmat_create(int32_t nrows, int32_t ncols, const int32_t *row_
     int rc = s->mem.upload(rp, &s->d.row_ptr) | s->mem.upload(ci, &s->d.col_idx);
     if (rc) { s->mem.release(); delete s; return fail(QD_EHIP, "device allocation/upload failed"); }
     s->d.nrows = nrows; s->d.ncols = ncols; s->d.nnz = nnz;
+    s->d.colmask = nullptr; s->d.mask_words = 0;
+    if (nrows > 0 && nrows <= 512 && ncols > 0) {
+        const int mw = (nrows + 31) / 32;
+        std::vector<uint32_t> cm((size_t)ncols * mw, 0u);
+        for (int r = 0; r < nrows; ++r)
+            for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) cm[(size_t)col_idx[e] * mw + (r >> 5)] ^= 1u << (r & 31);
+        if (s->mem.upload(cm, &s->d.colmask)) { s->mem.release(); delete s; return fail(QD_EHIP, "device allocation/upload failed"); }
+        s->d.mask_words = mw;
+    }
     *out = s;
     return QD_OK;
 }

@@ -143,4 +143,6 @@ struct SpmatDev {
     int nrows, ncols, nnz;
     const uint32_t *row_ptr;
     const uint32_t *col_idx;
+    const uint32_t *colmask;    // [ncols][mask_words] the rows of each column as a bit mask (null when nrows > 512)
+    int mask_words;
 };
