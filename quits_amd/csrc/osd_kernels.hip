@@ -274,6 +274,9 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
 // and the first QD_OSD_KWR Q planes in registers; LDS holds a write-through mirror that other threads read when one of
 // those rows becomes the pivot row.  Q planes beyond the LDS budget spill to HBM (rare: > 64 * f_kw pivots).
 #define QD_OSD_TIER 1024
+#ifndef QD_OSD_TIER_FIRST
+#define QD_OSD_TIER_FIRST 256
+#endif
 #define QD_OSD_KWR 6
 #define QD_OSD_KPT 20     // monotone keys a thread keeps in registers while a tier is drawn (n <= 20 * T; else re-read)
 
@@ -314,7 +317,7 @@ struct OsdRegArgs {
     unsigned long long *dbg;
 };
 
-struct TierState { uint32_t lo_key, lo_idx; int sphase, exhausted; };
+struct TierState { uint32_t lo_key, lo_idx; int sphase, exhausted, limit; };   // limit: tier size wanted (<= QD_OSD_TIER)
 
 // Draws the next tier: the <= QD_OSD_TIER not yet consumed columns with the smallest (key, fault index), sorted, as fault
 // indices in order[0..cnt).  State: every column with (key, index) < (lo_key, lo_idx) has been consumed.
@@ -327,6 +330,7 @@ __device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *l
     const bool in_regs = n <= QD_OSD_KPT * T;
     uint32_t lo_key = ts.lo_key, lo_idx = ts.lo_idx;
     int sphase = ts.sphase;
+    const uint32_t lim = (uint32_t)ts.limit;
     bool exhausted = false;
     int cnt = 0;
     {
@@ -353,77 +357,71 @@ __device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *l
                 else { lo_key += 1; lo_idx = 0; }
             }
             if (!by_index) {
-                // largest t_hi with  #{lo_key <= key < t_hi} <= TIER   (key 0xFFFFFFFF is reserved for "no column").
-                // 4-ary search, three thresholds per barrier: first on the top 12 key bits (6 rounds); the low 20 bits
-                // are only resolved when that coarse cut would yield a thin tier.
-                auto count3 = [&](uint32_t h1, uint32_t h2, uint32_t h3, uint32_t &c1, uint32_t &c2, uint32_t &c3) {
-                    uint32_t x1 = 0, x2 = 0, x3 = 0;
-                    const uint32_t lo = lo_key;
+                // largest bin boundary t_hi with  #{lo_key <= key < t_hi} <= lim   (key 0xFFFFFFFF is reserved for "no
+                // column").  Radix selection: a histogram of the keys over 2048 bins of 2^21 (one LDS atomic per key), a scan
+                // for the bin where the running count passes `lim`; when the cut in front of that bin would leave a thin tier,
+                // the bin itself is resolved with 2048 bins of 2^10, then 1024 bins of 1.
+                uint32_t *hist = reinterpret_cast<uint32_t *>(sortbuf);            // 8 KB, free until the gather
+                uint32_t base = 0u, cur_lo = lo_key, cum = 0u;
+                uint64_t thi64 = 0;
+                for (int level = 0; level < 3; ++level) {
+                    const int shift = level == 0 ? 21 : (level == 1 ? 10 : 0);
+                    const int nb = level == 2 ? 1024 : 2048;
+                    for (int i = tid; i < nb; i += T) hist[i] = 0u;
+                    __syncthreads();
+                    auto tally = [&](uint32_t u) {
+                        if (u != 0xFFFFFFFFu && u >= cur_lo) {
+                            const uint32_t bin = (u - base) >> shift;              // cur_lo >= base
+                            if (bin < (uint32_t)nb) atomicAdd(&hist[bin], 1u);
+                        }
+                    };
                     if (in_regs) {
 #pragma unroll
-                        for (int i = 0; i < QD_OSD_KPT; ++i) {
-                            const uint32_t u = kreg[i];
-                            const uint32_t ge = (u >= lo) ? 1u : 0u;
-                            x1 += ge & ((u < h1) ? 1u : 0u); x2 += ge & ((u < h2) ? 1u : 0u); x3 += ge & ((u < h3) ? 1u : 0u);
-                        }
+                        for (int i = 0; i < QD_OSD_KPT; ++i) tally(kreg[i]);
                     } else {
-                        for (int b = tid; b < n; b += T) {
-                            const uint32_t u = qd_mono_key(llr[b]);
-                            const uint32_t ge = (u >= lo) ? 1u : 0u;
-                            x1 += ge & ((u < h1) ? 1u : 0u); x2 += ge & ((u < h2) ? 1u : 0u); x3 += ge & ((u < h3) ? 1u : 0u);
-                        }
+                        for (int b = tid; b < n; b += T) tally(qd_mono_key(llr[b]));
                     }
-                    x1 = qd_wave_add(x1); x2 = qd_wave_add(x2); x3 = qd_wave_add(x3);
-                    uint32_t *buf = sumbuf + sphase * 64;                      // per phase: 3 x 16 partials
-                    if ((tid & 63) == 0) { buf[tid >> 6] = x1; buf[16 + (tid >> 6)] = x2; buf[32 + (tid >> 6)] = x3; }
                     __syncthreads();
-                    c1 = c2 = c3 = 0;
-                    constexpr int NWv = (T / 64 + 3) / 4;
-                    const uint4 *p4 = reinterpret_cast<const uint4 *>(buf);
+                    // every thread owns nb / T consecutive bins; exclusive prefix over the workgroup
+                    const int per = nb / T;                                        // 2..8
+                    uint32_t h[8], mysum = 0u;
 #pragma unroll
-                    for (int w = 0; w < NWv; ++w) {
-                        const uint4 a1 = p4[w], a2 = p4[4 + w], a3 = p4[8 + w];
-                        c1 += a1.x + a1.y + a1.z + a1.w; c2 += a2.x + a2.y + a2.z + a2.w; c3 += a3.x + a3.y + a3.z + a3.w;
-                    }
+                    for (int q = 0; q < 8; ++q) { h[q] = (q < per) ? hist[tid * per + q] : 0u; mysum += h[q]; }
+                    uint32_t incl = mysum;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if ((tid & 63) >= d) incl += o; }
+                    uint32_t *buf = sumbuf + sphase * 64;
+                    if ((tid & 63) == 63) buf[tid >> 6] = incl;
+                    if (tid == 0) { buf[32] = 0xFFFFFFFFu; }                       // first overflowing bin (minimum over threads)
+                    __syncthreads();
+                    uint32_t before = cum;
+                    for (int w = 0; w < (tid >> 6); ++w) before += buf[w];
+                    uint32_t run = before + incl - mysum;                          // keys in [lo_key, first key of my first bin)
+                    int kk = -1;
+                    uint32_t run_at = 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q < per && kk < 0) { if (run + h[q] > lim) { kk = tid * per + q; run_at = run; } else run += h[q]; }
+                    if (kk >= 0) atomicMin(&buf[32], (uint32_t)kk);
+                    __syncthreads();
+                    const uint32_t kmin = buf[32];
+                    if (kk >= 0 && (uint32_t)kk == kmin) buf[33] = run_at;         // exactly one thread owns that bin
+                    if (kmin == 0xFFFFFFFFu && tid == T - 1) buf[33] = run;        // nothing overflows: everything fits
+                    __syncthreads();
+                    const uint32_t k = (kmin == 0xFFFFFFFFu) ? (uint32_t)nb : kmin;
+                    const uint32_t cnt_here = buf[33];
                     sphase ^= 1;
-                };
-                // search over v in [vlo, vhi] (units of `unit` keys) for the largest v with count(lo_key, v * unit) <= TIER
-                auto search = [&](uint64_t vlo, uint64_t vhi, int shift, uint32_t &cnt_at) -> uint64_t {
-                    uint64_t L = vlo, H = vhi;
-                    while (L < H) {
-                        const uint64_t span = H - L;
-                        uint64_t m1 = L + (span + 3) / 4, m2 = L + (span + 1) / 2, m3 = L + (3 * span + 3) / 4;
-                        if (m2 < m1) m2 = m1;
-                        if (m3 < m2) m3 = m2;
-                        auto thr = [&](uint64_t v) -> uint32_t { const uint64_t t = v << shift; return t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t; };
-                        uint32_t c1, c2, c3;
-                        count3(thr(m1), thr(m2), thr(m3), c1, c2, c3);
-                        if (c3 <= (uint32_t)QD_OSD_TIER) { L = m3; cnt_at = c3; }
-                        else if (c2 <= (uint32_t)QD_OSD_TIER) { L = m2; cnt_at = c2; H = m3 - 1; }
-                        else if (c1 <= (uint32_t)QD_OSD_TIER) { L = m1; cnt_at = c1; H = m2 - 1; }
-                        else H = m1 - 1;
-                    }
-                    return L;
-                };
-                uint32_t cntL = 0;
-                // coarse: thresholds that are multiples of 2^20, never below lo_key's own bin boundary above it
-                const uint64_t b_lo = ((uint64_t)lo_key + 0xFFFFFull) >> 20;        // first bin boundary >= lo_key
-                uint64_t Lb = search(b_lo > 0 ? b_lo - 1 : 0, 4096, 20, cntL);      // v = b_lo - 1 stands for "nothing" (threshold <= lo_key)
-                uint64_t Lfine;
-                if (Lb >= b_lo && cntL >= (uint32_t)(QD_OSD_TIER / 4)) Lfine = (Lb << 20) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (Lb << 20);
-                else {
-                    // resolve the low bits between the coarse cut and the next bin boundary
-                    const uint64_t f_lo = (Lb >= b_lo) ? ((Lb << 20) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (Lb << 20)) : (uint64_t)lo_key;
-                    uint64_t f_hi = (Lb + 1) << 20;
-                    if (f_hi > 0xFFFFFFFFull) f_hi = 0xFFFFFFFFull;
-                    if (Lb < b_lo) cntL = 0;
-                    Lfine = search(f_lo, f_hi, 0, cntL);
+                    thi64 = (uint64_t)base + ((uint64_t)k << shift);
+                    cnt = (int)cnt_here;
+                    if (k == (uint32_t)nb || cnt_here >= lim / 4u || level == 2) break;
+                    // descend into the overflowing bin
+                    base = (uint32_t)thi64; cum = cnt_here; cur_lo = max(cur_lo, base);
                 }
-                t_lo = lo_key; t_hi = (uint32_t)Lfine;
-                cnt = (int)cntL;
+                __syncthreads();                                                   // hist (= sortbuf) is reused by the gather
+                t_lo = lo_key; t_hi = thi64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thi64;
                 if (cnt == 0) {
                     if (t_hi == 0xFFFFFFFFu) exhausted = true;                 // nothing at or above lo_key
-                    else { lo_key = t_hi; lo_idx = 0; by_index = true; }       // more than TIER columns share the next key value
+                    else { lo_key = t_hi; lo_idx = 0; by_index = true; }       // more than `lim` columns share the next key value
                 } else lo_key = t_hi;
             }
             if (by_index) {
@@ -432,7 +430,7 @@ __device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *l
                 while (L < H) {
                     const uint64_t mid = (L + H + 1) >> 1;
                     const uint32_t c = count_ties(lo_key, lo_idx, (uint32_t)mid);
-                    if (c <= (uint32_t)QD_OSD_TIER) { L = mid; cntL = c; } else H = mid - 1;
+                    if (c <= lim) { L = mid; cntL = c; } else H = mid - 1;
                 }
                 i_lo = lo_idx; i_hi = (uint32_t)L;
                 cnt = (int)cntL;
@@ -443,6 +441,26 @@ __device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *l
             // gather (one LDS counter bump per wavefront) and sort the tier
             if (tid == 0) red[80] = 0u;
             __syncthreads();
+            if (in_regs && !by_index) {
+                // keys are in registers: count the takes, one workgroup scan for the write offsets (order inside the tier
+                // buffer is irrelevant, it is sorted next)
+                uint32_t mask = 0u;
+#pragma unroll
+                for (int i = 0; i < QD_OSD_KPT; ++i) mask |= (kreg[i] >= t_lo && kreg[i] < t_hi) ? (1u << i) : 0u;
+                const uint32_t mine = (uint32_t)__popc(mask);
+                uint32_t incl = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if ((tid & 63) >= d) incl += o; }
+                uint32_t *buf = sumbuf + sphase * 64;
+                if ((tid & 63) == 63) buf[tid >> 6] = incl;
+                __syncthreads();
+                uint32_t at = incl - mine;
+                for (int w = 0; w < (tid >> 6); ++w) at += buf[w];
+                sphase ^= 1;
+#pragma unroll
+                for (int i = 0; i < QD_OSD_KPT; ++i)
+                    if ((mask >> i) & 1u) sortbuf[at++] = ((uint64_t)kreg[i] << 32) | a.bit_orig[tid + i * T];
+            } else
             for (int i = 0; i * T < n; ++i) {
                 const int b = tid + i * T;
                 uint32_t u = 0xFFFFFFFFu, j = 0;
@@ -463,8 +481,23 @@ __device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *l
             while (P < cnt) P <<= 1;
             for (int i = cnt + tid; i < P; i += T) sortbuf[i] = ~0ull;
             __syncthreads();
-            qd_bitonic_u64<T>(sortbuf, P, tid);
-            for (int i = tid; i < cnt; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
+            if (cnt <= 256 && cnt <= T) {
+                // small tier: rank by counting (the keys are distinct), one pass of broadcast reads instead of 36 barrier stages
+                if ((tid & ~63) < cnt) {
+                    const uint64_t mine = tid < cnt ? sortbuf[tid] : ~0ull;
+                    const uint4 *sb4 = reinterpret_cast<const uint4 *>(sortbuf);
+                    int rank = 0;
+                    for (int i = 0; i < (cnt + 1) / 2; ++i) {                 // sortbuf[cnt] is padding (~0) when cnt is odd
+                        const uint4 v = sb4[i];
+                        const uint64_t k0 = (uint64_t)v.x | ((uint64_t)v.y << 32), k1 = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                        rank += (k0 < mine ? 1 : 0) + (k1 < mine ? 1 : 0);
+                    }
+                    if (tid < cnt) order[rank] = (uint16_t)(mine & 0xFFFFu);
+                }
+            } else {
+                qd_bitonic_u64<T>(sortbuf, P, tid);
+                for (int i = tid; i < cnt; i += T) order[i] = (uint16_t)(sortbuf[i] & 0xFFFFu);
+            }
             __syncthreads();
     }
     ts.lo_key = lo_key; ts.lo_idx = lo_idx; ts.sphase = sphase; ts.exhausted = 0;
@@ -722,7 +755,7 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
         const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
 #ifdef QD_OSD_TIMING
         unsigned long long *a_dbg = a.dbg;
-        unsigned long long acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         unsigned long long tick_ = wall_clock64();
 #endif
         // ---- elimination state: registers + LDS mirror
@@ -751,12 +784,15 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
         if (tid < 64) red[tid] = ((tid & 16) == 0) ? QD_NOKEY : 0u;      // per phase: 16 keys then 16 flags
         __syncthreads();
 
-        int npiv = 0, done = 0, phase = 0, sphase = 0, nnp = 0;
+        int npiv = 0, done = 0, phase = 0, sphase = 0, nnp = 0, ntier = 0;
+        QD_TICK(10)
         uint32_t lo_key = 0, lo_idx = 0;             // every column with (key, fault index) < (lo_key, lo_idx) has been consumed
         while (!done) {
             // =============== draw the next tier of the column order (kept out of line: its 20 key registers and unrolled
             // compares must not push the elimination state of this loop into scratch)
-            TierState ts{lo_key, lo_idx, sphase, 0};
+            // OSD-0 stops after ~100 columns at the usual operating points: a first tier of 256 costs a third of a full one
+            TierState ts{lo_key, lo_idx, sphase, 0, (!want_full && ntier == 0) ? QD_OSD_TIER_FIRST : QD_OSD_TIER};
+            ++ntier;
             const int cnt = qd_osd_draw_tier<T>(a, llr, sortbuf, order, red, sumbuf, ts);
             lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
             if (ts.exhausted) break;
@@ -944,7 +980,7 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
 #ifdef QD_OSD_TIMING
         if (tid == 0) {
             for (int i = 0; i < 8; ++i) atomicAdd(&a_dbg[i], acc_[i]);
-            atomicAdd(&a_dbg[8], 1ull); atomicAdd(&a_dbg[9], (unsigned long long)npiv);
+            atomicAdd(&a_dbg[8], 1ull); atomicAdd(&a_dbg[9], (unsigned long long)npiv); atomicAdd(&a_dbg[10], acc_[10]);
         }
 #endif
         __syncthreads();   // LDS is recycled by the next shot

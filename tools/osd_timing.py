@@ -12,7 +12,8 @@ d.decode(det); torch.cuda.synchronize(); d.debug_counters()
 d.set_profiling(True); d.decode(det); torch.cuda.synchronize()
 c = d.debug_counters(); pr = d.profile()
 names = ["tier(select+sort)", "batch-load", "pivots(rest)", "finish", "round: key+reduce", "round: barrier", "round: read partials+pivot row", "round: update"]
-tot = sum(c[:8]) or 1
+tot = (sum(c[:8]) + c[10]) or 1
+print("%-10s %6.1f %%   %8.0f ticks/shot" % ("shot init", 100.0 * c[10] / tot, c[10] / max(c[8], 1)))
 
 print("osd kernel ms", pr["osd_ms"], "shots", c[8], "mean pivots", c[9] / max(c[8], 1))
 for i, nme in enumerate(names):
