@@ -183,6 +183,8 @@ def main():
         "logical_error_rate": pl, "ler_sigma": float(np.sqrt(max(pl * (1 - pl), 1e-30) / n_shots)),
         "lfr_per_round": 1.0 - (1.0 - pl) ** (1.0 / R),
         "bp_converged_frac": conv_frac, "osd_frac": osd_frac, "mean_bp_iters": total_iters / max(1, st.numel()),
+        # early exit makes the work data-dependent -- shot-windows by BP iterations used (index = iterations)
+        "bp_iters_hist": torch.bincount(iters.clamp(max=args.max_iter), minlength=args.max_iter + 1).tolist(),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "qd_bp_edge_kernel" if general else "qd_bp_minsum_kernel", "avg_launch_ms": prof["bp_ms"] / max(1, prof["bp_launches"]),

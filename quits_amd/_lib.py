@@ -54,6 +54,13 @@ def load():
         raise RuntimeError(
             "quits_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 and this library links the system one by the same
+    # SONAME.  Whichever is loaded first serves both; loading this library first and torch afterwards leaves two runtimes, and
+    # the second one sees no device.  So torch (the owner of device memory and streams on this path) goes first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     L.qd_version.restype = C.c_int
