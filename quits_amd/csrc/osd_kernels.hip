@@ -814,6 +814,7 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                 if (tid == 0) red[64] = 0u;
                 if (tid < 64) S.bcols[tid] = (base + tid < cnt) ? (uint32_t)order[base + tid] : 0xFFFFFFFFu;
                 __syncthreads();
+                if constexpr (want_full) {
                 for (int x = tid; x < 64 * a.max_cdeg; x += T) {
                     const int c = x / a.max_cdeg, q = x - c * a.max_cdeg;
                     const uint32_t col = S.bcols[c];
@@ -844,6 +845,53 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                         if (np) S.tb[r] = x;
                     }
                     my_tb[i] = x;
+                }
+                } else {
+                // OSD-0 (early stop, ~100 pivots): Q rows are sparse, so the transform is applied row-wise -- row r of T is
+                // e_r plus e_{pivot row k} for every bit k of Q[r]:  x[r] = raw[r] ^ XOR_{k in Q[r]} raw[prow[k]].
+                for (int x = tid; x < 64 * a.max_cdeg; x += T) {
+                    const int c = x / a.max_cdeg, q = x - c * a.max_cdeg;
+                    const uint32_t col = S.bcols[c];
+                    if (col != 0xFFFFFFFFu) {
+                        const uint32_t e0 = a.csc_ptr[col], e1 = a.csc_ptr[col + 1];
+                        if (e0 + q < e1)
+                            atomicXor(reinterpret_cast<unsigned long long *>(&S.tb[a.csc_row[e0 + q]]), 1ull << c);
+                    }
+                }
+                __syncthreads();
+                const int nplanes = (npiv + 63) >> 6;
+#pragma unroll
+                for (int i = 0; i < RPT; ++i) {
+                    const int r = tid + i * T;
+                    uint64_t x = 0ull;
+                    if (r < m) {
+                        x = S.tb[r];
+#pragma unroll
+                        for (int w = 0; w < KWR; ++w)
+                            if (w < nplanes) {
+                                uint64_t q = my_q[i][w];
+                                while (q) {
+                                    const int k = w * 64 + __builtin_ctzll(q);
+                                    q &= q - 1ull;
+                                    x ^= S.tb[S.prow[k]];
+                                }
+                            }
+                        for (int w = KWR; w < nplanes; ++w) {
+                            uint64_t q = qd_q_load<true>(S, qglb, kw_lds, m_pad, w, r);
+                            while (q) {
+                                const int k = w * 64 + __builtin_ctzll(q);
+                                q &= q - 1ull;
+                                x ^= S.tb[S.prow[k]];
+                            }
+                        }
+                    }
+                    my_tb[i] = x;
+                }
+                if (npiv > 0) {
+                    __syncthreads();                       // every raw word has been read
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) { const int r = tid + i * T; if (r < m) S.tb[r] = my_tb[i]; }
+                }
                 }
                 QD_TICK(1)
                 int bpos = 0;                               // batch columns before bpos have been classified
