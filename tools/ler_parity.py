@@ -3,7 +3,7 @@
 syndromes: BASELINE's headline configuration, DEM-sampled with the Philox sampler that is bit-identical on CPU and GPU.
 
   python tools/ler_parity.py cpu  <shots> <out.json> [procs]     # here (no GPU): oracle, shot ranges over processes
-  python tools/ler_parity.py gpu  <shots> <out.json>             # on the GPU box
+  python tools/ler_parity.py gpu|gpu-edge <shots> <out.json>     # on the GPU box (compressed LDS kernel | per-edge kernel)
   python tools/ler_parity.py cmp  <cpu.json> <gpu.json>
 Chunks of 10000 shots, chunk c = global shots [c*10000, (c+1)*10000), seed 1; per-chunk failure counts are stored."""
 import json, os, sys, time
@@ -51,7 +51,7 @@ def main():
         from quits_amd.decoder.device import BatchDecoder, DemSampler, GF2Matrix, WindowGraph, count_mismatch
         H, L, pri = helpers.dem_matrices(NAME)
         smp, g = DemSampler(H, L, pri), WindowGraph(H, pri)
-        dec, Lm = BatchDecoder(g, max_iter=MAX_ITER, osd_method="osd_0"), GF2Matrix(L)
+        dec, Lm = BatchDecoder(g, max_iter=MAX_ITER, osd_method="osd_0", edge_messages=(mode == "gpu-edge")), GF2Matrix(L)
         fails, conv = [], []
         for c in range(nch):
             det, obs = smp.sample(CHUNK, seed=SEED, shot0=c * CHUNK)
@@ -59,7 +59,8 @@ def main():
             pred = torch.zeros((CHUNK, L.shape[0]), dtype=torch.uint8, device="cuda")
             Lm.xor_apply(bits, pred, accumulate=False)
             fails.append(int(count_mismatch(pred, obs).item())); conv.append(int(((status >> 16) & 1).sum().item()))
-        rec = {"decoder": "libquits_amd.so, float, compressed min-sum flooding max_iter=50 + OSD-0", "fails": fails,
+        rec = {"decoder": "libquits_amd.so, float, %s min-sum flooding max_iter=50 + OSD-0"
+                          % ("one message per edge (ldpc's update order)" if mode == "gpu-edge" else "compressed"), "fails": fails,
                "bp_converged": conv, "seconds": time.time() - t0}
     rec.update({"config": NAME, "chunk": CHUNK, "seed": SEED, "shots": nch * CHUNK})
     json.dump(rec, open(out, "w"))
