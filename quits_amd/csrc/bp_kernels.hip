@@ -29,9 +29,6 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
     return I == 0 ? v.x : (I == 1 ? v.y : (I == 2 ? v.z : v.w));
 }
 
-#ifndef QD_ABLATE
-#define QD_ABLATE 0        // timing experiments only (tools/ablate_bp.sh); any value but 0 breaks the results
-#endif
 #ifdef QD_BP_TIMING   // phase cycle counters of wavefront 0 (tools/bp_timing.py); slots: 0 check pass, 1 block-OR, 2 bit pass, 3 barrier, 4 prologue, 5 epilogue
 #define QD_BP_TICK(slot) { const unsigned long long now_ = clock64(); acc_[slot] += now_ - tick_; tick_ = now_; }
 #else
