@@ -162,7 +162,7 @@ def main():
         try:
             pm = json.load(open(pmc_path))
             key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
-            if key in pm:
+            if key in pm and not general and args.code == "bb144":
                 traffic, traffic_src = pm[key]["bp_bytes_per_launch"], pm[key]["source"]
         except (ValueError, KeyError):
             pass
