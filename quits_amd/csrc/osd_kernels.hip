@@ -730,31 +730,36 @@ __device__ __noinline__ void qd_osd_sweep(const OsdRegArgs &a, unsigned char *sm
 // ---- one batch of the OSD-0 elimination by a single wavefront ---------------------------------------------------------
 // A pivot only ever touches rows whose 64-column panel word is non-zero, and a batch of sparse columns leaves most rows
 // zero (64 x ~3.5 entries on ~1000 rows).  Those rows are compacted (in row order) into `list`; wavefront 0 keeps them in
-// registers -- QD_PANEL_SLOTS per lane: panel word, syndrome bit, pivot flag, Q planes 0..1 -- and runs the pivot loop on
+// registers -- QD_PANEL_SLOTS per lane: panel word, syndrome bit, pivot flag, the first Q planes -- and runs the pivot loop on
 // its own: no workgroup barrier, no LDS round trip per pivot (the pivot row is broadcast with v_readlane).  Same pivot
 // choice as the workgroup-wide loop (lowest column, then lowest row: list positions ascend with the row index), same
 // updates, so the results are identical.  Preconditions checked by the caller: nL <= 64 * QD_PANEL_SLOTS, every pivot of
-// the batch stays in Q planes 0..1 (npiv0 + 64 <= 128).  Returns the new pivot count; *done_out = syndrome explained.
+// the batch stays in Q planes 0..QD_PANEL_PLANES-1.  Returns the new pivot count; *done_out = syndrome explained.
 #define QD_PANEL_SLOTS 4
+#define QD_PANEL_PLANES 2   // (3 measured slower: late batches hold few pivots, the fixed cost of compaction + call exceeds a handful of barrier rounds)
 __device__ __noinline__ int qd_osd_panel_wave0(const OsdLds &S, const uint16_t *list, int nL, int npiv0, uint32_t outside_resid,
                                                int m_pad, int *done_out)
 {
     const int lane = threadIdx.x & 63;
     int row[QD_PANEL_SLOTS];
-    uint64_t tb[QD_PANEL_SLOTS], q0[QD_PANEL_SLOTS], q1[QD_PANEL_SLOTS];
+    uint64_t tb[QD_PANEL_SLOTS], q[QD_PANEL_SLOTS][QD_PANEL_PLANES];
     uint32_t spb = 0u, pivb = 0u, valid = 0u;
+    const int planes0 = (npiv0 + 63) >> 6;                            // planes that hold anything yet
 #pragma unroll
     for (int s = 0; s < QD_PANEL_SLOTS; ++s) {
         const int pos = s * 64 + lane;
-        row[s] = 0; tb[s] = 0ull; q0[s] = 0ull; q1[s] = 0ull;
+        row[s] = 0; tb[s] = 0ull;
+#pragma unroll
+        for (int w = 0; w < QD_PANEL_PLANES; ++w) q[s][w] = 0ull;
         if (pos < nL) {
             const int r = list[pos];
             row[s] = r; valid |= 1u << s;
             tb[s] = S.tb[r];
             spb |= (uint32_t)(S.sp[r] & 1u) << s;
             pivb |= (S.rowpiv[r] >= 0 ? 1u : 0u) << s;
-            q0[s] = S.q[r];
-            q1[s] = S.q[(size_t)m_pad + r];
+#pragma unroll
+            for (int w = 0; w < QD_PANEL_PLANES; ++w)
+                if (w < planes0) q[s][w] = S.q[(size_t)w * m_pad + r];
         }
     }
     int npiv = npiv0, done = 0;
@@ -773,19 +778,26 @@ __device__ __noinline__ int qd_osd_panel_wave0(const OsdLds &S, const uint16_t *
         if (key == QD_NOKEY) break;                                  // rest of the batch depends on earlier pivots
         const int c = (int)(key >> 16), pos = (int)(key & 0xFFFFu);
         const int ol = pos & 63, os = pos >> 6;                      // owner lane / slot: uniform
-        uint64_t tp = 0ull, qp0 = 0ull, qp1 = 0ull;
+        const int K = npiv, kw = K >> 6;
+        uint64_t tp = 0ull, qp[QD_PANEL_PLANES];
         int prow = 0;
-        const int K = npiv;
+#pragma unroll
+        for (int w = 0; w < QD_PANEL_PLANES; ++w) qp[w] = 0ull;
 #pragma unroll
         for (int s = 0; s < QD_PANEL_SLOTS; ++s)
             if (s == os) {
                 tp = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(tb[s] >> 32), ol) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)tb[s], ol);
-                qp0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(q0[s] >> 32), ol) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)q0[s], ol);
-                if (K >= 64) qp1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(q1[s] >> 32), ol) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)q1[s], ol);
+#pragma unroll
+                for (int w = 0; w < QD_PANEL_PLANES; ++w)
+                    if (w <= kw)
+                        qp[w] = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(q[s][w] >> 32), ol) << 32) |
+                                (uint32_t)__builtin_amdgcn_readlane((int)q[s][w], ol);
                 prow = __builtin_amdgcn_readlane(row[s], ol);
             }
         const uint32_t spp = ((uint32_t)__builtin_amdgcn_readlane((int)spb, ol) >> os) & 1u;
-        const uint64_t kb0 = K < 64 ? (1ull << K) : 0ull, kb1 = K >= 64 ? (1ull << (K - 64)) : 0ull;
+#pragma unroll
+        for (int w = 0; w < QD_PANEL_PLANES; ++w)
+            if (w == kw) qp[w] ^= 1ull << (K & 63);                  // the new pivot's own bit rides along
         if (lane == 0) { S.rowpiv[prow] = (int16_t)K; S.prow[K] = (uint16_t)prow; S.pcol[K] = S.bcols[c]; }
 #pragma unroll
         for (int s = 0; s < QD_PANEL_SLOTS; ++s) {
@@ -794,8 +806,9 @@ __device__ __noinline__ int qd_osd_panel_wave0(const OsdLds &S, const uint16_t *
             else if ((tb[s] >> c) & 1ull) {
                 tb[s] ^= tp;
                 spb ^= spp << s;
-                q0[s] ^= qp0 ^ kb0;
-                if (K >= 64) q1[s] ^= qp1 ^ kb1;
+#pragma unroll
+                for (int w = 0; w < QD_PANEL_PLANES; ++w)
+                    if (w <= kw) q[s][w] ^= qp[w];
             }
         }
         npiv = K + 1;
@@ -807,8 +820,9 @@ __device__ __noinline__ int qd_osd_panel_wave0(const OsdLds &S, const uint16_t *
         if ((valid >> s) & 1u) {
             const int r = row[s];
             S.sp[r] = (uint8_t)((spb >> s) & 1u);
-            S.q[r] = q0[s];
-            if (planes > 1) S.q[(size_t)m_pad + r] = q1[s];
+#pragma unroll
+            for (int w = 0; w < QD_PANEL_PLANES; ++w)
+                if (w < planes) S.q[(size_t)w * m_pad + r] = q[s][w];
         }
     *done_out = done;
     return npiv;
@@ -983,7 +997,7 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                 QD_TICK(1)
                 bool did_panel = false;
                 if constexpr (!want_full) {
-                    if (npiv + 64 <= 128 && kw_lds >= 2 && NW <= 8 && RPT <= 4) {
+                    if (npiv + 64 <= 64 * min(min(QD_PANEL_PLANES, KWR), kw_lds) && NW <= 8 && RPT <= 4) {
                         // ---- compact the rows with a non-zero panel word (row order), then one wavefront does the batch
                         uint16_t *list = reinterpret_cast<uint16_t *>(sortbuf);          // the tier buffer is idle between draws
                         uint32_t *buf = sumbuf + sphase * 64;                            // [i * 8 + wave] counts, [32 + wave] flags, [48..49] results
@@ -1035,8 +1049,9 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                                 if (r < m) {
                                     my_sp = (my_sp & ~(1u << i)) | ((uint32_t)(S.sp[r] & 1u) << i);
                                     if (S.rowpiv[r] >= 0) my_piv |= 1u << i;
-                                    my_q[i][0] = S.q[r];
-                                    if (KWR > 1) my_q[i][1] = S.q[(size_t)m_pad + r];
+#pragma unroll
+                                    for (int w = 0; w < QD_PANEL_PLANES; ++w)
+                                        if (w < ((npiv + 63) >> 6)) my_q[i][w] = S.q[(size_t)w * m_pad + r];
                                 }
                             }
                         }
