@@ -156,7 +156,7 @@ def main():
 
     # HBM bytes per BP launch from the PMC passes of tools/profile_bench.sh (rocprofv3 cannot run inside this process);
     # only quoted when the committed profile was taken on this exact workload.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, issue = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -164,6 +164,7 @@ def main():
             key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
             if key in pm and not general and args.code == "bb144":
                 traffic, traffic_src = pm[key]["bp_bytes_per_launch"], pm[key]["source"]
+                issue = pm[key].get("valu_issue")
         except (ValueError, KeyError):
             pass
 
@@ -195,7 +196,9 @@ def main():
                              ("algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the kernel "
                               "keeps this message state in LDS, so the figure is the traffic an HBM-resident formulation "
                               "would need, not bytes that cross HBM (see DESIGN.md section 5)"),
-                     "osd_kernel_ms_per_launch": prof["osd_ms"] / max(1, prof["osd_launches"])},
+                     "osd_kernel_ms_per_launch": prof["osd_ms"] / max(1, prof["osd_launches"]),
+                     # what actually bounds the LDS-resident kernel (from the committed SQ counter profile of this workload)
+                     "issue_bound": issue},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:
