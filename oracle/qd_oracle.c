@@ -430,7 +430,8 @@ int oq_bposd_decode(oq_graph *g, const oq_params *prm, const uint8_t *synd, uint
     if (conv < 0) { free(llr); return -1; }
     if (!conv && prm->osd_method != OQ_OSD_OFF) {
         if (prm->osd_method == OQ_OSD_0 || prm->osd_order == 0) oq_osd0(g, synd, llr, 1, err, st);
-        else osd_w_impl(g, synd, llr, prm->osd_method, prm->osd_order, prm->form == OQ_FORM_COMPRESSED_F32, err, NULL);
+        else osd_w_impl(g, synd, llr, prm->osd_method, prm->osd_order,
+                        prm->form == OQ_FORM_COMPRESSED_F32 || prm->form == OQ_FORM_LDPC_F32 /* integer costs, as the device */, err, NULL);
     }
     if (flags_out) { flags_out[0] = conv; flags_out[1] = iters; flags_out[2] = st[0]; flags_out[3] = st[2]; }
     free(llr);

@@ -386,3 +386,15 @@ def test_codecap_driver_on_device(gpu):
         assert pl == ent["pL"], ent
         seen += 1
     assert seen == 4
+
+
+def test_randomised_parity_sweep(gpu):
+    """Random sparse check matrices (4..2600 detectors, column weight 1..6), equal / log-uniform / discrete priors, sampled and
+    arbitrary syndromes, every bp_method x schedule x osd_method/order the device path offers: decisions, convergence flags,
+    iteration counts, OSD use, pivot counts and the inconsistent flag equal the oracle's (tools/stress_parity.py; 2000 further
+    cases were run once for profiles/r01_stress_parity.txt)."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_parity
+    ok, skipped = stress_parity.run(80, seed=20260929)
+    assert ok >= 70
