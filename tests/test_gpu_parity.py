@@ -398,3 +398,12 @@ def test_randomised_parity_sweep(gpu):
     import stress_parity
     ok, skipped = stress_parity.run(80, seed=20260929)
     assert ok >= 70
+
+
+def test_every_window_shape(gpu):
+    """All (W, F) with 1 <= F <= W <= R + 3 for the [[72,12,6]] circuit (including F = W and the whole-history branch
+    W > R + 2): the batched device driver and the oracle's restatement of the reference loop give identical predictions."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import stress_windows
+    assert stress_windows.run(24, opts=(("minimum_sum", "parallel", 10, "osd_0", 0),)) == 45
