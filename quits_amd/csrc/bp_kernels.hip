@@ -165,7 +165,8 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             const uint32_t meta = __float_as_uint(st.w);
             const uint32_t idx_old = llr_base + ((meta & 0xFFFFu) << 2);   // label = LDS offset of the argmin fault's posterior
             const uint32_t synd = meta >> 31;
-            const int degp = g.chk_degp_w[__builtin_amdgcn_readfirstlane(c) >> 6];     // scalar load; multiple of 4
+            const int dw = g.chk_degp_w[__builtin_amdgcn_readfirstlane(c) >> 6];       // scalar load
+            const int degp = dw & 0xFFFF, wmax = dw >> 16;                             // trip count (multiple of 4), largest degree in this wavefront
             bool us = (synd != 0u);
             uint32_t idx = llr_base + (0xFFFFu << 2);
             float a1 = FLT_MAX, a2 = FLT_MAX;
@@ -178,15 +179,26 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
                 const int kend = min(degp - k0, 32);                // multiple of 4
                 const ADJ4 *ap = adj4 + (size_t)(k0 >> 2) * m_pad + c;
                 ADJ4 nx = ap[0];
+                int kk = 0;
 #pragma unroll 1
-                for (int kk = 0; kk < kend; kk += 4) {
+                for (; kk + 4 < kend; kk += 4) {
                     const ADJ4 cur = nx;
-                    if (kk + 4 < kend) nx = ap[(size_t)((kk >> 2) + 1) * m_pad];   // next four fault offsets while these are processed
+                    nx = ap[(size_t)((kk >> 2) + 1) * m_pad];                       // next four fault offsets while these are processed
                     const int sb = kend - 1 - kk;
                     QD_CHECK_EDGE(qd_adj_get<0>(cur), sb)
                     QD_CHECK_EDGE(qd_adj_get<1>(cur), sb - 1)
                     QD_CHECK_EDGE(qd_adj_get<2>(cur), sb - 2)
                     QD_CHECK_EDGE(qd_adj_get<3>(cur), sb - 3)
+                }
+                {
+                    // last group: edges beyond the wavefront's largest degree are padding for every lane (posterior +inf:
+                    // never a minimum, never negative) -- only their zero sign bit is shifted in
+                    const ADJ4 cur = nx;
+                    const int real = wmax - (k0 + kk);                              // 1..4 (or more in a non-final word)
+                    QD_CHECK_EDGE(qd_adj_get<0>(cur), 3)
+                    if (real > 1) QD_CHECK_EDGE(qd_adj_get<1>(cur), 2) else neww <<= 1;
+                    if (real > 2) QD_CHECK_EDGE(qd_adj_get<2>(cur), 1) else neww <<= 1;
+                    if (real > 3) QD_CHECK_EDGE(qd_adj_get<3>(cur), 0) else neww <<= 1;
                 }
                 npar ^= neww;
                 if (k0 == 0) neg0 = neww;
@@ -228,16 +240,19 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             {
                 qd_u32x4 s0 = QD_BIT_LOAD(r0.y), s1 = QD_BIT_LOAD(r0.z), s2 = QD_BIT_LOAD(r0.w);
                 QD_BIT_WAIT3(s0, s1, s2);
-                QD_BIT_USE(r0.y, s0) QD_BIT_USE(r0.z, s1) QD_BIT_USE(r0.w, s2)
+                QD_BIT_USE(r0.y, s0) QD_BIT_USE(r0.z, s1)
+                if (b0 < g.bit_thr[2]) QD_BIT_USE(r0.w, s2)          // (a wavefront of weight-2 faults gathers the dummy but skips its arithmetic)
             }
             if (NCH > 1 && b0 < g.bit_thr[3]) {
                 qd_u32x4 s0 = QD_BIT_LOAD(r1.x), s1 = QD_BIT_LOAD(r1.y);
                 QD_BIT_WAIT2(s0, s1);
-                QD_BIT_USE(r1.x, s0) QD_BIT_USE(r1.y, s1)
+                QD_BIT_USE(r1.x, s0)
+                if (b0 < g.bit_thr[4]) QD_BIT_USE(r1.y, s1)
                 if (b0 < g.bit_thr[5]) {
                     qd_u32x4 s2 = QD_BIT_LOAD(r1.z), s3 = QD_BIT_LOAD(r1.w);
                     QD_BIT_WAIT2(s2, s3);
-                    QD_BIT_USE(r1.z, s2) QD_BIT_USE(r1.w, s3)
+                    QD_BIT_USE(r1.z, s2)
+                    if (b0 < g.bit_thr[6]) QD_BIT_USE(r1.w, s3)
                 }
             }
             if (NCH > 2 && b0 < g.bit_thr[7]) {

@@ -190,7 +190,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     for (int w0 = 0; w0 < m_pad; w0 += 64) {
         int mx = 0;
         for (int s = w0; s < w0 + 64; ++s) mx = std::max(mx, (int)chk_deg[s]);
-        chk_degp_w[w0 / 64] = (mx + 3) & ~3;
+        chk_degp_w[w0 / 64] = ((mx + 3) & ~3) | (mx << 16);      // trip count | exact maximum (edges beyond it are padding for every lane)
     }
     // check -> fault adjacency, ELL-transposed, as LDS byte offsets of the posteriors
     std::vector<uint16_t> chk_adj16;
@@ -221,7 +221,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         for (int q = 0; q < cdeg[j]; ++q) {
             const int cs = chk_slot_of[ri[cp[j] + q]];
             const int k = pos[cp[j] + q];
-            const int degp = chk_degp_w[cs / 64];
+            const int degp = chk_degp_w[cs / 64] & 0xFFFF;
             const int w = k >> 5, kend = std::min(degp - 32 * w, 32);
             const int sbit = kend - 1 - (k & 31);              // the check pass shifts signs in from bit 0 (v_alignbit)
             // mode 0/1: bit index into the 64-bit value {w : z} of the state (signs 32..46 sit in w's bits 16..30)

@@ -23,7 +23,8 @@ struct BpGraphDev {
     int adj32;                  // 1: chk_adj holds uint32 entries (windows with more than 16379 fault slots), else uint16
     const void *chk_adj;        // [max_rdeg_pad/4][m_pad][4] absolute LDS byte offset (off_llr + slot * 4) of the posterior of the k-th
                                 //                        fault of the check, k ascending = original column order; the dummy bit beyond the degree
-    const int32_t *chk_degp_w;  // [m_pad / 64]           trip count of a wavefront of check slots: its max degree rounded up to 4
+    const int32_t *chk_degp_w;  // [m_pad / 64]           low 16 bits: trip count of a wavefront of check slots (its max degree rounded up
+                                //                        to 4); high 16 bits: that max degree itself
     const uint32_t *chk_orig;   // [m_pad]                detector index of the check slot
     const uint32_t *bit_rec;    // [rec_words/4][n_pad][4] word 0 = prior LLR (float bits: log((1-p)/p) computed in double, rounded once);
                                 //                        word 1+q = (LDS byte offset of the check state) << 16 | where the check keeps this edge's
