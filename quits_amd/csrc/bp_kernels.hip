@@ -121,6 +121,8 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
     const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
     const int m_pad = g.m_pad, n_pad = g.n_pad;
     const uint4 *rec4 = reinterpret_cast<const uint4 *>(g.bit_rec);
+    const __amdgpu_buffer_rsrc_t rec_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)g.bit_rec, 0, g.rec_words * n_pad * 4, 0x00020000);
+    const int rec_voff = tid * 16;
     const ADJ4 *adj4 = reinterpret_cast<const ADJ4 *>(g.chk_adj);
     const uint32_t llr_base = (uint32_t)g.off_llr;
 
@@ -229,13 +231,13 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
             if (base + T > g.n && b >= g.n) break;
             const int b0 = base + wave0;                                // first slot of this wavefront
             const uint16_t mylabel = (uint16_t)b;                       // my slot; the check keeps its argmin slot in the low 16 bits of w
-            const uint4 *rp = rec4 + base;
-            const uint4 r0 = rp[tid];
-            uint4 r1, r2, r3, r4;
-            if (NCH > 1 && b0 < g.bit_thr[3]) r1 = rp[(size_t)n_pad + tid];
-            if (NCH > 2 && b0 < g.bit_thr[7]) r2 = rp[(size_t)2 * n_pad + tid];
-            if (NCH > 3 && b0 < g.bit_thr[11]) r3 = rp[(size_t)3 * n_pad + tid];
-            if (NCH > 4 && b0 < g.bit_thr[15]) r4 = rp[(size_t)4 * n_pad + tid];
+            // records through buffer loads: per-lane offset tid * 16 fixed, everything that moves is a scalar offset
+            const qd_u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_voff, base * 16, 0);
+            qd_u32x4 r1, r2, r3, r4;
+            if (NCH > 1 && b0 < g.bit_thr[3]) r1 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_voff, (n_pad + base) * 16, 0);
+            if (NCH > 2 && b0 < g.bit_thr[7]) r2 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_voff, (2 * n_pad + base) * 16, 0);
+            if (NCH > 3 && b0 < g.bit_thr[11]) r3 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_voff, (3 * n_pad + base) * 16, 0);
+            if (NCH > 4 && b0 < g.bit_thr[15]) r4 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_voff, (4 * n_pad + base) * 16, 0);
             float acc = __uint_as_float(r0.x);
             {
                 qd_u32x4 s0 = QD_BIT_LOAD(r0.y), s1 = QD_BIT_LOAD(r0.z), s2 = QD_BIT_LOAD(r0.w);
