@@ -14,7 +14,9 @@
 // its lanes wait until the slowest of the 64 shots is done.
 // Flooding schedule: rows (then columns) are independent, so G wavefronts of one workgroup share the same 64 shots and
 // take every G-th row / column, with a barrier between the passes -- G times the loads in flight for the same memory.
-// Serial schedule: G = 1 (one wavefront per 64 shots, no barriers).
+// Serial schedule: faults that share no check commute; they are grouped into dependency levels on the host and the G = 4
+// wavefronts of a workgroup take the faults of a level in parallel, one barrier per level (3.4 faults per level at the
+// headline: 2795 levels for 9504 faults).
 //
 // The adjacency arrays are separate __restrict__ kernel arguments on purpose: only then can the compiler prove that the
 // kernel's stores do not clobber them and read them with scalar loads (as members of the by-value graph struct they came
@@ -57,6 +59,7 @@ template <int METHOD, int SCHED, int G>
 __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                             const int32_t *__restrict__ cp, const int32_t *__restrict__ ri,
                                                             const int32_t *__restrict__ c2r, const float *__restrict__ llr0,
+                                                            const int32_t *__restrict__ lvl_ptr, const int32_t *__restrict__ lvl_bits,
                                                             DecodeArgs a, GenWs w, int64_t shot0, int nshots)
 {
     __shared__ uint32_t red[G][64];
@@ -242,8 +245,13 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
             }
             if (G > 1) __syncthreads();
         } else {
-            // ---- serial schedule: faults in natural order, each one refreshing its incoming messages first
-            for (int j = 0; active && j < g.n; ++j) {
+            // ---- serial schedule: each fault refreshes its incoming messages first.  Faults are taken level by level (see
+            // GenGraphDev): inside a level they share no check, so the G wavefronts take one each; across levels every pair of
+            // faults with a common check keeps its natural order -- the result is that of the natural-order sweep of bp.hpp.
+            for (int lev = 0; lev < g.nlev; ++lev) {
+            const int x1 = lvl_ptr[lev + 1];
+            for (int x = lvl_ptr[lev] + wv; active && x < x1; x += G) {
+                const int j = lvl_bits[x];
                 const int c0 = cp[j], c1 = cp[j + 1];
                 float lj = llr0[j];
                 float cv[QD_MAX_COL_DEG], pre[QD_MAX_COL_DEG];
@@ -320,6 +328,8 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         temp += cv[k];
                     }
             }
+            if (G > 1) __syncthreads();
+            }
         }
         // ---- stop when the hard decision reproduces the syndrome
         uint32_t bad = 0;
@@ -388,13 +398,14 @@ __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__rest
     }
 }
 
+#define QD_GEN_GS 4           // wavefronts per 64 shots in the serial schedule (faults of one dependency level in parallel)
 #define QD_GEN_G 8            // wavefronts per 64 shots in the flooding schedule
 
 template <int METHOD, int SCHED, int G>
 static hipError_t launch_k(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
 {
     hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G>), dim3((unsigned)((nshots + 63) / 64)), dim3(64 * G), 0, s, g, g.rp, g.ci,
-                       g.cp, g.ri, g.c2r, g.llr0, a, w, shot0, nshots);
+                       g.cp, g.ri, g.c2r, g.llr0, g.lvl_ptr, g.lvl_bits, a, w, shot0, nshots);
     return hipGetLastError();
 }
 
@@ -404,10 +415,10 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
     hipError_t e;
     if (bp_method == QD_BP_PRODUCT_SUM)
         e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL, 1>(g, a, w, shot0, nshots, s);
+                                             : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, a, w, shot0, nshots, s);
     else
         e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL, 1>(g, a, w, shot0, nshots, s);
+                                             : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, a, w, shot0, nshots, s);
     if (e != hipSuccess || !a.want_llr) return e;
     hipLaunchKernelGGL(qd_publish_llr_kernel, dim3((unsigned)((g.n + 63) / 64), (unsigned)((nshots + 63) / 64)), dim3(256), 0, s,
                        w.llr, w.slot, w.S, nshots, g.n, bg.n_pad, bg.bit_orig, a.llr_ws);

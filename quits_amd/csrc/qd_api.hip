@@ -242,6 +242,24 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         rcg |= g->mem.upload(rp_v, &gg.rp); rcg |= g->mem.upload(ci_v, &gg.ci);
         rcg |= g->mem.upload(cp, &gg.cp); rcg |= g->mem.upload(ri, &gg.ri);
         rcg |= g->mem.upload(c2r, &gg.c2r); rcg |= g->mem.upload(l0, &gg.llr0);
+        {
+            std::vector<int32_t> last(m, 0), lev(n, 0);
+            int nlev = 0;
+            for (int j = 0; j < n; ++j) {
+                int l = 0;
+                for (int e = cp[j]; e < cp[j + 1]; ++e) l = std::max(l, last[ri[e]]);
+                lev[j] = l;                                     // 0-based
+                for (int e = cp[j]; e < cp[j + 1]; ++e) last[ri[e]] = l + 1;
+                nlev = std::max(nlev, l + 1);
+            }
+            std::vector<int32_t> lp(nlev + 1, 0), lb(n);
+            for (int j = 0; j < n; ++j) lp[lev[j] + 1]++;
+            for (int l = 0; l < nlev; ++l) lp[l + 1] += lp[l];
+            std::vector<int32_t> fillp(lp.begin(), lp.end() - 1);
+            for (int j = 0; j < n; ++j) lb[fillp[lev[j]]++] = j;
+            gg.nlev = nlev;
+            rcg |= g->mem.upload(lp, &gg.lvl_ptr); rcg |= g->mem.upload(lb, &gg.lvl_bits);
+        }
         if (rcg) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while building the graph"); }
     }
 

@@ -46,6 +46,12 @@ struct GenGraphDev {
     const int32_t *cp, *ri;     // [n + 1], [nnz]   CSC, rows ascending in a column
     const int32_t *c2r;         // [nnz]            CSC edge -> CSR edge
     const float *llr0;          // [n]              (float)log((1 - p) / p), the log in double
+    // serial schedule: faults grouped into dependency levels.  Two faults that share no check commute, so natural order
+    // is reproduced by any order that keeps every pair of faults with a common check in index order; level(j) = 1 + the
+    // highest level among earlier faults on j's checks.  Faults of one level are mutually independent.
+    int nlev;
+    const int32_t *lvl_ptr;     // [nlev + 1]
+    const int32_t *lvl_bits;    // [n]              faults by level, ascending index inside a level
 };
 // ... and its per-chunk workspace, [index][shot] with S shots per row
 struct GenWs {
