@@ -312,6 +312,7 @@ struct OsdRegArgs {
     const float *llr_ws;
     const int32_t *fail_list, *fail_count;
     uint64_t *q_spill_fast;
+    uint64_t *mt_ws;
     uint32_t *err_bits;
     int32_t *status;
     unsigned long long *dbg;
@@ -724,6 +725,176 @@ __device__ __noinline__ void qd_osd_sweep(const OsdRegArgs &a, unsigned char *sm
     }
     if (tid == 0)
         for (int c = 0; c < wcols; ++c) atomicOr(&S.outw[wcol[c] >> 5], 1u << (wcol[c] & 31u));
+    __syncthreads();
+}
+
+// ---- the same sweep with Q transposed --------------------------------------------------------------------------------------
+// t_c = XOR over the pivoted rows r of column c of (e_j + column j of Q), j = pivot order of r, as a bit vector over pivot
+// order k.  With Q stored by row that is <= max_cdeg word reads per (candidate, pivot); transposed (MT[w][j] = bits k in
+// word w of column j) it is <= max_cdeg * W reads per CANDIDATE, and a whole candidate fits one thread: no workgroup
+// reduction per 32 candidates, only one for the winner.  The transpose goes through a global scratch (64 x 64 bit blocks,
+// one per wavefront at a time) and replaces Q in LDS.  Same costs, same tie rule, same result as qd_osd_sweep.
+#define QD_SWEEP_W 16            // pivot-order words a candidate vector may span (rank <= 1024)
+template <int T>
+__device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *smem, const float *llr, uint64_t *qglb, uint64_t *mt,
+                                            int npiv, int nnp)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    constexpr int NW = T / 64;
+    OsdLds S;
+    qd_osd_carve(smem, a.off, S);
+    const uint32_t *pivmask = reinterpret_cast<const uint32_t *>(smem + a.off_pivmask);
+    const uint32_t *npl = reinterpret_cast<const uint32_t *>(smem + a.off_npl);
+    unsigned char *scr = smem + a.off_sort;                                  // 8 KB, dead after the elimination
+    int32_t *swl = reinterpret_cast<int32_t *>(scr);                         // [<= 1024] signed pivot weights
+    SweepBest *bests = reinterpret_cast<SweepBest *>(scr + 4096);            // [NW]
+    uint64_t *twin = reinterpret_cast<uint64_t *>(scr + 4096 + 512);         // [QD_SWEEP_W] winner's vector
+    const int m_pad = a.m_pad, kw_lds = a.f_kw, n = a.n;
+    const int Wp = (npiv + 63) >> 6;
+    uint64_t *tv = mt + (size_t)a.mw * m_pad;                                // [64][QD_SWEEP_W] vectors of the first non-pivot columns
+
+    // ---- MT = transpose of (Q rows in pivot order), block by block
+    for (int bi = tid >> 6; bi < Wp * Wp; bi += NW) {
+        const int kb = bi / Wp, jb = bi - kb * Wp;
+        const int k = kb * 64 + lane;
+        uint64_t x = 0ull;
+        if (k < npiv) x = qd_q_load<true>(S, qglb, kw_lds, m_pad, jb, S.prow[k]);
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            const uint64_t msk = sh == 32 ? 0x00000000FFFFFFFFull : sh == 16 ? 0x0000FFFF0000FFFFull : sh == 8 ? 0x00FF00FF00FF00FFull
+                               : sh == 4 ? 0x0F0F0F0F0F0F0F0Full : sh == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+            const uint64_t other = ((uint64_t)(uint32_t)__shfl_xor((int)(x >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)x, sh);
+            x = (lane & sh) ? (((other >> sh) & msk) | (x & ~msk)) : ((x & msk) | ((other & msk) << sh));
+        }
+        mt[(size_t)kb * m_pad + jb * 64 + lane] = x;                          // word kb of column j = jb * 64 + lane
+    }
+    for (int k = tid; k < Wp * 64; k += T) {
+        int32_t v = 0;
+        if (k < npiv) {
+            const int32_t w = (int32_t)a.wfix[S.pcol[k]];
+            v = S.sp[S.prow[k]] ? -w : w;                  // a pivot that is on in the OSD-0 solution gets cheaper when flipped
+        }
+        swl[k] = v;
+    }
+    __syncthreads();                                       // every Q word has been read, every MT word written
+    // (word kw_lds, when the rank needs one more plane than Q had in LDS, goes where the batch words lived: S.tb is idle now)
+    for (int i = tid; i < Wp * m_pad; i += T) {
+        if (i < kw_lds * m_pad) S.q[i] = mt[i];
+        else S.tb[i - kw_lds * m_pad] = mt[i];
+    }
+    __syncthreads();
+
+    auto add_col = [&](uint32_t col, uint64_t t[QD_SWEEP_W]) {               // t ^= vector of fault `col`
+        const uint32_t e0 = a.csc_ptr[col], e1 = a.csc_ptr[col + 1];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const int j = S.rowpiv[a.csc_row[e]];
+            if (j < 0) continue;
+#pragma unroll
+            for (int w = 0; w < QD_SWEEP_W; ++w)
+                if (w < Wp) t[w] ^= (w < kw_lds ? S.q[(size_t)w * m_pad + j] : S.tb[j]) ^ ((w == (j >> 6)) ? (1ull << (j & 63)) : 0ull);
+        }
+    };
+    auto wsum = [&](const uint64_t t[QD_SWEEP_W]) -> long long {
+        long long s = 0;
+#pragma unroll
+        for (int w = 0; w < QD_SWEEP_W; ++w)
+            if (w < Wp) {
+                uint64_t x = t[w];
+                while (x) { s += (long long)swl[w * 64 + __builtin_ctzll(x)]; x &= x - 1ull; }
+            }
+        return s;
+    };
+
+    SweepBest best{0x7FFFFFFFFFFFFFFFll, 3u, ~0ull, 0ull};
+    if (a.osd_w == 1) {
+        // ---- singles: every non-pivot column
+        for (int col = tid; col < n; col += T) {
+            if ((pivmask[col >> 5] >> (col & 31)) & 1u) continue;
+            uint64_t t[QD_SWEEP_W];
+#pragma unroll
+            for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+            add_col((uint32_t)col, t);
+            const long long d = wsum(t) + (long long)a.wfix[col];
+            if (d <= best.delta) {
+                const unsigned long long tie = ((unsigned long long)qd_mono_key(llr[a.bit_slot_of[col]]) << 32) | (uint32_t)col;
+                if (qd_sweep_less(d, 1u, tie, best.delta, best.cls, best.tie)) best = SweepBest{d, 1u, tie, (unsigned long long)col};
+            }
+        }
+    }
+    // ---- patterns over the first lam non-pivot columns of the order: pairs (combination sweep) or all subsets (exhaustive)
+    const int lam = min(min(a.osd_order, nnp), 64);
+    if (lam >= (a.osd_w == 1 ? 2 : 1)) {
+        if (tid < lam) {
+            uint64_t t[QD_SWEEP_W];
+#pragma unroll
+            for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+            add_col(npl[tid], t);
+#pragma unroll
+            for (int w = 0; w < QD_SWEEP_W; ++w) tv[tid * QD_SWEEP_W + w] = t[w];
+        }
+        __syncthreads();
+        const unsigned long long npat = (a.osd_w == 1) ? (unsigned long long)lam * (lam - 1) / 2 : ((1ull << lam) - 1ull);
+        for (unsigned long long ic = tid; ic < npat; ic += T) {
+            unsigned long long pat;
+            if (a.osd_w == 2) pat = ic + 1ull;
+            else {
+                unsigned long long qq = ic; int x = 0;                 // pairs (x, y), x < y < lam, lexicographic
+                while (qq >= (unsigned long long)(lam - 1 - x)) { qq -= (unsigned long long)(lam - 1 - x); ++x; }
+                pat = (1ull << x) | (1ull << (x + 1 + (int)qq));
+            }
+            uint64_t t[QD_SWEEP_W];
+#pragma unroll
+            for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+            long long d = 0;
+            for (int b = 0; b < lam; ++b)
+                if ((pat >> b) & 1ull) {
+                    d += (long long)a.wfix[npl[b]];
+#pragma unroll
+                    for (int w = 0; w < QD_SWEEP_W; ++w)
+                        if (w < Wp) t[w] ^= tv[b * QD_SWEEP_W + w];
+                }
+            d += wsum(t);
+            if (qd_sweep_less(d, 2u, ic, best.delta, best.cls, best.tie)) best = SweepBest{d, 2u, ic, pat};
+        }
+    }
+    // ---- winner: wavefront minimum by shuffles, then the NW partials
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) {
+        SweepBest o;
+        o.delta = ((long long)__shfl_xor((int)(best.delta >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)best.delta, sh);
+        o.cls = (uint32_t)__shfl_xor((int)best.cls, sh);
+        o.tie = ((unsigned long long)(uint32_t)__shfl_xor((int)(best.tie >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)best.tie, sh);
+        o.what = ((unsigned long long)(uint32_t)__shfl_xor((int)(best.what >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)best.what, sh);
+        if (qd_sweep_less(o.delta, o.cls, o.tie, best.delta, best.cls, best.tie)) best = o;
+    }
+    if (lane == 0) bests[tid >> 6] = best;
+    __syncthreads();
+    SweepBest win = bests[0];
+    for (int q = 1; q < NW; ++q) { const SweepBest c = bests[q]; if (qd_sweep_less(c.delta, c.cls, c.tie, win.delta, win.cls, win.tie)) win = c; }
+    // ---- solution: pivots = OSD-0 coefficients xor the winner's vector; winner columns on (OSD-0 unless strictly cheaper)
+    for (int w = tid; w < a.out_words; w += T) S.outw[w] = 0u;
+    const bool take = win.delta < 0;
+    if (tid == 0) {
+        uint64_t t[QD_SWEEP_W];
+#pragma unroll
+        for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+        if (take) {
+            if (win.cls == 1u) add_col((uint32_t)win.what, t);
+            else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) add_col(npl[b], t);
+        }
+#pragma unroll
+        for (int w = 0; w < QD_SWEEP_W; ++w) twin[w] = t[w];
+    }
+    __syncthreads();
+    for (int k = tid; k < npiv; k += T)
+        if ((uint32_t)S.sp[S.prow[k]] ^ (uint32_t)((twin[k >> 6] >> (k & 63)) & 1ull)) {
+            const uint32_t j = S.pcol[k];
+            atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
+        }
+    if (tid == 0 && take) {
+        if (win.cls == 1u) atomicOr(&S.outw[(uint32_t)win.what >> 5], 1u << ((uint32_t)win.what & 31u));
+        else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) atomicOr(&S.outw[npl[b] >> 5], 1u << (npl[b] & 31u));
+    }
     __syncthreads();
 }
 
@@ -1176,7 +1347,16 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
             if (tid + i * T < m && !((my_piv >> i) & 1u)) resid |= (my_sp >> i) & 1u;
         const int inconsistent = qd_block_sum<T>(resid, sumbuf, sphase) != 0u;
         if constexpr (want_full) {
-            qd_osd_sweep<T>(a, smem, llr, qglb, npiv, nnp);     // writes the winning candidate (or OSD-0) into outw
+            // writes the winning candidate (or OSD-0) into outw; the transposed form needs every used pivot-order word in LDS
+            if (a.mt_ws && ((npiv + 63) >> 6) <= min(kw_lds + 1, QD_SWEEP_W))
+            {
+#ifdef QD_OSD_TIMING
+                if (tid == 0) atomicAdd(&a.dbg[11], 1ull);
+#endif
+                qd_osd_sweep_t<T>(a, smem, llr, qglb, a.mt_ws + (size_t)blockIdx.x * ((size_t)a.mw * m_pad + 1024), npiv, nnp);
+            }
+            else
+                qd_osd_sweep<T>(a, smem, llr, qglb, npiv, nnp);
         } else {
             // ---- OSD-0 solution: e[pivot column k] = transformed syndrome at pivot row k
             for (int k = tid; k < npiv; k += T)
@@ -1252,7 +1432,7 @@ static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const D
     r.off_sort = wl ? g.w_off_sort : g.f_off_sort; r.off_order = wl ? g.w_off_order : g.f_off_order;
     r.csc_ptr = g.csc_ptr; r.csc_row = g.csc_row; r.bit_orig = bg.bit_orig;
     r.det = a.det; r.upd = a.upd; r.det_stride = a.det_stride; r.det_offset = a.det_offset; r.upd_stride = a.upd_stride;
-    r.llr_ws = a.llr_ws; r.fail_list = a.fail_list; r.fail_count = a.fail_count; r.q_spill_fast = a.q_spill_fast;
+    r.llr_ws = a.llr_ws; r.fail_list = a.fail_list; r.fail_count = a.fail_count; r.q_spill_fast = a.q_spill_fast; r.mt_ws = a.mt_ws;
     r.err_bits = a.err_bits; r.status = a.status; r.dbg = a.dbg;
     r.off_pivmask = wl ? g.w_off_pivmask : g.f_off_pivmask; r.off_npl = wl ? g.w_off_npl : g.f_off_npl;
     r.osd_w = a.osd_w; r.osd_order = a.osd_order; r.rank = a.rank; r.wfix = g.wfix; r.bit_slot_of = bg.bit_slot_of;

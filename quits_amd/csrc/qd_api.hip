@@ -81,7 +81,7 @@ struct qd_decoder {
     float *llr_ws = nullptr;
     int32_t *fail_list = nullptr, *fail_count = nullptr;
     uint16_t *order_ws = nullptr;
-    uint64_t *q_spill = nullptr, *q_spill_fast = nullptr;
+    uint64_t *q_spill = nullptr, *q_spill_fast = nullptr, *mt_ws = nullptr;
     int32_t *hard_list = nullptr, *hard_list2 = nullptr;
     int osd_blocks_fast = 0;
     int osd_w = 0;
@@ -468,6 +468,8 @@ static void free_ws(qd_decoder *d)
     if (d->q_spill) (void)hipFree(d->q_spill);
     if (d->q_spill_fast) (void)hipFree(d->q_spill_fast);
     d->q_spill_fast = nullptr;
+    if (d->mt_ws) (void)hipFree(d->mt_ws);
+    d->mt_ws = nullptr;
     if (d->gws.b2c) (void)hipFree(d->gws.b2c);
     if (d->gws.c2b) (void)hipFree(d->gws.c2b);
     if (d->gws.th) (void)hipFree(d->gws.th);
@@ -518,6 +520,8 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
             HIP_TRY(hipMalloc((void **)&d->q_spill_fast, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * spill_fast * g->osd.m_pad));
+        if (d->osd_w && g->osd.w_lds_bytes > 0)
+            HIP_TRY(hipMalloc((void **)&d->mt_ws, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * ((size_t)g->osd.mw * g->osd.m_pad + 1024)));
         HIP_TRY(hipMalloc((void **)&d->hard_list, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->hard_list2, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->llr_ws, sizeof(float) * (size_t)max_batch * g->bp.n_pad));
@@ -601,7 +605,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
     a.max_iter = d->prm.max_iter; a.ms_scale = (float)d->prm.ms_scaling_factor; a.want_llr = osd ? 1 : 0;
     a.err_bits = d_err_bits; a.status = d_status;
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
-    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast;
+    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.mt_ws = d->mt_ws;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;   // bytes 16..143 of the counter block
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
@@ -671,7 +675,7 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     a.max_iter = d->prm.max_iter; a.ms_scale = (float)d->prm.ms_scaling_factor; a.want_llr = 1;
     a.err_bits = d_err_bits; a.status = d_status;
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
-    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast;
+    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.mt_ws = d->mt_ws;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;

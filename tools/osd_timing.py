@@ -6,8 +6,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, helpers
 from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
 H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
-det, obs = DemSampler(H, L, pri).sample(32768, seed=5)
-g = WindowGraph(H, pri); d = BatchDecoder(g, max_iter=50, osd_method="osd_0")
+det, obs = DemSampler(H, L, pri).sample(int(os.environ.get("SHOTS", "32768")), seed=5)
+g = WindowGraph(H, pri); d = BatchDecoder(g, max_iter=50, osd_method=os.environ.get("OSD_METHOD", "osd_0"), osd_order=int(os.environ.get("OSD_ORDER", "0")))
 d.decode(det); torch.cuda.synchronize(); d.debug_counters()
 d.set_profiling(True); d.decode(det); torch.cuda.synchronize()
 c = d.debug_counters(); pr = d.profile()
@@ -15,6 +15,7 @@ names = ["tier(select+sort)", "batch-load", "pivots(rest)", "finish", "round: ke
 tot = (sum(c[:8]) + c[10]) or 1
 print("%-10s %6.1f %%   %8.0f ticks/shot" % ("shot init", 100.0 * c[10] / tot, c[10] / max(c[8], 1)))
 
+print("transposed sweeps", c[11], "kernel info", g.info())
 print("osd kernel ms", pr["osd_ms"], "shots", c[8], "mean pivots", c[9] / max(c[8], 1))
 for i, nme in enumerate(names):
     print("%-10s %6.1f %%   %8.0f ticks/shot" % (nme, 100.0 * c[i] / tot, c[i] / max(c[8], 1)))
