@@ -274,6 +274,9 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
 // and the first QD_OSD_KWR Q planes in registers; LDS holds a write-through mirror that other threads read when one of
 // those rows becomes the pivot row.  Q planes beyond the LDS budget spill to HBM (rare: > 64 * f_kw pivots).
 #define QD_OSD_TIER 1024
+#ifndef QD_OSD_FULL_PAIRS
+#define QD_OSD_FULL_PAIRS 1   // full-rank elimination: loop over the (column, pivot) incidences (the row-wise form, Q rows being dense by then, measured 30 % slower)
+#endif
 #ifndef QD_OSD_TIER_FIRST
 #define QD_OSD_TIER_FIRST 256
 #endif
@@ -1086,7 +1089,7 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                 if (tid == 0) red[64] = 0u;
                 if (tid < 64) S.bcols[tid] = (base + tid < cnt) ? (uint32_t)order[base + tid] : 0xFFFFFFFFu;
                 __syncthreads();
-                if constexpr (want_full) {
+                if constexpr (want_full && QD_OSD_FULL_PAIRS) {
                 for (int x = tid; x < 64 * a.max_cdeg; x += T) {
                     const int c = x / a.max_cdeg, q = x - c * a.max_cdeg;
                     const uint32_t col = S.bcols[c];
