@@ -737,8 +737,8 @@ __device__ __noinline__ void qd_osd_sweep(const OsdRegArgs &a, unsigned char *sm
 // word w of column j) it is <= max_cdeg * W reads per CANDIDATE, and a whole candidate fits one thread: no workgroup
 // reduction per 32 candidates, only one for the winner.  The transpose goes through a global scratch (64 x 64 bit blocks,
 // one per wavefront at a time) and replaces Q in LDS.  Same costs, same tie rule, same result as qd_osd_sweep.
-#define QD_SWEEP_W 16            // pivot-order words a candidate vector may span (rank <= 1024)
-template <int T>
+// SW = pivot-order words a candidate vector may span: 16 (rank <= 1024) or 32 (rank <= 2048)
+template <int T, int SW>
 __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *smem, const float *llr, uint64_t *qglb, uint64_t *mt,
                                             int npiv, int nnp)
 {
@@ -749,12 +749,13 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     const uint32_t *pivmask = reinterpret_cast<const uint32_t *>(smem + a.off_pivmask);
     const uint32_t *npl = reinterpret_cast<const uint32_t *>(smem + a.off_npl);
     unsigned char *scr = smem + a.off_sort;                                  // 8 KB, dead after the elimination
-    int32_t *swl = reinterpret_cast<int32_t *>(scr);                         // [<= 1024] signed pivot weights
-    SweepBest *bests = reinterpret_cast<SweepBest *>(scr + 4096);            // [NW]
-    uint64_t *twin = reinterpret_cast<uint64_t *>(scr + 4096 + 512);         // [QD_SWEEP_W] winner's vector
+    int32_t *swl = reinterpret_cast<int32_t *>(scr);                         // [<= 2048] signed pivot weights
+    unsigned char *scr2 = smem + a.off_order;                                // 2 KB, the tier order: dead as well
+    SweepBest *bests = reinterpret_cast<SweepBest *>(scr2);                  // [NW]
+    uint64_t *twin = reinterpret_cast<uint64_t *>(scr2 + 1024);              // [SW] winner's vector
     const int m_pad = a.m_pad, kw_lds = a.f_kw, n = a.n;
     const int Wp = (npiv + 63) >> 6;
-    uint64_t *tv = mt + (size_t)a.mw * m_pad;                                // [64][QD_SWEEP_W] vectors of the first non-pivot columns
+    uint64_t *tv = mt + (size_t)a.mw * m_pad;                                // [64][SW] vectors of the first non-pivot columns
 
     // ---- MT = transpose of (Q rows in pivot order), block by block
     for (int bi = tid >> 6; bi < Wp * Wp; bi += NW) {
@@ -781,26 +782,33 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     }
     __syncthreads();                                       // every Q word has been read, every MT word written
     // (word kw_lds, when the rank needs one more plane than Q had in LDS, goes where the batch words lived: S.tb is idle now)
-    for (int i = tid; i < Wp * m_pad; i += T) {
+    // words beyond that stay in the scratch (L2)
+    for (int i = tid; i < min(Wp, kw_lds + 1) * m_pad; i += T) {
         if (i < kw_lds * m_pad) S.q[i] = mt[i];
         else S.tb[i - kw_lds * m_pad] = mt[i];
     }
     __syncthreads();
 
-    auto add_col = [&](uint32_t col, uint64_t t[QD_SWEEP_W]) {               // t ^= vector of fault `col`
+    auto add_col = [&](uint32_t col, uint64_t t[SW]) {               // t ^= vector of fault `col`
         const uint32_t e0 = a.csc_ptr[col], e1 = a.csc_ptr[col + 1];
         for (uint32_t e = e0; e < e1; ++e) {
             const int j = S.rowpiv[a.csc_row[e]];
             if (j < 0) continue;
 #pragma unroll
-            for (int w = 0; w < QD_SWEEP_W; ++w)
-                if (w < Wp) t[w] ^= (w < kw_lds ? S.q[(size_t)w * m_pad + j] : S.tb[j]) ^ ((w == (j >> 6)) ? (1ull << (j & 63)) : 0ull);
+            for (int w = 0; w < SW; ++w)
+                if (w < Wp) {                                               // (uniform branches: no speculative loads)
+                    uint64_t v;
+                    if (w < kw_lds) v = S.q[(size_t)w * m_pad + j];
+                    else if (w == kw_lds) v = S.tb[j];
+                    else v = mt[(size_t)w * m_pad + j];
+                    t[w] ^= v ^ ((w == (j >> 6)) ? (1ull << (j & 63)) : 0ull);
+                }
         }
     };
-    auto wsum = [&](const uint64_t t[QD_SWEEP_W]) -> long long {
+    auto wsum = [&](const uint64_t t[SW]) -> long long {
         long long s = 0;
 #pragma unroll
-        for (int w = 0; w < QD_SWEEP_W; ++w)
+        for (int w = 0; w < SW; ++w)
             if (w < Wp) {
                 uint64_t x = t[w];
                 while (x) { s += (long long)swl[w * 64 + __builtin_ctzll(x)]; x &= x - 1ull; }
@@ -813,9 +821,9 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
         // ---- singles: every non-pivot column
         for (int col = tid; col < n; col += T) {
             if ((pivmask[col >> 5] >> (col & 31)) & 1u) continue;
-            uint64_t t[QD_SWEEP_W];
+            uint64_t t[SW];
 #pragma unroll
-            for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+            for (int w = 0; w < SW; ++w) t[w] = 0ull;
             add_col((uint32_t)col, t);
             const long long d = wsum(t) + (long long)a.wfix[col];
             if (d <= best.delta) {
@@ -828,12 +836,12 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     const int lam = min(min(a.osd_order, nnp), 64);
     if (lam >= (a.osd_w == 1 ? 2 : 1)) {
         if (tid < lam) {
-            uint64_t t[QD_SWEEP_W];
+            uint64_t t[SW];
 #pragma unroll
-            for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+            for (int w = 0; w < SW; ++w) t[w] = 0ull;
             add_col(npl[tid], t);
 #pragma unroll
-            for (int w = 0; w < QD_SWEEP_W; ++w) tv[tid * QD_SWEEP_W + w] = t[w];
+            for (int w = 0; w < SW; ++w) tv[tid * SW + w] = t[w];
         }
         __syncthreads();
         const unsigned long long npat = (a.osd_w == 1) ? (unsigned long long)lam * (lam - 1) / 2 : ((1ull << lam) - 1ull);
@@ -845,16 +853,16 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
                 while (qq >= (unsigned long long)(lam - 1 - x)) { qq -= (unsigned long long)(lam - 1 - x); ++x; }
                 pat = (1ull << x) | (1ull << (x + 1 + (int)qq));
             }
-            uint64_t t[QD_SWEEP_W];
+            uint64_t t[SW];
 #pragma unroll
-            for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+            for (int w = 0; w < SW; ++w) t[w] = 0ull;
             long long d = 0;
             for (int b = 0; b < lam; ++b)
                 if ((pat >> b) & 1ull) {
                     d += (long long)a.wfix[npl[b]];
 #pragma unroll
-                    for (int w = 0; w < QD_SWEEP_W; ++w)
-                        if (w < Wp) t[w] ^= tv[b * QD_SWEEP_W + w];
+                    for (int w = 0; w < SW; ++w)
+                        if (w < Wp) t[w] ^= tv[b * SW + w];
                 }
             d += wsum(t);
             if (qd_sweep_less(d, 2u, ic, best.delta, best.cls, best.tie)) best = SweepBest{d, 2u, ic, pat};
@@ -878,15 +886,15 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     for (int w = tid; w < a.out_words; w += T) S.outw[w] = 0u;
     const bool take = win.delta < 0;
     if (tid == 0) {
-        uint64_t t[QD_SWEEP_W];
+        uint64_t t[SW];
 #pragma unroll
-        for (int w = 0; w < QD_SWEEP_W; ++w) t[w] = 0ull;
+        for (int w = 0; w < SW; ++w) t[w] = 0ull;
         if (take) {
             if (win.cls == 1u) add_col((uint32_t)win.what, t);
             else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) add_col(npl[b], t);
         }
 #pragma unroll
-        for (int w = 0; w < QD_SWEEP_W; ++w) twin[w] = t[w];
+        for (int w = 0; w < SW; ++w) twin[w] = t[w];
     }
     __syncthreads();
     for (int k = tid; k < npiv; k += T)
@@ -899,6 +907,15 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
         else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) atomicOr(&S.outw[npl[b] >> 5], 1u << (npl[b] & 31u));
     }
     __syncthreads();
+}
+
+// one call site in the kernel (two would change its register allocation: the pivot rounds measured 40 % slower)
+template <int T>
+__device__ __noinline__ void qd_osd_sweep_pick(const OsdRegArgs &a, unsigned char *smem, const float *llr, uint64_t *qglb, uint64_t *mt,
+                                               int npiv, int nnp)
+{
+    if (npiv <= 1024) qd_osd_sweep_t<T, 16>(a, smem, llr, qglb, mt, npiv, nnp);
+    else qd_osd_sweep_t<T, 32>(a, smem, llr, qglb, mt, npiv, nnp);
 }
 
 // ---- one batch of the OSD-0 elimination by a single wavefront ---------------------------------------------------------
@@ -1351,12 +1368,12 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
         const int inconsistent = qd_block_sum<T>(resid, sumbuf, sphase) != 0u;
         if constexpr (want_full) {
             // writes the winning candidate (or OSD-0) into outw; the transposed form needs every used pivot-order word in LDS
-            if (a.mt_ws && ((npiv + 63) >> 6) <= min(kw_lds + 1, QD_SWEEP_W))
+            if (a.mt_ws && ((npiv + 63) >> 6) <= 32)
             {
 #ifdef QD_OSD_TIMING
                 if (tid == 0) atomicAdd(&a.dbg[11], 1ull);
 #endif
-                qd_osd_sweep_t<T>(a, smem, llr, qglb, a.mt_ws + (size_t)blockIdx.x * ((size_t)a.mw * m_pad + 1024), npiv, nnp);
+                qd_osd_sweep_pick<T>(a, smem, llr, qglb, a.mt_ws + (size_t)blockIdx.x * ((size_t)a.mw * m_pad + 64 * 32), npiv, nnp);
             }
             else
                 qd_osd_sweep<T>(a, smem, llr, qglb, npiv, nnp);

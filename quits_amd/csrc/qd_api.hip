@@ -521,7 +521,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
             HIP_TRY(hipMalloc((void **)&d->q_spill_fast, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * spill_fast * g->osd.m_pad));
         if (d->osd_w && g->osd.w_lds_bytes > 0)
-            HIP_TRY(hipMalloc((void **)&d->mt_ws, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * ((size_t)g->osd.mw * g->osd.m_pad + 1024)));
+            HIP_TRY(hipMalloc((void **)&d->mt_ws, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * ((size_t)g->osd.mw * g->osd.m_pad + 64 * 32)));   // + 64 candidate vectors of QD_SWEEP_W words
         HIP_TRY(hipMalloc((void **)&d->hard_list, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->hard_list2, sizeof(int32_t) * (size_t)max_batch));
         HIP_TRY(hipMalloc((void **)&d->llr_ws, sizeof(float) * (size_t)max_batch * g->bp.n_pad));

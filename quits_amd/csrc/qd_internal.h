@@ -98,7 +98,7 @@ struct DecodeArgs {
     uint16_t *order_ws;         // [blocks][n]   sorted column order (full OSD kernel)
     uint64_t *q_spill;          // [blocks][(mw - kw_lds)][m_pad]
     uint64_t *q_spill_fast;     // [blocks_fast][(mw - f_kw)][m_pad]   register kernel
-    uint64_t *mt_ws;            // [blocks_fast][mw * m_pad + 1024]    higher-order OSD: transposed Q + candidate vectors
+    uint64_t *mt_ws;            // [blocks_fast][mw * m_pad + 2048]    higher-order OSD: transposed Q + candidate vectors
     int32_t *hard_list;         // [cap]         fail-list slots the first fast OSD pass could not finish
     int32_t *hard_list2;        // [cap]         ... and the second
     int32_t *hard_count;        // [2]

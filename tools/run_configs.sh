@@ -13,6 +13,8 @@ for p in 0.001 0.002 0.004 0.005 0.006; do $B --p $p --shots 65536 --no-cpu 2>/d
 $B --code qlp1020 --window 3 1 --shots 8192 --no-cpu 2>/dev/null
 $B --code qlp1020 --window 3 1 --shots 8192 --p-override 0.001 --no-cpu 2>/dev/null
 $B --code qlp1020 --window 3 1 --shots 8192 --p-override 0.0005 --no-cpu 2>/dev/null
+$B --code qlp1020 --window 3 1 --shots 4096 --p-override 0.001 --osd-method osd_cs --osd-order 1 --no-cpu 2>/dev/null     # configs[4]: OSD-CS leg
+$B --osd-method osd_cs --osd-order 1 --shots 32768 --cpu-shots 100 2>/dev/null                                            # headline code with OSD-CS(1)
 # the general (one message per edge) BP kernel at the headline code: the reference wrapper's other bp_method / schedule options
 $B --bp-method product_sum --schedule serial --max-iter 10 --cpu-shots 100 2>/dev/null
 $B --bp-method product_sum --schedule parallel --cpu-shots 100 2>/dev/null
