@@ -1122,21 +1122,37 @@ __global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
                 }
                 __syncthreads();
                 const int np = (int)red[64];
+                {
+                    // incidences eight at a time: the pair words first, then the 8 x RPT independent Q loads, then the bits
+                    // (one pair -> one dependent Q load per step left the loop waiting on LDS latency)
+                    uint64_t xr[RPT];
 #pragma unroll
-                for (int i = 0; i < RPT; ++i) {
-                    const int r = tid + i * T;
-                    uint64_t x = 0ull;
-                    if (r < m) {
-                        x = S.tb[r];
-                        for (int pi = 0; pi < np; ++pi) {
-                            const uint32_t pr = S.pairs[pi];
-                            const int k = (int)(pr >> 8);
-                            const uint64_t qw = qd_q_load<true>(S, qglb, kw_lds, m_pad, k >> 6, r);
-                            x ^= ((qw >> (k & 63)) & 1ull) << (pr & 63u);
-                        }
-                        if (np) S.tb[r] = x;
+                    for (int i = 0; i < RPT; ++i) { const int r = tid + i * T; xr[i] = r < m ? S.tb[r] : 0ull; }
+                    for (int p0 = 0; p0 < np; p0 += 8) {
+                        uint32_t pr[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) pr[q] = (p0 + q < np) ? S.pairs[p0 + q] : 0xFFFFFFFFu;
+                        uint64_t qw[RPT][8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int i = 0; i < RPT; ++i) {
+                                const int r = tid + i * T;
+                                qw[i][q] = 0ull;
+                                if (pr[q] != 0xFFFFFFFFu && r < m) qw[i][q] = qd_q_load<true>(S, qglb, kw_lds, m_pad, (int)(pr[q] >> 14), r);
+                            }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+#pragma unroll
+                            for (int i = 0; i < RPT; ++i)
+                                if (pr[q] != 0xFFFFFFFFu) xr[i] ^= ((qw[i][q] >> ((pr[q] >> 8) & 63u)) & 1ull) << (pr[q] & 63u);
                     }
-                    my_tb[i] = x;
+#pragma unroll
+                    for (int i = 0; i < RPT; ++i) {
+                        const int r = tid + i * T;
+                        if (np && r < m) S.tb[r] = xr[i];
+                        my_tb[i] = xr[i];
+                    }
                 }
                 } else {
                 // OSD-0 (early stop, ~100 pivots): Q rows are sparse, so the transform is applied row-wise -- row r of T is
