@@ -1020,7 +1020,7 @@ __device__ __noinline__ int qd_osd_panel_wave0(const OsdLds &S, const uint16_t *
 }
 
 template <int T, int RPT, bool WFULL>
-__global__ void __launch_bounds__(T, T / 128) qd_osd0_reg_kernel(OsdRegArgs a)
+__global__ void __launch_bounds__(T, (WFULL ? T / 256 : T / 128)) qd_osd0_reg_kernel(OsdRegArgs a)   // full-rank instantiation: one workgroup per CU, so twice the registers
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
