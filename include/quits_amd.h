@@ -87,6 +87,10 @@ void qd_decoder_destroy(qd_decoder *d);
 /* Pre-size the device workspace for batches of up to max_batch shots (otherwise grown on demand, which
  * synchronises). */
 int qd_decoder_reserve(qd_decoder *d, int64_t max_batch);
+/* Cap the message workspace of the one-message-per-edge BP kernel (bytes; default 48 GB or QD_GENERAL_WS_GB).  Larger
+ * batches are decoded in equal chunks that fit.  A sliding-window plan holds one decoder per window: the host divides
+ * the budget among them.  No reference counterpart (memory management). */
+int qd_decoder_set_workspace_limit(qd_decoder *d, int64_t bytes);
 
 /* ---- decode: replaces the per-shot `decoder.decode(syndrome)` calls (sliding_window.py:85,95,171,182) for a
  *      whole batch of shots, including the syndrome preparation in front of them (:168-169,179-180):

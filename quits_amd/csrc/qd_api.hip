@@ -86,6 +86,7 @@ struct qd_decoder {
     int osd_blocks_fast = 0;
     int osd_w = 0;
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
+    int64_t gen_ws_limit = 0;   // bytes; 0 = default
     GenWs gws{};
     int profiling = 0;
     struct Span { int kind; hipEvent_t t0, t1; };   // kind 0 = BP kernel, 1 = OSD kernel(s)
@@ -540,6 +541,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         // the same for 8 K or 64 K shots and chunks should be as large as memory allows -- and of equal size.
         double budget_gb = 48.0;
         if (const char *ev = std::getenv("QD_GENERAL_WS_GB")) budget_gb = std::max(0.001, std::atof(ev));
+        if (d->gen_ws_limit > 0) budget_gb = (double)d->gen_ws_limit / 1073741824.0;
         int64_t S = (int64_t)(budget_gb * 1073741824.0 / (double)per_shot) & ~(int64_t)255;
         S = std::max<int64_t>(256, S);
         const int64_t nchunks = (max_batch + S - 1) / S;
@@ -554,6 +556,18 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         HIP_TRY(hipMalloc((void **)&w.slot, sizeof(int32_t) * (size_t)S));
     }
     d->cap = max_batch;
+    return QD_OK;
+}
+
+extern "C" int qd_decoder_set_workspace_limit(qd_decoder *d, int64_t bytes)
+{
+    if (!d || bytes <= 0) return fail(QD_EINVAL, "bad workspace limit");
+    d->gen_ws_limit = bytes;
+    if (d->general && d->cap > 0) {          // takes effect at the next reserve: drop what is there
+        HIP_TRY(hipSetDevice(d->g->device));
+        HIP_TRY(hipDeviceSynchronize());
+        free_ws(d);
+    }
     return QD_OK;
 }
 

@@ -84,6 +84,10 @@ class BatchDecoder:
         self._L = L
         self.params = prm
 
+    def set_workspace_limit(self, nbytes: int):
+        """Cap the HBM message workspace of the one-message-per-edge BP kernel (product_sum / serial); no effect on the LDS kernel."""
+        _lib.check(self._L.qd_decoder_set_workspace_limit(self._h, int(nbytes)))
+
     def reserve(self, max_batch: int):
         _lib.check(self._L.qd_decoder_reserve(self._h, int(max_batch)))
 

@@ -102,6 +102,14 @@ class DeviceWindowPlan:
                 Uk = csr_matrix((Uk.data, Uk.indices, Uk.indptr), shape=(Uk.shape[0], graph.n))
                 U = GF2Matrix(Uk)
             self.windows.append({"dec": dec, "graph": graph, "L": GF2Matrix(Lk), "U": U, "row0": int(row0[k])})
+        # the per-edge BP kernel (product_sum / serial) keeps its messages in HBM, one workspace per decoder: split a fixed
+        # budget among the windows' decoders instead of letting each claim the single-decoder default
+        decs = self.decoders()
+        if len(decs) > 1:
+            import os
+            budget = float(os.environ.get("QD_GENERAL_WS_GB", "96")) * (1 << 30)
+            for d in decs:
+                d.set_workspace_limit(max(1 << 28, int(budget / len(decs))))
 
     def decoders(self):
         out = []
