@@ -101,8 +101,8 @@ __device__ __forceinline__ qd_u32x4 qd_lds_gather16(uint32_t lds_addr)
 //       (sign of check->bit message k = syndrome ^ parity of all incoming signs ^ incoming sign k),
 //   w = slot of the argmin fault (bits 0..15) | (sign mode 1: sign bits of edges 32..46) << 16 | syndrome bit << 31.
 // Sign mode 2 (checks wider than 44): edges 32.. keep their sign words in `csgn_hi`.
-template <int T, int NCH, int SM, typename ADJ4>
-__global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraphDev g, DecodeArgs a)
+template <int T, int NCH, int SM, typename ADJ4, int MW>
+__global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, DecodeArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;   // LDS address of smem[0]
@@ -306,14 +306,23 @@ __global__ void __launch_bounds__(T, QD_BP_MINWAVES) qd_bp_minsum_kernel(BpGraph
 }
 
 // ---- launch wrappers -------------------------------------------------------------------------------------------------
-template <int T, int NCH, int SM, typename ADJ4>
-static hipError_t launch_bp_k(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
+template <int T, int NCH, int SM, typename ADJ4, int MW>
+static hipError_t launch_bp_m(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
 {
-    auto k = qd_bp_minsum_kernel<T, NCH, SM, ADJ4>;
+    auto k = qd_bp_minsum_kernel<T, NCH, SM, ADJ4, MW>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, g.lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(T), g.lds_bytes, s, g, a);
     return hipGetLastError();
+}
+
+// A window whose LDS footprint leaves room for one 1024-thread workgroup per CU (4 wavefronts per SIMD) gets the
+// instantiation that may use 128 registers instead of 64 (QLP-1020 windows: 38.0 -> 33.3 ms per launch).
+template <int T, int NCH, int SM, typename ADJ4>
+static hipError_t launch_bp_k(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
+{
+    if (T == 1024 && 2 * g.lds_bytes > QD_LDS_BYTES) return launch_bp_m<T, NCH, SM, ADJ4, (T == 1024 ? 4 : QD_BP_MINWAVES)>(g, a, B, s);
+    return launch_bp_m<T, NCH, SM, ADJ4, QD_BP_MINWAVES>(g, a, B, s);
 }
 
 template <int T, int NCH>
