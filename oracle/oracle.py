@@ -45,6 +45,10 @@ def lib():
         L.oq_graph_create.restype = C.c_void_p
         L.oq_graph_create.argtypes = [C.c_int, C.c_int, i32p, i32p, f64p]
         L.oq_graph_destroy.argtypes = [C.c_void_p]
+        L.oq_graph_quantize_llr.argtypes = [C.c_void_p, C.c_int]
+        L.oq_graph_quantize_llr.restype = None
+        L.oq_max_abs_llr.argtypes = [C.c_int]
+        L.oq_max_abs_llr.restype = C.c_double
         L.oq_bp_decode.argtypes = [C.c_void_p, C.POINTER(Params), u8p, u8p, f64p, C.POINTER(C.c_int)]
         L.oq_osd_column_order.argtypes = [C.c_int, f64p, i32p]
         L.oq_gf2_rank.argtypes = [C.c_void_p]
@@ -107,6 +111,11 @@ class Graph:
     def rank(self) -> int:
         return lib().oq_gf2_rank(self._h)
 
+    def quantize_llr(self, frac_bits: int):
+        """Round the channel LLRs to multiples of 2**-frac_bits (negative: back to the exact doubles)."""
+        lib().oq_graph_quantize_llr(self._h, int(frac_bits))
+        return self
+
     def bp(self, syndrome, params: Params):
         s = np.ascontiguousarray(np.asarray(syndrome) % 2, dtype=np.uint8)
         dec = np.zeros(self.n, np.uint8)
@@ -146,6 +155,10 @@ class Graph:
         if rc:
             raise ValueError("oracle decode failed (unsupported parameter combination)")
         return err, flags
+
+
+def max_abs_llr(reset=False) -> float:
+    return float(lib().oq_max_abs_llr(int(bool(reset))))
 
 
 def column_order(llr):

@@ -65,7 +65,14 @@ typedef struct {
     double *prior;
     double *llr0;            /* log((1-p)/p) in double; cast to float by the f32 forms */
     int rank;                /* -1 until computed */
+    int llr_frac_bits;       /* -1: llr0 exact; k >= 0: llr0 rounded to the nearest multiple of 2^-k (oq_graph_quantize_llr) */
 } oq_graph;
+
+/* largest |posterior LLR| any BP call of this process has produced since the last reset (tools/ler_forms.py uses it to
+ * show how far the exact-arithmetic range of the quantised forms is from being exhausted) */
+static double g_max_abs_llr = 0.0;
+double oq_max_abs_llr(int reset) { double v = g_max_abs_llr; if (reset) g_max_abs_llr = 0.0; return v; }
+#define OQ_TRACK_LLR(x) do { double ax_ = fabs((double)(x)); if (ax_ > g_max_abs_llr) g_max_abs_llr = ax_; } while (0)
 
 /* the shared float functions, exposed so that tests can compare them with libm in double */
 void oq_math_f32(int kind, const float *x, float *y, int64_t count)
@@ -78,7 +85,7 @@ oq_graph *oq_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *c
 {
     oq_graph *g = (oq_graph *)calloc(1, sizeof(oq_graph));
     int nnz = row_ptr[m];
-    g->m = m; g->n = n; g->nnz = nnz; g->rank = -1;
+    g->m = m; g->n = n; g->nnz = nnz; g->rank = -1; g->llr_frac_bits = -1;
     g->rp = (int *)malloc(sizeof(int) * (size_t)(m + 1));
     g->ci = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
     g->cp = (int *)calloc((size_t)(n + 1), sizeof(int));
@@ -107,6 +114,22 @@ oq_graph *oq_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *c
         g->llr0[j] = log((1.0 - priors[j]) / priors[j]);
     }
     return g;
+}
+
+/* Channel LLRs on a binary grid.  frac_bits = k >= 0 replaces llr0[j] = log((1-p_j)/p_j) by the nearest multiple of
+ * 2^-k (ties to even); k < 0 restores the exact doubles.  Min-sum BP with ms_scaling_factor = 1 only ever adds,
+ * subtracts, negates and compares such values, so while every intermediate stays below 2^(24-k) in magnitude the float
+ * forms -- and below 2^(53-k) the double forms -- perform EXACT arithmetic: all four forms (ldpc's prefix sums or
+ * "total minus own", float or double) then return identical bits.  That is the arithmetic of the headline HIP kernel
+ * (qd_graph_create does the same rounding); what separates it from ldpc is therefore this one rounding of the inputs. */
+void oq_graph_quantize_llr(oq_graph *g, int frac_bits)
+{
+    g->llr_frac_bits = frac_bits;
+    for (int j = 0; j < g->n; j++) {
+        double l = log((1.0 - g->prior[j]) / g->prior[j]);
+        if (frac_bits >= 0) l = ldexp(nearbyint(ldexp(l, frac_bits)), -frac_bits);
+        g->llr0[j] = l;
+    }
 }
 
 void oq_graph_destroy(oq_graph *g)

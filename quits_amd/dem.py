@@ -214,12 +214,16 @@ class Circuit(str):
 
 
 def as_dem(circuit) -> DetectorErrorModel:
-    """Accept a stim.Circuit (if Stim is installed), circuit text, a Circuit or a DEM-like object."""
-    if hasattr(circuit, "flattened") and hasattr(circuit, "num_detectors") and not isinstance(circuit, str):
-        return circuit
+    """Accept a stim.Circuit (if Stim is installed), circuit text, a Circuit or a DEM-like object.
+
+    A circuit is recognised by its `detector_error_model` method and asked for the DEM exactly as the reference does
+    (`decoder/base.py:151`: `circuit.detector_error_model(decompose_errors=False)`); this has to be tested FIRST because a
+    real stim.Circuit also carries `flattened()` and `num_detectors`.  Only an object without that method is taken for
+    an already-built DEM (stim.DetectorErrorModel or the duck type `detector_error_model_to_matrix` reads)."""
     if isinstance(circuit, str):
-        return Circuit(circuit).detector_error_model() if not isinstance(circuit, Circuit) \
-            else circuit.detector_error_model()
+        return (circuit if isinstance(circuit, Circuit) else Circuit(circuit)).detector_error_model()
     if hasattr(circuit, "detector_error_model"):
         return circuit.detector_error_model(decompose_errors=False)
+    if hasattr(circuit, "flattened") and hasattr(circuit, "num_detectors"):
+        return circuit
     raise TypeError("circuit must be a stim.Circuit, circuit text, quits_amd.dem.Circuit or a DEM")

@@ -19,6 +19,7 @@ _GATES = {"R", "RX", "H", "CX", "M", "MX", "MR"}
 _NOISE = {"X_ERROR", "Z_ERROR", "DEPOLARIZE1", "DEPOLARIZE2"}
 _ANNOT = {"DETECTOR", "OBSERVABLE_INCLUDE"}
 _IGNORED = {"TICK", "QUBIT_COORDS", "SHIFT_COORDS"}
+_COORD_ARGS = {"DETECTOR", "QUBIT_COORDS", "SHIFT_COORDS"}     # parenthesised arguments are coordinates: ignored
 _UNSUPPORTED = {"PAULI_CHANNEL_1", "PAULI_CHANNEL_2", "Y_ERROR", "CORRELATED_ERROR", "E",
                 "ELSE_CORRELATED_ERROR", "MPP", "MY", "RY", "MRX", "MRY", "CZ", "CY", "SWAP",
                 "S", "S_DAG", "SQRT_X", "X", "Y", "Z", "CNOT", "ZCX"}
@@ -49,6 +50,9 @@ def _parse_line(line: str):
         name, _, tail = line.partition("(")
         argtxt, _, rest = tail.partition(")")
         name = name.strip()
+        if name.upper() in _COORD_ARGS:
+            # DETECTOR(x, y, t) / QUBIT_COORDS(x, y) / SHIFT_COORDS(...): coordinates carry no decoding information
+            return name.upper(), 0.0, rest.split()
         if "," in argtxt:
             raise NotImplementedError(
                 f"{name} with a multi-parameter channel is not supported (reference emits it only for "
@@ -104,6 +108,11 @@ def flatten(text: str) -> Tuple[List[Op], int, int, int]:
                     qs = tuple(int(t) for t in toks)
                 except ValueError as exc:
                     raise CircuitSyntaxError(f"bad qubit target in {ln!r}") from exc
+                if name in ("M", "MX", "MR") and arg != 0.0:
+                    # Stim's measurement-flip noise M(p): the reference models measurement errors with X_ERROR / Z_ERROR
+                    # before the measurement instead (circuit.py:201-246); dropping the argument would silently empty the DEM
+                    raise NotImplementedError(f"{name}({arg:g}): noisy-measurement arguments are outside the QUITS dialect "
+                                              "handled here (the reference emits X_ERROR/Z_ERROR before M/MX/MR)")
                 if name in ("CX", "DEPOLARIZE2") and len(qs) % 2:
                     raise CircuitSyntaxError(f"{name} needs an even number of targets")
                 ops.append(Op(name, arg, qs))

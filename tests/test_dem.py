@@ -182,3 +182,41 @@ def test_rate_substitution_reproduces_the_reference_circuit():
     base = "bb144_custom_r12_p0.003"
     for p in (0.001, 0.002, 0.004, 0.005, 0.006):
         assert helpers.circuit_text_at_p(base, 0.003, p) == helpers.circuit_text("bb144_custom_r12_p%g" % p)
+
+
+def test_as_dem_routes_a_stim_like_circuit_through_detector_error_model():
+    """a real stim.Circuit has flattened() AND num_detectors, so it must not be mistaken for a DEM --
+    the reference's call (`decoder/base.py:151`) is circuit.detector_error_model(decompose_errors=False)."""
+    from quits_amd.dem import as_dem
+    text = helpers.circuit_text("bb72_custom_r6_p0.003")
+    real = Circuit(text).detector_error_model()
+    calls = []
+
+    class FakeStimCircuit:                      # the attributes of stim.Circuit that fooled round 1's test order
+        num_detectors = 288
+        num_observables = 12
+
+        def flattened(self):
+            raise AssertionError("a circuit's flattened() is a circuit, not a DEM: must not be used")
+
+        def detector_error_model(self, decompose_errors=True, **kw):
+            calls.append(decompose_errors)
+            return real
+
+    assert as_dem(FakeStimCircuit()) is real and calls == [False]
+    assert as_dem(real) is real                                # an actual DEM passes through
+    assert as_dem(text).num_errors == real.num_errors          # plain text
+    with pytest.raises(TypeError):
+        as_dem(42)
+
+
+def test_coordinates_are_ignored_and_noisy_measurements_rejected():
+    """DETECTOR(x, y, t) / QUBIT_COORDS are valid Stim and carry no decoding information; M(p) is valid
+    Stim measurement noise the QUITS emitter never produces -- refusing it beats silently dropping the noise."""
+    plain = circuit_to_dem("R 0\nX_ERROR(0.125) 0\nM 0\nDETECTOR rec[-1]\n")
+    coords = circuit_to_dem("QUBIT_COORDS(1, 2) 0\nR 0\nX_ERROR(0.125) 0\nM 0\nDETECTOR(1, 2, 0) rec[-1]\nSHIFT_COORDS(0, 0, 1)\n")
+    assert coords.errors == plain.errors == [(0.125, (0,), ())]
+    for op in ("M(0.01) 0", "MX(0.01) 0", "MR(0.01) 0"):
+        with pytest.raises(NotImplementedError):
+            flatten("R 0\n%s\nDETECTOR rec[-1]\n" % op)
+    flatten("R 0\nM(0) 0\n")                                   # a zero argument is harmless
