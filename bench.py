@@ -139,7 +139,7 @@ def main():
         for k in prof:
             prof[k] += pr[k]
     st = torch.cat([t for (_, t) in stats])
-    iters = (st & 0xFFFF).to(torch.int64)
+    iters = (st & 0x3FFF).to(torch.int64)
     total_iters = int(iters.sum().item())
     conv_frac = float(((st >> 16) & 1).float().mean().item())
     osd_frac = float(((st >> 17) & 1).float().mean().item())
@@ -150,7 +150,7 @@ def main():
         b_iter[id(w["dec"])] = (4 * info["nnz"] + 2 * info["n"]) * 4
     algo_bytes = 0
     for (k, s_t) in stats:
-        algo_bytes += int((s_t & 0xFFFF).to(torch.int64).sum().item()) * b_iter[id(plan.windows[k]["dec"])]
+        algo_bytes += int((s_t & 0x3FFF).to(torch.int64).sum().item()) * b_iter[id(plan.windows[k]["dec"])]
     bp_s = prof["bp_ms"] / 1e3
     achieved = (algo_bytes / bp_s / 1e9) if bp_s > 0 else 0.0
 

@@ -40,7 +40,9 @@ extern "C" {
 #define QD_OSD_CS 3
 
 /* status word written per shot by qd_decode_batch */
-#define QD_STATUS_ITER_MASK 0xFFFF      /* BP iterations used                                         */
+#define QD_STATUS_ITER_MASK 0x3FFF      /* BP iterations used (max_iter is capped at 16383)           */
+#define QD_STATUS_COARSE_GRID (1 << 14) /* flooding min-sum: decoded on the coarse LLR grid (see qd_decoder_info)          */
+#define QD_STATUS_INEXACT (1 << 15)     /* ... and even there the exactness bound tripped: float rounding may have occurred */
 #define QD_STATUS_CONVERGED (1 << 16)   /* BP reproduced the syndrome                                 */
 #define QD_STATUS_OSD (1 << 17)         /* OSD post-processing produced the output                    */
 #define QD_STATUS_INCONSISTENT (1 << 18)/* OSD: syndrome outside the column space of the window matrix */
@@ -51,8 +53,11 @@ typedef struct qd_decoder qd_decoder;   /* graph + parameters + device workspace
 typedef struct qd_spmat qd_spmat;       /* sparse GF(2) matrix on the device (L_k, U_k, H for sampling) */
 
 /* qd_params.reserved: run flooding min-sum in the one-message-per-edge kernel too (ldpc's own update order, prefix sums
- * instead of "total minus own"; differs from the compressed kernel only in float rounding).  Validation aid. */
+ * instead of "total minus own").  On the LLR grid both kernels compute exactly and agree bit for bit.  Validation aid. */
 #define QD_FLAG_EDGE_MESSAGES 1
+/* qd_params.reserved: keep the channel LLRs as (float)log((1-p)/p) instead of putting them on a binary grid (round-1
+ * arithmetic: float rounding in every sum).  Validation aid; see qd_decoder_info. */
+#define QD_FLAG_RAW_LLR 2
 
 /* Keyword arguments the reference hands to BpOsdDecoder (decoder/bposd.py:38-49,74-83). */
 typedef struct qd_params {
@@ -84,6 +89,16 @@ int qd_graph_info(const qd_graph *g, int32_t *info);
 /* ---- decoder: replaces BpOsdDecoder.__init__'s parameter half. */
 int qd_decoder_create(const qd_graph *g, const qd_params *params, qd_decoder **out);
 void qd_decoder_destroy(qd_decoder *d);
+/* Arithmetic of this decoder.  info[0] = k: the channel LLRs log((1-p)/p) (computed in double, as ldpc does) are rounded to
+ * the nearest multiple of 2^-k before BP starts; -1 = not rounded (product-sum, ms_scaling_factor != 1, QD_FLAG_RAW_LLR).
+ * Flooding min-sum with ms_scaling_factor = 1 only adds, subtracts, negates and compares messages, so on such a grid
+ * single-precision arithmetic is EXACT while magnitudes stay below 2^(24-k): the kernels then return, bit for bit, what
+ * ldpc's double-precision BpDecoder returns for those LLRs, in any summation order.  The LDS kernel proves this per shot
+ * (bound S < 2^(23-k), bp_kernels.hip); a shot whose bound trips is decoded again on the coarser grid info[1]
+ * (QD_STATUS_COARSE_GRID), and flagged QD_STATUS_INEXACT if that trips too.  k = 23 - ceil(log2(8 * max|llr| * max_iter))
+ * clamped to [2, 20]; info[1] = max(k - 4, 0).  info[2] = 1 if BP runs in the one-message-per-edge kernel.  info[3] = 0.
+ * No reference counterpart (ldpc computes in double). */
+int qd_decoder_info(const qd_decoder *d, int32_t *info);
 /* Pre-size the device workspace for batches of up to max_batch shots (otherwise grown on demand, which
  * synchronises). */
 int qd_decoder_reserve(qd_decoder *d, int64_t max_batch);

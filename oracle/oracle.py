@@ -49,6 +49,10 @@ def lib():
         L.oq_graph_quantize_llr.restype = None
         L.oq_max_abs_llr.argtypes = [C.c_int]
         L.oq_max_abs_llr.restype = C.c_double
+        L.oq_graph_set_coarse_grid.argtypes = [C.c_void_p, C.c_int]
+        L.oq_graph_set_coarse_grid.restype = None
+        L.oq_grid_bits_rule.argtypes = [C.c_double, C.c_int, C.POINTER(C.c_int)]
+        L.oq_bposd_decode_batch2.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_int64, u8p, i32p, i32p]
         L.oq_bp_decode.argtypes = [C.c_void_p, C.POINTER(Params), u8p, u8p, f64p, C.POINTER(C.c_int)]
         L.oq_osd_column_order.argtypes = [C.c_int, f64p, i32p]
         L.oq_gf2_rank.argtypes = [C.c_void_p]
@@ -111,10 +115,18 @@ class Graph:
     def rank(self) -> int:
         return lib().oq_gf2_rank(self._h)
 
-    def quantize_llr(self, frac_bits: int):
-        """Round the channel LLRs to multiples of 2**-frac_bits (negative: back to the exact doubles)."""
+    def quantize_llr(self, frac_bits: int, coarse_bits: int = -1):
+        """Round the channel LLRs to multiples of 2**-frac_bits (negative: back to the exact doubles).  With coarse_bits >= 0
+        a shot whose exactness bound trips on the fine grid is decoded again on the coarse one, as the device does."""
         lib().oq_graph_quantize_llr(self._h, int(frac_bits))
+        lib().oq_graph_set_coarse_grid(self._h, int(coarse_bits))
+        self.grid = (int(frac_bits), int(coarse_bits))
         return self
+
+    def device_grid(self, max_iter: int):
+        """Put the LLRs on the grid libquits_amd.so picks for this graph and max_iter (flooding min-sum, ms_scaling 1)."""
+        k, kc = grid_bits(self.priors, max_iter if max_iter > 0 else self.n)
+        return self.quantize_llr(k, kc)
 
     def bp(self, syndrome, params: Params):
         s = np.ascontiguousarray(np.asarray(syndrome) % 2, dtype=np.uint8)
@@ -146,15 +158,37 @@ class Graph:
                        OSD_METHOD[osd_method], int(osd_order), err)
         return err
 
-    def decode_batch(self, syndromes, params: Params):
+    def decode_batch(self, syndromes, params: Params, return_grid=False):
         S = np.ascontiguousarray(np.asarray(syndromes) % 2, dtype=np.uint8)
         S = S.reshape(-1, self.m)
         err = np.zeros((S.shape[0], self.n), np.uint8)
         flags = np.zeros((S.shape[0], 4), np.int32)
-        rc = lib().oq_bposd_decode_batch(self._h, C.byref(params), S, S.shape[0], err, flags)
+        grid = np.zeros((S.shape[0], 2), np.int32)
+        rc = lib().oq_bposd_decode_batch2(self._h, C.byref(params), S, S.shape[0], err, flags, grid)
         if rc:
             raise ValueError("oracle decode failed (unsupported parameter combination)")
-        return err, flags
+        return (err, flags, grid) if return_grid else (err, flags)
+
+
+def grid_bits(priors, max_iter: int):
+    """(fine, coarse) LLR grid bits by the library's rule (oq_grid_bits_rule restates qd_decoder_create's)."""
+    pri = np.asarray(priors, dtype=np.float64)
+    mx = float(np.max(np.abs(np.log((1.0 - pri) / pri))))
+    kc = C.c_int(0)
+    k = lib().oq_grid_bits_rule(mx, int(max_iter), C.byref(kc))
+    return int(k), int(kc.value)
+
+
+def device_arithmetic(pcm, priors, bp_method="minimum_sum", schedule="parallel", max_iter=0, ms_scaling_factor=1.0):
+    """(Graph, form) that reproduce libquits_amd.so bit for bit for these options: flooding min-sum with ms_scaling 1 runs
+    exact arithmetic on the LLR grid -> ldpc's double-precision update order on the same grid; every other combination runs
+    float arithmetic on float(log((1-p)/p)) -> the float mirrors."""
+    g = Graph(pcm, priors)
+    ms = BP_METHOD[str(bp_method).lower()] == 1
+    par = SCHEDULE[str(schedule).lower()] == 0
+    if ms and par and float(ms_scaling_factor) == 1.0:
+        return g.device_grid(int(max_iter)), FORM_LDPC_F64
+    return g, (FORM_COMPRESSED_F32 if (ms and par) else FORM_LDPC_F32)
 
 
 def max_abs_llr(reset=False) -> float:
@@ -174,7 +208,7 @@ class OracleBpOsdDecoder:
 
     def __init__(self, pcm, error_rate=None, error_channel=None, max_iter=0, bp_method="minimum_sum",
                  ms_scaling_factor=1.0, schedule="parallel", osd_method="osd_0", osd_order=0,
-                 channel_probs=None, form=FORM_LDPC_F64, **_ignored):
+                 channel_probs=None, form=FORM_LDPC_F64, llr_grid=None, **_ignored):
         if channel_probs is not None:
             error_channel = channel_probs
         if error_channel is None:
@@ -182,6 +216,10 @@ class OracleBpOsdDecoder:
                 raise ValueError("error_rate or error_channel/channel_probs is required")
             error_channel = float(error_rate)
         self.graph = Graph(pcm, error_channel)
+        if llr_grid == "device":       # the grid the HIP library uses for these options (flooding min-sum, ms_scaling 1)
+            self.graph.device_grid(int(max_iter))
+        elif llr_grid is not None:
+            self.graph.quantize_llr(int(llr_grid))
         self.params = make_params(bp_method, schedule, max_iter, osd_method, osd_order, ms_scaling_factor, form)
         self.last_flags = None
 
@@ -191,12 +229,16 @@ class OracleBpOsdDecoder:
         return err[0]
 
 
-def sliding_window_decode(windows, nz, samples, params: Params):
-    """windows: list of dicts {H (csr), priors, L (csr over committed cols), U (csr or None), row0}."""
+def sliding_window_decode(windows, nz, samples, params: Params, device_grid=False):
+    """windows: list of dicts {H (csr), priors, L (csr over committed cols), U (csr or None), row0}.
+    device_grid: put every window's LLRs on the grid libquits_amd.so uses for it (flooding min-sum, ms_scaling 1)."""
     L = lib()
     samples = np.ascontiguousarray(np.asarray(samples) % 2, dtype=np.uint8)
     B, ndet = samples.shape
     graphs = [Graph(w["H"], w["priors"]) for w in windows]
+    if device_grid:
+        for g in graphs:
+            g.device_grid(params.max_iter)
     nobs = windows[0]["L"].shape[0]
     keep = []
 

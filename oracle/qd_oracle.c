@@ -66,6 +66,7 @@ typedef struct {
     double *llr0;            /* log((1-p)/p) in double; cast to float by the f32 forms */
     int rank;                /* -1 until computed */
     int llr_frac_bits;       /* -1: llr0 exact; k >= 0: llr0 rounded to the nearest multiple of 2^-k (oq_graph_quantize_llr) */
+    int llr_coarse_bits;     /* -1: none; else the grid a shot is re-decoded on when the fine grid's exactness bound trips */
 } oq_graph;
 
 /* largest |posterior LLR| any BP call of this process has produced since the last reset (tools/ler_forms.py uses it to
@@ -73,6 +74,12 @@ typedef struct {
 static double g_max_abs_llr = 0.0;
 double oq_max_abs_llr(int reset) { double v = g_max_abs_llr; if (reset) g_max_abs_llr = 0.0; return v; }
 #define OQ_TRACK_LLR(x) do { double ax_ = fabs((double)(x)); if (ax_ > g_max_abs_llr) g_max_abs_llr = ax_; } while (0)
+/* Exactness bound of the grid arithmetic (mirrors quits_amd/csrc/bp_kernels.hip): for every fault and iteration
+ * S_j = |llr0_j| + sum_k |c2b_k|.  Every partial sum of the posterior and every bit->check message is bounded by S_j, so
+ * S_j < 2^(23-k) for all j guarantees that single-precision arithmetic on multiples of 2^-k never rounded.  The largest
+ * S of the current BP call is kept here; oq_bposd_decode compares it with the limit. */
+static double g_max_s = 0.0;
+#define OQ_TRACK_S(x) do { if ((double)(x) > g_max_s) g_max_s = (double)(x); } while (0)
 
 /* the shared float functions, exposed so that tests can compare them with libm in double */
 void oq_math_f32(int kind, const float *x, float *y, int64_t count)
@@ -85,7 +92,7 @@ oq_graph *oq_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *c
 {
     oq_graph *g = (oq_graph *)calloc(1, sizeof(oq_graph));
     int nnz = row_ptr[m];
-    g->m = m; g->n = n; g->nnz = nnz; g->rank = -1; g->llr_frac_bits = -1;
+    g->m = m; g->n = n; g->nnz = nnz; g->rank = -1; g->llr_frac_bits = -1; g->llr_coarse_bits = -1;
     g->rp = (int *)malloc(sizeof(int) * (size_t)(m + 1));
     g->ci = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
     g->cp = (int *)calloc((size_t)(n + 1), sizeof(int));
@@ -122,6 +129,23 @@ oq_graph *oq_graph_create(int m, int n, const int32_t *row_ptr, const int32_t *c
  * forms -- and below 2^(53-k) the double forms -- perform EXACT arithmetic: all four forms (ldpc's prefix sums or
  * "total minus own", float or double) then return identical bits.  That is the arithmetic of the headline HIP kernel
  * (qd_graph_create does the same rounding); what separates it from ldpc is therefore this one rounding of the inputs. */
+void oq_graph_set_coarse_grid(oq_graph *g, int coarse_bits) { g->llr_coarse_bits = coarse_bits; }
+
+/* The rule by which the HIP library picks the grid (qd_decoder_create; restated here so that tests can hold the two
+ * against each other): the bound S grows by a few prior-LLRs per iteration (about 6 * max|llr0| * max_iter at the headline),
+ * so the grid leaves room for 8 * max|llr0| * max_iter below 2^(23-k); the coarse grid is 16 times wider. */
+int oq_grid_bits_rule(double max_abs_llr0, int max_iter, int *coarse)
+{
+    double need = 8.0 * max_abs_llr0 * (double)(max_iter > 0 ? max_iter : 1);
+    int e = 0;
+    while (ldexp(1.0, e) < need && e < 40) e++;
+    int k = 23 - e;
+    if (k > 20) k = 20;
+    if (k < 2) k = 2;
+    if (coarse) *coarse = k - 4 < 0 ? 0 : k - 4;
+    return k;
+}
+
 void oq_graph_quantize_llr(oq_graph *g, int frac_bits)
 {
     g->llr_frac_bits = frac_bits;
@@ -444,31 +468,55 @@ int oq_osd_w_fixed(oq_graph *g, const uint8_t *synd, const double *llr, int osd_
 
 /* BpOsdDecoder.decode (bposd_decoder.pyx): BP; if converged return the BP decision, else OSD on the posteriors.
  * flags_out (optional, int[4]): converged, iterations, osd pivots, osd inconsistent. */
+static int g_last_grid = -1, g_last_uncertified = 0;
+/* grid the last oq_bposd_decode call ended on (-1: exact LLRs), and whether even that grid's bound tripped */
+void oq_last_grid(int32_t *out2) { out2[0] = g_last_grid; out2[1] = g_last_uncertified; }
+
 int oq_bposd_decode(oq_graph *g, const oq_params *prm, const uint8_t *synd, uint8_t *err, int32_t *flags_out)
 {
     double *llr = (double *)malloc(sizeof(double) * (size_t)(g->n > 0 ? g->n : 1));
     int iters = 0;
     int32_t st[4] = {0, 0, 0, 0};
+    g_max_s = 0.0;
     int conv = oq_bp_decode(g, prm, synd, err, llr, &iters);
     if (conv < 0) { free(llr); return -1; }
+    g_last_grid = g->llr_frac_bits; g_last_uncertified = 0;
+    if (g->llr_frac_bits >= 0 && g->llr_coarse_bits >= 0 && g_max_s >= ldexp(1.0, 23 - g->llr_frac_bits)) {
+        /* the device re-decodes such a shot on the coarse grid (bp_kernels.hip, redo pass) */
+        const int fine = g->llr_frac_bits;
+        oq_graph_quantize_llr(g, g->llr_coarse_bits);
+        g_max_s = 0.0;
+        conv = oq_bp_decode(g, prm, synd, err, llr, &iters);
+        g_last_grid = g->llr_coarse_bits;
+        g_last_uncertified = g_max_s >= ldexp(1.0, 23 - g->llr_coarse_bits);
+        oq_graph_quantize_llr(g, fine);
+    }
     if (!conv && prm->osd_method != OQ_OSD_OFF) {
         if (prm->osd_method == OQ_OSD_0 || prm->osd_order == 0) oq_osd0(g, synd, llr, 1, err, st);
         else osd_w_impl(g, synd, llr, prm->osd_method, prm->osd_order,
-                        prm->form == OQ_FORM_COMPRESSED_F32 || prm->form == OQ_FORM_LDPC_F32 /* integer costs, as the device */, err, NULL);
+                        prm->form == OQ_FORM_COMPRESSED_F32 || prm->form == OQ_FORM_LDPC_F32 || g->llr_frac_bits >= 0
+                        /* the device's arithmetic (float forms, or any form on the LLR grid): integer candidate costs */, err, NULL);
     }
     if (flags_out) { flags_out[0] = conv; flags_out[1] = iters; flags_out[2] = st[0]; flags_out[3] = st[2]; }
     free(llr);
     return 0;
 }
 
-int oq_bposd_decode_batch(oq_graph *g, const oq_params *prm, const uint8_t *synd, int64_t B, uint8_t *err,
-                          int32_t *flags /* B x 4 or NULL */)
+int oq_bposd_decode_batch2(oq_graph *g, const oq_params *prm, const uint8_t *synd, int64_t B, uint8_t *err,
+                           int32_t *flags /* B x 4 or NULL */, int32_t *grid /* B x 2 or NULL: grid used, bound tripped */)
 {
     for (int64_t b = 0; b < B; b++) {
         int rc = oq_bposd_decode(g, prm, synd + b * g->m, err + b * g->n, flags ? flags + 4 * b : NULL);
         if (rc) return rc;
+        if (grid) oq_last_grid(grid + 2 * b);
     }
     return 0;
+}
+
+int oq_bposd_decode_batch(oq_graph *g, const oq_params *prm, const uint8_t *synd, int64_t B, uint8_t *err,
+                          int32_t *flags /* B x 4 or NULL */)
+{
+    return oq_bposd_decode_batch2(g, prm, synd, B, err, flags, NULL);
 }
 
 /* ---------------------------------------------------------------------------------------------------------- */

@@ -16,7 +16,9 @@ QD_SCHEDULE = {"parallel": 0, "p": 0, "serial": 1, "s": 1, 0: 0, 1: 1}
 QD_OSD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "osd_e": 2, "osde": 2, "exhaustive": 2,
           "osd_cs": 3, "osdcs": 3, "combination_sweep": 3, 0: 0, 1: 1, 2: 2, 3: 3}
 
-STATUS_ITER_MASK = 0xFFFF
+STATUS_ITER_MASK = 0x3FFF
+STATUS_COARSE_GRID = 1 << 14
+STATUS_INEXACT = 1 << 15
 STATUS_CONVERGED = 1 << 16
 STATUS_OSD = 1 << 17
 STATUS_INCONSISTENT = 1 << 18
@@ -39,7 +41,7 @@ _lib = None
 
 EXPORTS = [
     "qd_version", "qd_last_error", "qd_device_count", "qd_graph_create", "qd_graph_destroy", "qd_graph_info",
-    "qd_decoder_create", "qd_decoder_destroy", "qd_decoder_reserve", "qd_decoder_set_workspace_limit", "qd_decode_batch", "qd_decode_stage", "qd_osd0_batch", "qd_decoder_failed_llr",
+    "qd_decoder_create", "qd_decoder_info", "qd_decoder_destroy", "qd_decoder_reserve", "qd_decoder_set_workspace_limit", "qd_decode_batch", "qd_decode_stage", "qd_osd0_batch", "qd_decoder_failed_llr",
     "qd_decoder_set_profiling", "qd_decoder_profile", "qd_decoder_debug_counters", "qd_spmat_create", "qd_spmat_destroy", "qd_gf2_spmv_batch",
     "qd_unpack_bits", "qd_count_mismatch", "qd_sample_dem",
 ]
@@ -71,6 +73,7 @@ def load():
     L.qd_graph_destroy.restype = None
     L.qd_graph_info.argtypes = [vp, vp]
     L.qd_decoder_create.argtypes = [vp, C.POINTER(QdParams), C.POINTER(vp)]
+    L.qd_decoder_info.argtypes = [vp, vp]
     L.qd_decoder_destroy.argtypes = [vp]
     L.qd_decoder_destroy.restype = None
     L.qd_decoder_reserve.argtypes = [vp, i64]

@@ -16,6 +16,7 @@
 //     one check pass + one bit pass + two barriers.
 //   * No atomics on floats, fixed summation order (ascending detector index) -> bit-reproducible.
 #include "qd_internal.h"
+#include "../../include/quits_amd.h"
 #include <float.h>
 
 // Four LDS byte offsets per vector load: uint2 = 4 x uint16 (windows up to 16379 fault slots), uint4 = 4 x uint32.
@@ -94,6 +95,7 @@ __device__ __forceinline__ qd_u32x4 qd_lds_gather16(uint32_t lds_addr)
             sg_ = (st_).z >> ((rec) & 31u);                                                 \
         }                                                                                                    \
         acc += __uint_as_float(sg_ << 31 | mag_);                                           \
+        sabs += __uint_as_float(mag_);                                                      \
     }
 
 // State of a check in LDS (16 bytes, one ds_read_b128):  x = min1 * alpha,  y = min2 * alpha,
@@ -116,7 +118,11 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
 
     const int tid = threadIdx.x;
     const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);   // first thread of this wavefront
-    const int64_t shot = blockIdx.x;
+    int64_t shot = blockIdx.x;
+    if (a.shot_list) {                                             // redo pass: one workgroup per parked shot
+        if ((int)blockIdx.x >= *a.shot_count) return;
+        shot = a.shot_list[blockIdx.x];
+    }
     const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
     const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
     const int m_pad = g.m_pad, n_pad = g.n_pad;
@@ -152,10 +158,18 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
     any = qd_block_or(any, misc, NW, 0);
     if (!any) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
         for (int w = tid; w < g.out_words; w += T) a.err_bits[shot * g.out_words + w] = 0u;
-        if (tid == 0) a.status[shot] = (1 << 16) | (1 << 19);
+        if (tid == 0) a.status[shot] = (1 << 16) | (1 << 19) | a.status_or;
         return;
     }
 
+    // Exactness bound of the grid arithmetic.  The channel LLRs are multiples of q = 2^-k and ms_scaling is 1, so every
+    // message is a multiple of q; a float sum or difference of such values is exact while its magnitude stays below
+    // 2^24 q.  S_j = |llr0_j| + sum_k |c2b_k| bounds every partial sum of fault j's posterior, and a bit->check message
+    // |L_j - c2b| <= S_j as well; S_j itself is a sum of non-negative terms (monotone: exact whenever the total is).  So
+    // max_j S_j < 2^23 q over the whole run (a.s_limit) certifies that no operation rounded: the result is then what
+    // ldpc's double-precision arithmetic returns for the same LLRs.  One extra add per edge, one compare per fault.
+    bool trip = false;             // a lane mask in scalar registers: costs no vector register
+    const float s_lim = a.s_limit > 0.f ? a.s_limit : __builtin_inff();
     int t = 0, converged = 0, phase = 1;
     QD_BP_TICK(4)
     for (;;) {
@@ -239,6 +253,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
             if (NCH > 3 && b0 < g.bit_thr[11]) r3 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_voff, (3 * n_pad + base) * 16, 0);
             if (NCH > 4 && b0 < g.bit_thr[15]) r4 = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, rec_voff, (4 * n_pad + base) * 16, 0);
             float acc = __uint_as_float(r0.x);
+            float sabs = fabsf(acc);
             {
                 qd_u32x4 s0 = QD_BIT_LOAD(r0.y), s1 = QD_BIT_LOAD(r0.z), s2 = QD_BIT_LOAD(r0.w);
                 QD_BIT_WAIT3(s0, s1, s2);
@@ -273,6 +288,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
                 QD_BIT_USE(r4.x, s0)
             }
             llr[b] = acc;
+            trip |= (sabs >= s_lim);
         }
         QD_BP_TICK(2)
         __syncthreads();
@@ -280,6 +296,23 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
         ++t;
     }
 
+    // ---- grid arithmetic: did the bound hold?  (a.s_limit = 0: LLRs are not on a grid, nothing to certify)
+    int status_or = a.status_or;
+    if (a.s_limit > 0.f) {
+        const int tripped = qd_block_or(trip ? 1 : 0, misc, NW, phase);
+        if (tripped) {
+            if (a.redo_list) {                                     // park the shot for the coarse-grid pass, if there is room
+                if (tid == 0) misc[33] = atomicAdd(a.redo_count, 1);
+                __syncthreads();
+                const int at = misc[33];
+                if (at < a.redo_cap) {
+                    if (tid == 0) a.redo_list[at] = (int32_t)shot;
+                    return;
+                }
+            }
+            status_or |= QD_STATUS_INEXACT;
+        }
+    }
     // ---- hard decision, packed by fault index
     for (int b = tid; b < g.n; b += T)
         if (llr[b] <= 0.f) {
@@ -295,7 +328,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
         for (int b = tid; b < g.n; b += T) dst[b] = llr[b];
         if (tid == 0) a.fail_list[slot] = (int32_t)shot;
     }
-    if (tid == 0) a.status[shot] = t | (converged << 16);
+    if (tid == 0) a.status[shot] = t | (converged << 16) | status_or;
 #ifdef QD_BP_TIMING
     QD_BP_TICK(5)
     if (tid == 0) {

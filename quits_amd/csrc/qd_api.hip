@@ -71,6 +71,9 @@ struct qd_graph {
     OsdGraphDev osd{};
     DevAllocs mem;
     std::vector<int32_t> h_cp, h_ri;   // host CSC, for the rank
+    std::vector<double> h_llr0;        // log((1-p)/p) in double, fault order
+    std::vector<uint32_t> h_bit_rec;   // host copy of bp.bit_rec: a decoder on an LLR grid uploads its own with word 0 replaced
+    std::vector<uint32_t> h_bit_orig;  // bit slot -> fault
 };
 
 struct qd_decoder {
@@ -88,6 +91,13 @@ struct qd_decoder {
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
     int64_t gen_ws_limit = 0;   // bytes; 0 = default
     GenWs gws{};
+    // ---- LLR grid (flooding min-sum, ms_scaling 1): decoder-owned prior arrays on the fine and the coarse grid
+    int grid_k = -1, grid_kc = -1;
+    BpGraphDev bp_fine{}, bp_coarse{};         // copies of g->bp with their own bit_rec
+    const float *llr0_q = nullptr;             // fault-order LLRs for the one-message-per-edge kernel (fine grid)
+    int32_t *redo_list = nullptr;
+    int redo_cap = 0;
+    DevAllocs mem;
     int profiling = 0;
     struct Span { int kind; hipEvent_t t0, t1; };   // kind 0 = BP kernel, 1 = OSD kernel(s)
     std::vector<Span> ev;
@@ -232,6 +242,9 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         }
     }
     g->h_cp = cp; g->h_ri = ri;
+    g->h_bit_rec = bit_rec; g->h_bit_orig = bit_orig_u;
+    g->h_llr0.resize(n);
+    for (int j = 0; j < n; ++j) g->h_llr0[j] = std::log((1.0 - priors[j]) / priors[j]);
     {
         GenGraphDev &gg = g->gen;
         gg.m = m; gg.n = n; gg.nnz = nnz; gg.out_words = (n + 31) / 32;
@@ -455,8 +468,43 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     d->osd_w = osd0 || p->osd_method == QD_OSD_OFF ? 0 : (p->osd_method == QD_OSD_CS ? 1 : 2);
     if (d->osd_w) host_rank(const_cast<qd_graph *>(g));     // the sweep needs the complete factorisation: rank pivots
     if (d->prm.max_iter == 0) d->prm.max_iter = g->n;       // ldpc: max_iter = 0 -> number of bits
-    if (d->prm.max_iter > 0xFFFF) d->prm.max_iter = 0xFFFF;
+    if (d->prm.max_iter > QD_STATUS_ITER_MASK) d->prm.max_iter = QD_STATUS_ITER_MASK;
+    d->bp_fine = g->bp; d->bp_coarse = g->bp; d->llr0_q = g->gen.llr0;
+    if (p->bp_method == QD_BP_MINIMUM_SUM && p->schedule == QD_SCHEDULE_PARALLEL && p->ms_scaling_factor == 1.0 &&
+        !(p->reserved & QD_FLAG_RAW_LLR)) {
+        // Channel LLRs on a binary grid: see qd_decoder_info in quits_amd.h.  (oracle/qd_oracle.c restates this rule.)
+        double mx = 0.0;
+        for (double l : g->h_llr0) mx = std::max(mx, std::fabs(l));
+        const double need = 8.0 * mx * (double)std::max(1, d->prm.max_iter);
+        int e = 0;
+        while (std::ldexp(1.0, e) < need && e < 40) ++e;
+        d->grid_k = std::min(20, std::max(2, 23 - e));
+        d->grid_kc = std::max(0, d->grid_k - 4);
+        if (hipSetDevice(g->device) != hipSuccess) { delete d; return fail(QD_EHIP, "hipSetDevice(%d) failed", g->device); }
+        auto on_grid = [&](double l, int k) { return (float)std::ldexp(std::nearbyint(std::ldexp(l, k)), -k); };
+        int rc = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            const int k = pass == 0 ? d->grid_k : d->grid_kc;
+            std::vector<uint32_t> rec = g->h_bit_rec;
+            for (int s = 0; s < g->n; ++s) {
+                const float l0 = on_grid(g->h_llr0[g->h_bit_orig[s]], k);
+                std::memcpy(&rec[(size_t)s * 4], &l0, 4);                  // word 0 of chunk 0: [chunk][slot][4]
+            }
+            rc |= d->mem.upload(rec, pass == 0 ? &d->bp_fine.bit_rec : &d->bp_coarse.bit_rec);
+        }
+        std::vector<float> lq(g->n);
+        for (int j = 0; j < g->n; ++j) lq[j] = on_grid(g->h_llr0[j], d->grid_k);
+        rc |= d->mem.upload(lq, &d->llr0_q);
+        if (rc) { d->mem.release(); delete d; return fail(QD_EHIP, "device allocation failed while building the LLR grid"); }
+    }
     *out = d;
+    return QD_OK;
+}
+
+extern "C" int qd_decoder_info(const qd_decoder *d, int32_t *info)
+{
+    if (!d || !info) return fail(QD_EINVAL, "null argument");
+    info[0] = d->grid_k; info[1] = d->grid_kc; info[2] = d->general; info[3] = 0;
     return QD_OK;
 }
 
@@ -480,6 +528,8 @@ static void free_ws(qd_decoder *d)
     d->gws = GenWs{};
     if (d->hard_list) (void)hipFree(d->hard_list);
     if (d->hard_list2) (void)hipFree(d->hard_list2);
+    if (d->redo_list) (void)hipFree(d->redo_list);
+    d->redo_list = nullptr; d->redo_cap = 0;
     d->hard_list = nullptr; d->hard_list2 = nullptr;
     d->llr_ws = nullptr; d->fail_list = nullptr; d->fail_count = nullptr; d->order_ws = nullptr; d->q_spill = nullptr;
     d->cap = 0;
@@ -490,6 +540,7 @@ extern "C" void qd_decoder_destroy(qd_decoder *d)
     if (!d) return;
     (void)hipSetDevice(d->g->device);
     free_ws(d);
+    d->mem.release();
     for (auto &sp : d->ev) { (void)hipEventDestroy(sp.t0); (void)hipEventDestroy(sp.t1); }
     delete d;
 }
@@ -505,6 +556,10 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
     const bool osd = d->prm.osd_method != QD_OSD_OFF;
     HIP_TRY(hipMalloc((void **)&d->fail_count, 256));
     HIP_TRY(hipMemset(d->fail_count, 0, 256));
+    if (d->grid_k >= 0 && !d->general) {
+        d->redo_cap = (int)std::min<int64_t>(max_batch, 4096);
+        HIP_TRY(hipMalloc((void **)&d->redo_list, sizeof(int32_t) * (size_t)d->redo_cap));
+    }
     if (osd) {
         int ncu = 256;
         hipDeviceProp_t prop;
@@ -632,13 +687,28 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         return QD_OK;
     };
     if (stage & 1) {
+        int32_t *redo_count = d->fail_count + 40;       // bytes 160..163 of the counter block (16..143 are the debug counters)
         HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
         hipEvent_t t0 = nullptr;
         if (int rc = span(0, t0)) return rc;
         if (d->general) {
+            GenGraphDev gg = d->g->gen;
+            gg.llr0 = d->llr0_q;
             for (int64_t b0 = 0; b0 < B; b0 += d->gws.S)
-                HIP_TRY(qd_launch_bp_general(d->g->gen, d->g->bp, a, d->gws, d->prm.bp_method, d->prm.schedule, b0,
+                HIP_TRY(qd_launch_bp_general(gg, d->g->bp, a, d->gws, d->prm.bp_method, d->prm.schedule, b0,
                                              (int)std::min<int64_t>(d->gws.S, B - b0), s));
+        } else if (d->grid_k >= 0) {
+            // grid arithmetic: first pass on the fine grid parks the shots whose exactness bound tripped; they are decoded
+            // again on the coarse grid by a second launch (one workgroup per parked shot; the others exit at once)
+            HIP_TRY(hipMemsetAsync(redo_count, 0, sizeof(int32_t), s));
+            DecodeArgs a1 = a;
+            a1.s_limit = std::ldexp(1.0f, 23 - d->grid_k);
+            a1.redo_list = d->redo_list; a1.redo_count = redo_count; a1.redo_cap = d->redo_cap;
+            HIP_TRY(qd_launch_bp(d->bp_fine, a1, B, s));
+            DecodeArgs a2 = a;
+            a2.s_limit = std::ldexp(1.0f, 23 - d->grid_kc);
+            a2.shot_list = d->redo_list; a2.shot_count = redo_count; a2.status_or = QD_STATUS_COARSE_GRID;
+            HIP_TRY(qd_launch_bp(d->bp_coarse, a2, std::min<int64_t>(B, d->redo_cap), s));
         } else
             HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
         if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));

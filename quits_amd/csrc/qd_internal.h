@@ -104,6 +104,14 @@ struct DecodeArgs {
     int32_t *hard_count;        // [2]
     unsigned long long *dbg;    // [16] phase cycle counters (only written by -DQD_OSD_TIMING builds)
     int osd_w, osd_order, rank; // higher-order OSD: 0 = OSD-0, 1 = combination sweep, 2 = exhaustive; GF(2) rank of the window matrix
+    // ---- grid arithmetic of the LDS min-sum kernel (channel LLRs are multiples of 2^-k, ms_scaling = 1: see bp_kernels.hip)
+    float s_limit;              // 2^(23-k): the run is exact while every S_j = |llr0_j| + sum |c2b| stays below it; 0 = not on a grid
+    const int32_t *shot_list;   // redo pass: workgroup x decodes shot shot_list[x] (x < *shot_count); null = shot x
+    const int32_t *shot_count;
+    int32_t *redo_list;         // first pass: shots whose bound tripped are parked here for the coarse-grid pass; null = last pass
+    int32_t *redo_count;
+    int redo_cap;
+    int status_or;              // ORed into the status word (QD_STATUS_COARSE_GRID in the redo pass)
 };
 
 // Workgroup-wide OR without static LDS (a static __shared__ object in front of the dynamic region can knock the

@@ -78,7 +78,7 @@ class BpOsdDecoder:
         out = self.decode_batch(syndrome.reshape(1, -1))[0]
         st = int(self.last_status[0])
         self.converge = bool(st & (1 << 16))
-        self.iter = st & 0xFFFF
+        self.iter = st & 0x3FFF
         return out.astype(syndrome.dtype) if syndrome.dtype != np.bool_ else out
 
 

@@ -64,14 +64,15 @@ class BatchDecoder:
     """qd_decoder: BP(+OSD-0) over a batch of shots for one window."""
 
     def __init__(self, graph: WindowGraph, bp_method="minimum_sum", schedule="parallel", max_iter=0,
-                 osd_method="osd_0", osd_order=0, ms_scaling_factor=1.0, edge_messages=False):
+                 osd_method="osd_0", osd_order=0, ms_scaling_factor=1.0, edge_messages=False, raw_llr=False):
         """bp_method 'minimum_sum' + schedule 'parallel' runs in the compressed LDS kernel; every other pair -- and that one
-        too when `edge_messages` is set -- in the one-message-per-edge kernel (csrc/bp_general.hip)."""
+        too when `edge_messages` is set -- in the one-message-per-edge kernel (csrc/bp_general.hip).  `raw_llr` keeps the
+        channel LLRs off the binary grid (QD_FLAG_RAW_LLR: round-1 float arithmetic, validation only)."""
         self.graph = graph
         L = graph._L
         try:
             prm = _lib.QdParams(_lib.QD_BP[_norm(bp_method)], _lib.QD_SCHEDULE[_norm(schedule)], int(max_iter),
-                                _lib.QD_OSD[_norm(osd_method)], int(osd_order), 1 if edge_messages else 0,
+                                _lib.QD_OSD[_norm(osd_method)], int(osd_order), (1 if edge_messages else 0) | (2 if raw_llr else 0),
                                 float(ms_scaling_factor))
         except KeyError as exc:
             raise ValueError("unknown decoder option %s" % exc) from exc
@@ -83,6 +84,12 @@ class BatchDecoder:
         self._h = h
         self._L = L
         self.params = prm
+
+    def info(self) -> dict:
+        """Arithmetic of this decoder (qd_decoder_info): LLR grid bits (-1 = float LLRs as they are), coarse grid, kernel."""
+        arr = (C.c_int32 * 4)()
+        _lib.check(self._L.qd_decoder_info(self._h, arr))
+        return {"llr_grid_bits": int(arr[0]), "llr_coarse_bits": int(arr[1]), "edge_kernel": bool(arr[2])}
 
     def set_workspace_limit(self, nbytes: int):
         """Cap the HBM message workspace of the one-message-per-edge BP kernel (product_sum / serial); no effect on the LDS kernel."""

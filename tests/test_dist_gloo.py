@@ -20,7 +20,7 @@ N = 301
 lo, hi = parallel.shard_range(N, rank, world)
 H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
 synd, obs, _ = orc.sample_dem(H, L, pri, seed=42, shot0=lo, B=hi - lo)         # counter-based sampler: shard = slice
-err, _ = orc.Graph(H, pri).decode_batch(synd, orc.make_params("minimum_sum", "parallel", 10, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32))
+err, _ = orc.Graph(H, pri).decode_batch(synd, orc.make_params("minimum_sum", "parallel", 10, "osd_0", 0, 1.0, orc.FORM_LDPC_F64))
 fails = int(((np.asarray(L @ err.T %% 2).T != obs).any(axis=1)).sum())
 tot_err, tot_shots = parallel.reduce_counts(dist, fails, hi - lo)
 tmax = parallel.reduce_max(dist, float(rank + 1))

@@ -203,3 +203,42 @@ def test_float_edge_form_tracks_double(method, schedule, max_iter):
     assert (e32 == e64).all(axis=1).mean() > 0.97
     Hd = np.asarray(H.todense(), dtype=np.int64)
     assert np.array_equal(e32.astype(np.int64) @ Hd.T % 2, synd)
+
+
+def test_grid_arithmetic_is_exact_in_every_form():
+    """Channel LLRs on a binary grid (Graph.device_grid: the grid libquits_amd.so picks): min-sum with ms_scaling 1 only adds,
+    subtracts, negates and compares, so float or double, ldpc's prefix sums or "total minus own" all return the SAME bits --
+    which is why the HIP kernel may be held to the double-precision / ldpc-order form.  Off the grid the float forms differ."""
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=17, shot0=0, B=300)
+    forms = (orc.FORM_LDPC_F64, orc.FORM_COMPRESSED_F32, orc.FORM_COMPRESSED_F64, orc.FORM_LDPC_F32)
+    g = orc.Graph(H, pri).device_grid(30)
+    assert g.grid == orc.grid_bits(pri, 30) and g.grid[1] == g.grid[0] - 4
+    out = [g.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 30, "osd_0", 0, 1.0, f), return_grid=True) for f in forms]
+    for e, fl, gr in out[1:]:
+        assert np.array_equal(e, out[0][0]) and np.array_equal(fl, out[0][1]) and np.array_equal(gr, out[0][2])
+    assert (out[0][2][:, 0] == g.grid[0]).all() and not out[0][2][:, 1].any()       # nobody left the fine grid
+    raw = orc.Graph(H, pri)
+    e64, _ = raw.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 30, "osd_0", 0, 1.0, orc.FORM_LDPC_F64))
+    e32, _ = raw.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 30, "osd_0", 0, 1.0, orc.FORM_LDPC_F32))
+    assert not np.array_equal(e64, e32)
+    # (grid vs exact LLRs: non-converged min-sum is chaotic, the error vectors differ on a quarter of these shots while the
+    #  logical error rates agree -- profiles/r02_ler_forms_*.json holds the paired comparison on 2 x 10^6 shots)
+
+
+def test_grid_bound_sends_a_shot_to_the_coarse_grid():
+    """The exactness bound S < 2^(23-k): on a deliberately fine grid it trips, the shot is decoded again on the coarse grid and
+    the result is the coarse grid's (what the device's redo pass does); the float forms still agree with the double form."""
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=18, shot0=0, B=120)
+    prm = orc.make_params("minimum_sum", "parallel", 40, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)
+    g = orc.Graph(H, pri).quantize_llr(17, 10)          # limit 2^6 = 64: most non-trivial shots exceed it
+    e, fl, gr = g.decode_batch(synd, prm, return_grid=True)
+    tripped = gr[:, 0] == 10
+    assert 0 < tripped.sum() < len(synd) and not gr[:, 1].any()
+    ec, _ = orc.Graph(H, pri).quantize_llr(10).decode_batch(synd, prm)
+    ef, _ = orc.Graph(H, pri).quantize_llr(17).decode_batch(synd, prm)
+    assert np.array_equal(e[tripped], ec[tripped]) and np.array_equal(e[~tripped], ef[~tripped])
+    e32, fl32, gr32 = g.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 40, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32), return_grid=True)
+    assert np.array_equal(e32, e) and np.array_equal(gr32, gr)
+    assert orc.grid_bits(np.array([0.003]), 50) == (11, 7) and orc.grid_bits(np.array([0.5 - 1e-9]), 1)[0] == 20

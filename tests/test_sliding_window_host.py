@@ -32,8 +32,9 @@ def test_host_loop_matches_reference_loop(name, code, R, cases, nshots):
     cd = helpers.code(code)
     circ = Circuit(helpers.circuit_text(name))
     for (W, F, mi) in cases:
-        for form, tag in ((orc.FORM_LDPC_F64, "f64"), (orc.FORM_COMPRESSED_F32, "f32c")):
-            opts = dict(bp_method="minimum_sum", max_iter=mi, schedule="parallel", osd_method="osd_0", osd_order=0, form=form)
+        for grid, tag in ((None, "f64"), ("device", "grid")):
+            opts = dict(bp_method="minimum_sum", max_iter=mi, schedule="parallel", osd_method="osd_0", osd_order=0,
+                        form=orc.FORM_LDPC_F64, llr_grid=grid)
             d1, d2 = dict(opts), dict(opts)
             with warnings.catch_warnings(record=True) as wlog:
                 warnings.simplefilter("always")
@@ -57,9 +58,9 @@ def test_oracle_c_loop_matches_reference_loop(name, code, R, cases, nshots):
         checks, commits, priors, updates = spacetime(circ, cd["hz"], W, F, ncr)
         wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None,
                  "row0": F * k * nz} for k in range(len(checks))]
-        prm = orc.make_params("minimum_sum", "parallel", mi, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32)
-        pred, stats = orc.sliding_window_decode(wins, nz, synd, prm)
-        assert np.array_equal(pred, z["circ_W%dF%d_it%d_f32c" % (W, F, mi)])
+        prm = orc.make_params("minimum_sum", "parallel", mi, "osd_0", 0, 1.0, orc.FORM_LDPC_F64)
+        pred, stats = orc.sliding_window_decode(wins, nz, synd, prm, device_grid=True)
+        assert np.array_equal(pred, z["circ_W%dF%d_it%d_grid" % (W, F, mi)])
         assert stats["bp_converged"] + stats["osd_calls"] == synd.shape[0] * len(wins)
 
 
@@ -69,10 +70,10 @@ def test_phenom_host_loop_matches_reference_loop(name, code, R, cases, nshots):
     cd = helpers.code(code)
     for (W, F, mi) in cases[:2]:
         opts = dict(bp_method="minimum_sum", max_iter=mi, schedule="parallel", osd_method="osd_0", osd_order=0,
-                    error_rate=0.03, form=orc.FORM_COMPRESSED_F32)
+                    error_rate=0.03, form=orc.FORM_LDPC_F64, llr_grid="device")
         pred = sliding_window_phenom_mem(synd[:nshots].astype(int), cd["hz"], cd["lz"], W, F, orc.OracleBpOsdDecoder,
                                          orc.OracleBpOsdDecoder, dict(opts), dict(opts), "decode", "decode")
-        assert np.array_equal(pred, z["phen_W%dF%d_it%d_f32c" % (W, F, mi)][:nshots])
+        assert np.array_equal(pred, z["phen_W%dF%d_it%d_grid" % (W, F, mi)][:nshots])
 
 
 def test_phenom_window_matrices_shape():

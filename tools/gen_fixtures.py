@@ -242,9 +242,11 @@ def gen_loop():
         out = {"syndromes": np.packbits(synd, axis=1), "observables": np.packbits(obs, axis=1),
                "shape": np.asarray(synd.shape, np.int64)}
         for (W, F, mi) in cases:
-            for form, ftag in ((orc.FORM_LDPC_F64, "f64"), (orc.FORM_COMPRESSED_F32, "f32c")):
+            # "grid": ldpc's double-precision arithmetic on the LLR grid the HIP library uses (exact there; see
+            # qd_decoder_info in include/quits_amd.h) -- what the device path must reproduce bit for bit
+            for grid, ftag in ((None, "f64"), ("device", "grid")):
                 d1 = dict(bp_method="minimum_sum", max_iter=mi, schedule="parallel", osd_method="osd_0",
-                          osd_order=0, form=form)
+                          osd_order=0, form=orc.FORM_LDPC_F64, llr_grid=grid)
                 d2 = dict(d1)
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
@@ -256,11 +258,11 @@ def gen_loop():
         # tests/test_sliding_window.py:106-166), scalar prior
         for (W, F, mi) in cases[:2]:
             d1 = dict(bp_method="minimum_sum", max_iter=mi, schedule="parallel", osd_method="osd_0", osd_order=0,
-                      error_rate=0.03, form=orc.FORM_COMPRESSED_F32)
+                      error_rate=0.03, form=orc.FORM_LDPC_F64, llr_grid="device")
             d2 = dict(d1)
             pred = sliding_window_phenom_mem(synd.astype(int), hz, lz, W, F, orc.OracleBpOsdDecoder,
                                              orc.OracleBpOsdDecoder, d1, d2, "decode", "decode")
-            out["phen_W%dF%d_it%d_f32c" % (W, F, mi)] = pred.astype(np.uint8)
+            out["phen_W%dF%d_it%d_grid" % (W, F, mi)] = pred.astype(np.uint8)
         np.savez_compressed(os.path.join(GOLD, "loop", cname + ".npz"), **out)
         print("loop:", cname, {k: v.shape for k, v in out.items() if k.startswith(("circ", "phen"))})
 
@@ -283,9 +285,10 @@ def gen_codecap():
         cd = _load_code(code)
         cobj = types.SimpleNamespace(hz=cd["hz"], hx=cd["hx"], lz=cd["lz"], lx=cd["lx"])
         for form, ftag in ((orc.FORM_LDPC_F64, "f64"), (orc.FORM_LDPC_F32, "f32")):
-            if opts["bp_method"] == "minimum_sum" and opts["schedule"] == "parallel" and ftag == "f32":
-                form, ftag = orc.FORM_COMPRESSED_F32, "f32c"
             d = dict(opts, error_rate=p, form=form)
+            if opts["bp_method"] == "minimum_sum" and opts["schedule"] == "parallel" and ftag == "f32":
+                ftag = "grid"
+                d = dict(opts, error_rate=p, form=orc.FORM_LDPC_F64, llr_grid="device")
             pl = get_codecap_pL(cobj, p, trials, orc.OracleBpOsdDecoder, d, basis=basis, seed=seed)
             out.append(dict(code=code, p=p, trials=trials, seed=seed, basis=basis, opts=opts, form=ftag, pL=pl))
             print("codecap:", code, p, basis, opts["bp_method"], opts["schedule"], ftag, pl)

@@ -24,7 +24,7 @@ import numpy as np
 CHUNK, NAME, MAX_ITER = 2000, "bb144_custom_r12_p0.003", 50
 CONFIGS = {  # name -> (oracle form, LLR fraction bits or -1)
     "ldpc_f64": (0, -1), "comp_f64": (2, -1), "ldpc_f32": (3, -1), "comp_f32": (1, -1),
-    "ldpc_f64_q12": (0, 12), "ldpc_f64_q16": (0, 16), "ldpc_f64_q20": (0, 20),
+    "ldpc_f64_q9": (0, 9), "ldpc_f64_q11": (0, 11), "ldpc_f64_q12": (0, 12), "ldpc_f64_q16": (0, 16), "ldpc_f64_q20": (0, 20),
     "comp_f32_q16": (1, 16),
 }
 _G = {}

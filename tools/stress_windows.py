@@ -25,8 +25,8 @@ def run(shots=96, name="bb72_custom_r6_p0.003", code="bb72", R=6, opts=(("minimu
     for W in range(1, R + 4):
         for F in range(1, W + 1):
             for (method, sched, mi, osd, order) in opts:
-                form = orc.FORM_COMPRESSED_F32 if (method, sched) == ("minimum_sum", "parallel") else orc.FORM_LDPC_F32
-                prm = orc.make_params(method, sched, mi, osd, order, 1.0, form)
+                grid = (method, sched) == ("minimum_sum", "parallel")          # exact arithmetic on the LLR grid <-> double form
+                prm = orc.make_params(method, sched, mi, osd, order, 1.0, orc.FORM_LDPC_F64 if grid else orc.FORM_LDPC_F32)
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
                     pred = sliding_window_bposd_circuit_mem(det, circ, hz, lz, W, F, max_iter=mi, osd_order=order,
@@ -35,7 +35,7 @@ def run(shots=96, name="bb72_custom_r6_p0.003", code="bb72", R=6, opts=(("minimu
                     checks, commits, priors, updates = spacetime(circ, hz, W, F, ncr)
                 wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None,
                          "row0": F * k * nz} for k in range(len(checks))]
-                ref, _ = orc.sliding_window_decode(wins, nz, det, prm)
+                ref, _ = orc.sliding_window_decode(wins, nz, det, prm, device_grid=grid)
                 assert np.array_equal(pred, ref.astype(np.int64)), ("circuit", W, F, method, sched)
                 n_ok += 1
     print("window sweep: %d (W, F, options) combinations identical, %.0f s" % (n_ok, time.time() - t0))
