@@ -103,6 +103,7 @@ class Graph:
         self.m, self.n = A.shape
         pri = np.ascontiguousarray(np.broadcast_to(np.asarray(priors, dtype=np.float64), (self.n,)))
         self.priors = pri
+        self.grid = (-1, -1)
         self._h = lib().oq_graph_create(self.m, self.n, A.indptr.astype(np.int32), A.indices.astype(np.int32), pri)
         if not self._h:
             raise ValueError("oq_graph_create failed (bad indices or column weight > 64)")

@@ -447,7 +447,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     *out = nullptr;
     if (p->bp_method != QD_BP_MINIMUM_SUM && p->bp_method != QD_BP_PRODUCT_SUM) return fail(QD_EINVAL, "unknown bp_method %d", p->bp_method);
     if (p->schedule != QD_SCHEDULE_PARALLEL && p->schedule != QD_SCHEDULE_SERIAL) return fail(QD_EINVAL, "unknown schedule %d", p->schedule);
-    if (p->reserved & ~QD_FLAG_EDGE_MESSAGES) return fail(QD_EINVAL, "unknown flag bits 0x%x", p->reserved);
+    if (p->reserved & ~(QD_FLAG_EDGE_MESSAGES | QD_FLAG_RAW_LLR)) return fail(QD_EINVAL, "unknown flag bits 0x%x", p->reserved);
     const bool osd0 = p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
     if (p->osd_method != QD_OSD_OFF && !osd0) {
         if (p->osd_method != QD_OSD_CS && p->osd_method != QD_OSD_E) return fail(QD_EINVAL, "unknown osd_method %d", p->osd_method);

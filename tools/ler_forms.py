@@ -13,9 +13,13 @@ stand-in for ldpc.BpOsdDecoder:
   ldpc_f64_qK   reference arithmetic on channel LLRs rounded to multiples of 2^-K: every form then computes exactly
                 (no rounding anywhere), so this one column stands for all four forms AND for the round-2 HIP kernel
 
-  python tools/ler_forms.py run <shots> <seed> <out.npz> [procs] [configs,comma,separated]
-  python tools/ler_forms.py report <out.npz> [<out2.npz> ...]          # pooled over the files given
-CPU only (oracle); run it where the cores are (the GPU box has 256 hardware threads)."""
+  k1_grid / k1g_grid / k1_raw   (gpu mode) the HIP library itself: LDS kernel on its LLR grid (the product path), the
+                one-message-per-edge kernel on the same grid, and the LDS kernel with QD_FLAG_RAW_LLR (round-1 arithmetic)
+
+  python tools/ler_forms.py run <shots> <seed> <out.npz> [procs] [configs,comma,separated]      # CPU oracle
+  python tools/ler_forms.py gpu <shots> <seed> <out.npz>                                        # on the GPU box
+  python tools/ler_forms.py report <out.npz> [<out2.npz> ...]   # files of one seed are merged, seeds are pooled
+The GPU box grants 16 CPUs (cgroup), this container 8: a 10^6-shot double-precision column takes ~20 core-minutes."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -73,20 +77,74 @@ def run(shots, seed, path, procs, names):
     print("wrote", path, "%.0f s" % meta["seconds"])
 
 
+def gpu(shots, seed, path):
+    import torch, helpers
+    from quits_amd.decoder.device import BatchDecoder, DemSampler, GF2Matrix, WindowGraph
+    H, L, pri = helpers.dem_matrices(NAME)
+    smp, g, Lm = DemSampler(H, L, pri), WindowGraph(H, pri), GF2Matrix(L)
+    decs = {"k1_grid": BatchDecoder(g, max_iter=MAX_ITER, osd_method="osd_0"),
+            "k1g_grid": BatchDecoder(g, max_iter=MAX_ITER, osd_method="osd_0", edge_messages=True),
+            "k1_raw": BatchDecoder(g, max_iter=MAX_ITER, osd_method="osd_0", raw_llr=True)}
+    w = (1 << torch.arange(L.shape[0], device="cuda")).to(torch.int32)
+    t0 = time.time()
+    B = 50000
+    acc = {nm: ([], [], []) for nm in decs}
+    obs_all, coarse = [], 0
+    for c in range(shots // B):
+        det, obs = smp.sample(B, seed=seed, shot0=c * B)
+        obs_all.append((obs.to(torch.int32) * w).sum(1).to(torch.int16).cpu().numpy().view(np.uint16))
+        for nm, dec in decs.items():
+            bits, status = dec.decode(det)
+            pred = torch.zeros((B, L.shape[0]), dtype=torch.uint8, device="cuda")
+            Lm.xor_apply(bits, pred, accumulate=False)
+            acc[nm][0].append((pred.to(torch.int32) * w).sum(1).to(torch.int16).cpu().numpy().view(np.uint16))
+            acc[nm][1].append(((status >> 16) & 1).to(torch.uint8).cpu().numpy())
+            acc[nm][2].append((status & 0x3FFF).clamp(max=255).to(torch.uint8).cpu().numpy())
+            if nm == "k1_grid":
+                coarse += int(((status >> 14) & 3).ne(0).sum().item())
+    arrs = {"obs": np.concatenate(obs_all)}
+    meta = {"config": NAME, "max_iter": MAX_ITER, "seed": seed, "shots": (shots // B) * B, "seconds": time.time() - t0,
+            "names": list(decs), "max_abs_llr": {nm: 0.0 for nm in decs}, "k1_grid_info": decs["k1_grid"].info(),
+            "k1_grid_shots_off_the_fine_grid": coarse}
+    for nm in decs:
+        arrs[nm + "_pred"] = np.concatenate(acc[nm][0])
+        arrs[nm + "_conv"] = np.packbits(np.concatenate(acc[nm][1]))
+        arrs[nm + "_iters"] = np.concatenate(acc[nm][2])
+    arrs["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, "%.0f s" % meta["seconds"], meta["k1_grid_info"], "off the fine grid:", coarse)
+
+
 def report(paths):
     from math import erfc, sqrt
-    zs = [np.load(p) for p in paths]
-    metas = [json.loads(bytes(z["meta"]).decode()) for z in zs]
-    names = [nm for nm in metas[0]["names"] if all(nm in m["names"] for m in metas)]
-    obs = np.concatenate([z["obs"] for z in zs])
+    by_seed = {}
+    for p in paths:
+        z = np.load(p)
+        m = json.loads(bytes(z["meta"]).decode())
+        ent = by_seed.setdefault(m["seed"], {"arr": {}, "names": [], "mx": {}, "shots": m["shots"], "extra": {}})
+        n = min(ent["shots"], m["shots"])
+        if "obs" in ent["arr"]:
+            assert np.array_equal(ent["arr"]["obs"][:n], z["obs"][:n]), "files of one seed disagree on the observables"
+        ent["shots"] = n
+        for k in z.files:
+            if k != "meta":
+                ent["arr"][k] = z[k]
+        ent["names"] += [nm for nm in m["names"] if nm not in ent["names"]]
+        ent["mx"].update(m["max_abs_llr"])
+        ent["extra"].update({k: v for k, v in m.items() if k.startswith("k1_")})
+    seeds = sorted(by_seed)
+    names = [nm for nm in by_seed[seeds[0]]["names"] if all(nm in by_seed[sd]["names"] for sd in seeds)]
+    cat = lambda key: np.concatenate([by_seed[sd]["arr"][key][:by_seed[sd]["shots"]] for sd in seeds])
+    obs = cat("obs")
     N = len(obs)
-    fail = {nm: np.concatenate([z[nm + "_pred"] for z in zs]) != obs for nm in names}
-    pred = {nm: np.concatenate([z[nm + "_pred"] for z in zs]) for nm in names}
-    iters = {nm: np.concatenate([z[nm + "_iters"] for z in zs]) for nm in names}
+    pred = {nm: cat(nm + "_pred") for nm in names}
+    fail = {nm: pred[nm] != obs for nm in names}
+    iters = {nm: cat(nm + "_iters") for nm in names}
+    metas = [{"seed": sd, "max_abs_llr": by_seed[sd]["mx"]} for sd in seeds]
     ref = "ldpc_f64"
-    out = {"shots": N, "files": [os.path.basename(p) for p in paths], "seeds": [m["seed"] for m in metas],
-           "config": metas[0]["config"] + ", min-sum flooding max_iter=%d ms_scaling=1.0 + OSD-0" % MAX_ITER,
-           "reference_form": ref, "forms": {}}
+    out = {"shots": N, "files": [os.path.basename(p) for p in paths], "seeds": seeds,
+           "config": NAME + ", min-sum flooding max_iter=%d ms_scaling=1.0 + OSD-0" % MAX_ITER,
+           "reference_form": ref, "device": {str(sd): by_seed[sd]["extra"] for sd in seeds}, "forms": {}}
     pr = fail[ref].mean()
     for nm in names:
         p = fail[nm].mean()
@@ -106,7 +164,9 @@ def report(paths):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "run":
+    if sys.argv[1] == "gpu":
+        gpu(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
+    elif sys.argv[1] == "run":
         names = sys.argv[6].split(",") if len(sys.argv) > 6 else list(CONFIGS)
         run(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else os.cpu_count(), names)
     else:
