@@ -9,7 +9,8 @@ from quits_amd.decoder.base import spacetime, window_count, window_support_repor
 from quits_amd.dem import Circuit
 
 CASES = [("bb72_custom_r6_p0.003", "bb72", 6), ("bb144_custom_r12_p0.003", "bb144", 12),
-         ("hgp225_cardinal_r3_p0.01", "hgp225", 3)]
+         ("hgp225_cardinal_r3_p0.01", "hgp225", 3),
+         ("qlp1020_cardinal_r20_p0.003", "qlp1020", 20)]      # BASELINE configs[4]: 20 windows of 1350 x 18900 (W = 3, F = 1)
 
 
 @pytest.mark.parametrize("name,code,R", CASES)

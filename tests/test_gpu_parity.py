@@ -427,3 +427,55 @@ def test_every_window_shape(gpu):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import stress_windows
     assert stress_windows.run(24, opts=(("minimum_sum", "parallel", 10, "osd_0", 0),)) == 45
+
+
+# ---- BASELINE.json configs[3] and configs[4] ("configs_untested") ------------------------------------------
+def _circuit_dem(name, p_from=None, p_to=None):
+    from quits_amd.decoder.base import detector_error_model_to_matrix
+    from quits_amd.dem import Circuit
+    text = helpers.circuit_text(name) if p_to is None else helpers.circuit_text_at_p(name, p_from, p_to)
+    circ = Circuit(text)
+    return circ, detector_error_model_to_matrix(circ)
+
+
+@pytest.mark.parametrize("p,shots", [(0.001, 400), (0.006, 200)])
+def test_config3_p_sweep_points_bit_exact(gpu, p, shots):
+    """configs[3]: the [[144,12,12]] single window at the two ends of the p-sweep (p = 1e-3: BP converges on ~98 % of the shots;
+    p = 6e-3: practically every shot goes through OSD), device against the oracle's double-precision ldpc-order decoder."""
+    circ, (H, L, pri) = _circuit_dem("bb144_custom_r12_p%g" % p)
+    synd, obs, _ = orc.sample_dem(H, L, pri, seed=606, shot0=0, B=shots)
+    err, status, dec = _gpu_decode(H, pri, synd, 50, osd="osd_0")
+    g, prm = _oracle(H, pri, 50, "osd_0")
+    ref, flags, grid = g.decode_batch(synd, prm, return_grid=True)
+    assert np.array_equal((status >> 16) & 1, flags[:, 0]) and np.array_equal(status & 0x3FFF, flags[:, 1])
+    assert np.array_equal((status >> 14) & 1, (grid[:, 0] != g.grid[0]).astype(int))
+    assert np.array_equal((status >> 20) & 0xFFF, np.minimum(flags[:, 2], 4095)), "pivot counts differ"
+    assert np.array_equal(err, ref)
+    conv = flags[:, 0].mean()
+    assert (conv > 0.9) if p == 0.001 else (conv < 0.05), conv
+
+
+@pytest.mark.parametrize("osd,order,shots,max_iter", [("osd_0", 0, 32, 30), ("osd_cs", 1, 8, 30)])
+def test_config4_qlp_sliding_window_bit_exact(gpu, osd, order, shots, max_iter):
+    """configs[4]: QLP [[1020,136]], cardinal circuit, R = 20, sliding window W = 3 F = 1 (20 windows of 1350 x 18900: 77-wide
+    checks -> separate sign words, 22-word OSD rows, the 128-register BP instantiation), OSD-0 and OSD-CS order 1, at
+    p = 1e-3 (at the fixture's p = 3e-3 the code is above threshold).  Device driver against the oracle's loop."""
+    from quits_amd.decoder import sliding_window_bposd_circuit_mem
+    from quits_amd.decoder.base import spacetime, window_count
+    name, R = "qlp1020_cardinal_r20_p0.003", 20
+    circ, (H, L, pri) = _circuit_dem(name, 0.003, 0.001)
+    cd = helpers.code("qlp1020")
+    hz, lz = cd["hz"], cd["lz"]
+    nz = hz.shape[0]
+    det, obs, _ = orc.sample_dem(H, L, pri, seed=44, shot0=0, B=shots)
+    pred = sliding_window_bposd_circuit_mem(det, circ, hz, lz, 3, 1, max_iter=max_iter, osd_order=order,
+                                            bp_method="minimum_sum", schedule="parallel", osd_method=osd)
+    ncr, _, _ = window_count(R, 3, 1)
+    checks, commits, priors, updates = spacetime(circ, hz, 3, 1, ncr)
+    assert len(checks) == 20 and checks[1].shape == (1350, 18900)
+    wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None, "row0": k * nz}
+            for k in range(len(checks))]
+    prm = orc.make_params("minimum_sum", "parallel", max_iter, osd, order, 1.0, orc.FORM_LDPC_F64)
+    ref, stats = orc.sliding_window_decode(wins, nz, det, prm, device_grid=True)
+    assert stats["osd_calls"] > shots, "OSD is not exercised"
+    assert pred.shape == (shots, lz.shape[0]) and np.array_equal(pred, ref.astype(np.int64))

@@ -133,16 +133,20 @@ def _csc_dump(prefix, mat, out):
     out[prefix + "_indices"] = mat.indices.astype(np.int32)
 
 
-def gen_windows():
-    """G3 + G7: reference spacetime() on the DEM produced by quits_amd.dem (duck-typed)."""
+def gen_windows(which="std"):
+    """G3 + G7: reference spacetime() on the DEM produced by quits_amd.dem (duck-typed).  `qlp`: BASELINE configs[4]
+    (QLP [[1020,136]], R = 20, W = 3, F = 1: 20 windows of 1350 x 18900)."""
     import_reference()
     from quits.decoder.base import detector_error_model_to_matrix, spacetime
     from quits_amd.dem import Circuit
 
     os.makedirs(os.path.join(GOLD, "windows"), exist_ok=True)
-    for cname, code, R, grid in (("bb72_custom_r6_p0.003", "bb72", 6, ((3, 1), (5, 3), (8, 1), (4, 2))),
-                                 ("bb144_custom_r12_p0.003", "bb144", 12, ((3, 1), (5, 3))),
-                                 ("hgp225_cardinal_r3_p0.01", "hgp225", 3, ((3, 1), (2, 1)))):
+    sets = (("bb72_custom_r6_p0.003", "bb72", 6, ((3, 1), (5, 3), (8, 1), (4, 2))),
+            ("bb144_custom_r12_p0.003", "bb144", 12, ((3, 1), (5, 3))),
+            ("hgp225_cardinal_r3_p0.01", "hgp225", 3, ((3, 1), (2, 1))))
+    if which == "qlp":
+        sets = (("qlp1020_cardinal_r20_p0.003", "qlp1020", 20, ((3, 1),)),)
+    for cname, code, R, grid in sets:
         circ = Circuit(_load_text(cname))
         hz = _load_code(code)["hz"]
         H, L, pri = detector_error_model_to_matrix(circ.detector_error_model())
@@ -166,6 +170,8 @@ def gen_windows():
                     _csc_dump("%s_U%d" % (tag, k), d[k], out)
         np.savez_compressed(os.path.join(GOLD, "windows", cname + ".npz"), **out)
         print("windows:", cname, H.shape, H.nnz)
+    if which == "qlp":
+        return
     # G7: window-count table straight from the reference's arithmetic (sliding_window.py:134-141) by running it
     rows = []
     from quits.decoder.sliding_window import sliding_window_phenom_mem
@@ -346,6 +352,8 @@ if __name__ == "__main__":
         gen_dem_merge()
     if what in ("all", "windows"):
         gen_windows()
+    if what == "qlpwin":
+        gen_windows("qlp")
     if what in ("all", "gf2"):
         gen_gf2()
     if what in ("all", "loop"):
