@@ -28,6 +28,72 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+NUM_CU = 256               # ... 256 CUs, 4 SIMD-32 each, 2.4 GHz max clock
+CLOCK_HZ = 2.4e9
+
+_CPU = {}
+
+
+def _cpu_worker(lo_hi):
+    """One slice of the CPU baseline: the oracle (double precision, ldpc's update order, exact LLRs) through the same window plan."""
+    import oracle as orc
+    lo, hi = lo_hi
+    t = time.perf_counter()
+    ref, _ = orc.sliding_window_decode(_CPU["wins"], _CPU["nz"], _CPU["det"][lo:hi], _CPU["prm"])
+    return lo, ref, time.perf_counter() - t
+
+
+def cpu_baseline(args, circ, hz, R, W, F, batch, plan, gpu_value):
+    """the reference's decoder is ldpc.BpOsdDecoder, absent here and on the GPU box
+    (profiles/r02_probe_ldpc_stim.txt) -> kind "port": oracle/qd_oracle.c timed on one core and on every core this process may
+    use (decoders rebuilt per worker, shot slices over a multiprocessing pool), on a bounded sample of the first timed batch."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    from quits_amd.decoder.base import spacetime, window_count
+    ncpu = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            ncpu = max(1, min(ncpu, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    ns1 = min(args.cpu_shots, args.shots)
+    nsa = min(args.shots, ns1 * ncpu)
+    det_h = batch[0][:nsa].cpu().numpy()
+    obs_h = batch[1][:nsa].cpu().numpy()
+    ncr, _, _ = window_count(R, W, F)
+    checks, commits, priors, updates = spacetime(circ, hz, W, F, ncr)
+    wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None,
+             "row0": F * k * hz.shape[0]} for k in range(len(checks))]
+    _CPU.update(wins=wins, nz=hz.shape[0], det=det_h,
+                prm=orc.make_params(args.bp_method, args.schedule, args.max_iter, args.osd_method, args.osd_order, 1.0, orc.FORM_LDPC_F64))
+    orc.lib()
+    _, ref1, cpu1_s = _cpu_worker((0, ns1))
+    res = {}
+    if ncpu > 1:
+        sl = [(i * nsa // ncpu, (i + 1) * nsa // ncpu) for i in range(ncpu)]
+        t = time.perf_counter()
+        with mp.get_context("fork").Pool(ncpu) as pool:          # children never touch the GPU
+            parts = sorted(pool.map(_cpu_worker, sl), key=lambda r: r[0])
+        cpua_s = time.perf_counter() - t
+        ref = np.concatenate([p[1] for p in parts])
+    else:
+        ref, cpua_s = ref1, cpu1_s
+    cpu_fail = int((ref != obs_h[:len(ref)]).any(axis=1).sum())
+    gpu_pred = plan.decode(batch[0][:len(ref)]).cpu().numpy()
+    gpu_fail = int((gpu_pred != obs_h[:len(ref)]).any(axis=1).sum())
+    sample = ("first %d shots of the first timed batch, same window plan and parameters; oracle/qd_oracle.c (double precision, ldpc's "
+              "update order, exact LLRs)")
+    res["cpu_baseline"] = {
+        "value": len(ref) / cpua_s, "unit": "shots/s", "cores": ncpu, "kind": "port",
+        "sample": sample % len(ref) + ", %d processes over shot slices" % ncpu,
+        "ler": cpu_fail / len(ref), "gpu_ler_same_sample": gpu_fail / len(ref),
+        "shots_with_identical_prediction": float((ref == gpu_pred).all(axis=1).mean()),
+        "speedup_vs_all_cores": gpu_value / (len(ref) / cpua_s)}
+    res["cpu_baseline_1core"] = {"value": ns1 / cpu1_s, "unit": "shots/s", "cores": 1, "kind": "port", "sample": sample % ns1 + ", one thread",
+                                 "speedup_vs_cpu_core": gpu_value / (ns1 / cpu1_s)}
+    return res
 
 
 def main():
@@ -93,7 +159,6 @@ def main():
     decs = plan.decoders()
     for d in decs:
         d.reserve(min(args.shots, 1 << 16))
-        d.set_profiling(True)
 
     # ---- synthetic inputs, resident in HBM before the timed region
     sampler = DemSampler(H, Lobs, pri)
@@ -112,9 +177,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    for d in decs:
-        d.profile(reset=True)
 
+    # ---- the timed region: K steps, no event recording inside (the per-launch hipEventCreate/Record pairs were
+    # part of the number)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -132,10 +197,21 @@ def main():
     # the path's only collective: 16 bytes over RCCL
     n_err, n_shots = parallel.reduce_counts(dist, int(fails.item()), args.shots * args.steps, "cuda")
 
-    # ---- per-kernel device time (HIP events recorded by the library on the launch stream) and algorithmic bytes
+    # ---- the same K steps once more with the library's HIP events on (recorded on the launch stream around each kernel):
+    # per-kernel device time for the roofline object
+    for d in decs:
+        d.set_profiling(True)
+        d.profile(reset=True)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for i in range(args.warmup, nbatch):
+        step(i)
+    torch.cuda.synchronize()
+    elapsed_ev = time.perf_counter() - t1
     prof = {"bp_ms": 0.0, "osd_ms": 0.0, "bp_launches": 0, "osd_launches": 0}
     for d in decs:
         pr = d.profile(reset=True)
+        d.set_profiling(False)
         for k in prof:
             prof[k] += pr[k]
     st = torch.cat([t for (_, t) in stats])
@@ -143,20 +219,43 @@ def main():
     total_iters = int(iters.sum().item())
     conv_frac = float(((st >> 16) & 1).float().mean().item())
     osd_frac = float(((st >> 17) & 1).float().mean().item())
-    # B_iter = (4E + 2n) * sizeof(msg) per shot per BP iteration, per window graph
-    b_iter = {}
+    off_grid = int(((st >> 14) & 3).ne(0).sum().item())
+    bp_s = prof["bp_ms"] / 1e3
+    nlaunch = max(1, prof["bp_launches"])
+
+    # ---- per-window work of one BP iteration of one shot
+    #   B_iter = (4E + 2n) * 4 bytes of message traffic (what an HBM-resident formulation moves);
+    #   LDS kernel: wave-steps of the check pass (64 checks x one edge) and of the bit pass (64 faults x one gather), padded as
+    #   the kernel pads them (slots sorted by degree, a wavefront runs to its largest degree; check trips in fours)
+    from scipy.sparse import csr_matrix, csc_matrix
+    per_dec = {}
     for w in plan.windows:
         info = w["graph"].info()
-        b_iter[id(w["dec"])] = (4 * info["nnz"] + 2 * info["n"]) * 4
+        rec = {"b_iter": (4 * info["nnz"] + 2 * info["n"]) * 4, "n": info["n"], "m": info["m"], "nnz": info["nnz"]}
+        per_dec[id(w["dec"])] = rec
+    def wave_steps(Hm):
+        rdeg = np.sort(np.diff(csr_matrix(Hm).indptr))[::-1]
+        cdeg = np.sort(np.diff(csc_matrix(Hm).indptr))[::-1]
+        ws_c = sum((int(rdeg[i:i + 64].max()) + 3) // 4 * 4 for i in range(0, len(rdeg), 64))
+        ws_b = sum(int(cdeg[i:i + 64].max()) for i in range(0, len(cdeg), 64))
+        return ws_c, ws_b
+    for w, Hm in zip(plan.windows, plan.window_matrices()):
+        per_dec[id(w["dec"])]["ws"] = wave_steps(Hm)
     algo_bytes = 0
+    ws_c_tot = ws_b_tot = 0
+    hbm_algo = 0
     for (k, s_t) in stats:
-        algo_bytes += int((s_t & 0x3FFF).to(torch.int64).sum().item()) * b_iter[id(plan.windows[k]["dec"])]
-    bp_s = prof["bp_ms"] / 1e3
-    achieved = (algo_bytes / bp_s / 1e9) if bp_s > 0 else 0.0
+        rec = per_dec[id(plan.windows[k]["dec"])]
+        it_k = int((s_t & 0x3FFF).to(torch.int64).sum().item())
+        algo_bytes += it_k * rec["b_iter"]
+        ws_c_tot += it_k * rec["ws"][0]
+        ws_b_tot += it_k * rec["ws"][1]
+        nf = int((((s_t >> 16) & 1) == 0).sum().item())
+        hbm_algo += s_t.numel() * (rec["m"] + 4 * ((rec["n"] + 31) // 32) + 4) + nf * 4 * ((rec["n"] + 63) // 64 * 64)
 
     # HBM bytes per BP launch from the PMC passes of tools/profile_bench.sh (rocprofv3 cannot run inside this process);
     # only quoted when the committed profile was taken on this exact workload.
-    traffic, traffic_src, issue = None, None, None
+    traffic, traffic_src = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -164,17 +263,76 @@ def main():
             key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
             if key in pm and not general and args.code == "bb144":
                 traffic, traffic_src = pm[key]["bp_bytes_per_launch"], pm[key]["source"]
-                issue = pm[key].get("valu_issue")
         except (ValueError, KeyError):
             pass
 
+    if general:
+        achieved = (algo_bytes / bp_s / 1e9) if bp_s > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel": "qd_bp_edge_kernel", "avg_launch_ms": prof["bp_ms"] / nlaunch,
+                    "algorithmic_bytes_per_launch": algo_bytes / nlaunch,
+                    "note": "one message per edge in HBM: algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md "
+                            "8d); the kernel really moves a multiple of this (ldpc's forward/backward sweeps; the serial schedule "
+                            "re-reads a row per edge), see DESIGN.md"}
+    else:
+        # The LDS kernel's messages never leave the CU, so HBM cannot bound it ("report ... LDS bytes as the bound").
+        # What bounds it is vector-ALU issue: wave-instructions per edge from the compiler's assembly
+        # (profiles/k1_issue_model.json <- tools/isa_histogram.py), peak = 4 SIMDs x one wave-instruction per 2 clk
+        # (MI355X_MICROARCH.md: a wave64 instruction issues over 2 cycles on a SIMD-32) = 2.0 per CU per clk at 2.4 GHz.
+        mdl = {"check_pass_loop_4_edges": {"valu_fast": 16, "valu_slow": 38}, "bit_pass_gather_blocks": {"valu_fast": 31, "valu_slow": 34},
+               "bit_pass_gathers": 8}
+        mp = os.path.join(ROOT, "profiles", "k1_issue_model.json")
+        if os.path.exists(mp):
+            try:
+                mdl = json.load(open(mp))["summary"]
+            except (ValueError, KeyError):
+                pass
+        cf, cs = mdl["check_pass_loop_4_edges"]["valu_fast"] / 4.0, mdl["check_pass_loop_4_edges"]["valu_slow"] / 4.0
+        bf, bs = (mdl["bit_pass_gather_blocks"][k] / float(mdl["bit_pass_gathers"]) for k in ("valu_fast", "valu_slow"))
+        n_inst = ws_c_tot * (cf + cs) + ws_b_tot * (bf + bs)
+        issue_clk = ws_c_tot * (2 * cf + 4 * cs) + ws_b_tot * (2 * bf + 4 * bs)          # SIMD-cycles, fast class 2 clk, slow class 4
+        lds_clk = ws_c_tot * 2 + ws_b_tot * 4                                            # ds_read_b32 2 cycles, ds_read_b128 4 (conflict-free)
+        lds_bytes = ws_c_tot * 64 * 4 + ws_b_tot * 64 * 16
+        peak_inst = NUM_CU * 2.0 * CLOCK_HZ / 1e9
+        ach_inst = n_inst / bp_s / 1e9 if bp_s > 0 else 0.0
+        roofline = {
+            "bound": "valu", "achieved": ach_inst, "peak": peak_inst, "unit": "G wave-instructions/s", "frac": ach_inst / peak_inst,
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": "qd_bp_minsum_kernel",
+            "avg_launch_ms": prof["bp_ms"] / nlaunch,
+            "algorithmic_instructions_per_launch": n_inst / nlaunch,
+            "model": "VALU wave-instructions = check-pass wave-steps x %.2f + bit-pass wave-steps x %.2f (per edge, from "
+                     "profiles/r02_k1_isa_histogram.txt), summed over the BP iterations each shot really ran; per-node overhead "
+                     "outside the two edge loops is not counted, so `achieved` is a floor" % (cf + cs, bf + bs),
+            # the same instructions priced by class: two-operand add/sub/logic/shift/fma issue in 2 clk per wavefront per SIMD,
+            # compares / cndmask / min / max / med3 / three-operand logic / 64-bit shifts in 4 (profiles/r01f_valu_issue_rates.txt)
+            "frac_priced_by_class": issue_clk / (bp_s * NUM_CU * 4 * CLOCK_HZ) if bp_s > 0 else 0.0,
+            "lds": {"achieved": lds_bytes / bp_s / 1e9 if bp_s > 0 else 0.0, "peak": NUM_CU * 256 * CLOCK_HZ / 1e9, "unit": "GB/s",
+                    "frac_of_conflict_free_cycles": lds_clk / (bp_s * NUM_CU * CLOCK_HZ) if bp_s > 0 else 0.0,
+                    "note": "gathers only (4 B per check-pass edge, 16 B per bit-pass edge); LDS-array cycles at the conflict-free "
+                            "rate of MI355X_MICROARCH.md (ds_read_b32 2 clk, ds_read_b128 4 clk per wavefront); bank conflicts add to it "
+                            "(tools/lds_model.py, profiles/r02_pmc_*)"},
+            "hbm": {"achieved": hbm_algo / bp_s / 1e9 if bp_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_algo / bp_s / 1e9 / HBM_PEAK_GBS if bp_s > 0 else 0.0,
+                    "algorithmic_bytes_per_launch": hbm_algo / nlaunch,
+                    "traffic_over_algorithmic": (traffic / (hbm_algo / nlaunch)) if traffic else None,
+                    "note": "detector bytes in, packed decisions + status out, posteriors of the shots that go to OSD"},
+            "hbm_resident_equivalent": {"bytes_per_launch": algo_bytes / nlaunch, "GBps": algo_bytes / bp_s / 1e9 if bp_s > 0 else 0.0,
+                                        "note": "SURVEY.md 8(d) B_iter = (4E+2n)*4 per shot-iteration: what a one-message-per-edge "
+                                                "layout in HBM would have to move in the same time (not bytes that cross HBM here)"},
+        }
+    roofline["osd_kernel_ms_per_launch"] = prof["osd_ms"] / max(1, prof["osd_launches"])
+
     value = n_shots / elapsed
     pl = n_err / n_shots
+    dinfo = decs[0].info()
     out = {
         "metric": "decoded shots/sec + logical-error-rate, [[144,12,12]] BB code, d rounds, p=0.003",
         "value": value, "unit": "shots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "arithmetic": ("f32 on channel LLRs rounded to multiples of 2^-%d: exact (no operation rounds; certified per shot), i.e. the "
+                       "result ldpc's f64 BpDecoder returns for those LLRs; %d of %d shot-windows left the fine grid"
+                       % (dinfo["llr_grid_bits"], off_grid, st.numel())) if dinfo["llr_grid_bits"] >= 0 else "f32, float(log((1-p)/p)) LLRs",
         "config": {"workload": "%s circuit %s, R=%d, Z basis; DEM %dx%d (E=%d); "
                                "%s %s BP max_iter=%d ms_scaling=1.0 + %s(%d); W=%d F=%d (%d window%s)"
                                % ({"bb144": "BB [[144,12,12]]", "bb72": "BB [[72,12,6]]", "hgp225": "HGP [[225,9,6]]", "qlp1020": "QLP [[1020,136]]"}[args.code],
@@ -184,48 +342,14 @@ def main():
         "logical_error_rate": pl, "ler_sigma": float(np.sqrt(max(pl * (1 - pl), 1e-30) / n_shots)),
         "lfr_per_round": 1.0 - (1.0 - pl) ** (1.0 / R),
         "bp_converged_frac": conv_frac, "osd_frac": osd_frac, "mean_bp_iters": total_iters / max(1, st.numel()),
+        "ms_per_step_with_kernel_events": 1e3 * elapsed_ev / args.steps,
         # early exit makes the work data-dependent -- shot-windows by BP iterations used (index = iterations)
         "bp_iters_hist": torch.bincount(iters.clamp(max=args.max_iter), minlength=args.max_iter + 1).tolist(),
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "qd_bp_edge_kernel" if general else "qd_bp_minsum_kernel", "avg_launch_ms": prof["bp_ms"] / max(1, prof["bp_launches"]),
-                     "algorithmic_bytes_per_launch": algo_bytes / max(1, prof["bp_launches"]),
-                     "note": ("algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the general kernel "
-                              "keeps one message per edge in HBM and really moves a multiple of this (ldpc's forward/backward "
-                              "sweeps; the serial schedule re-reads a row per edge), see DESIGN.md") if general else
-                             ("algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md 8d); the kernel "
-                              "keeps this message state in LDS, so the figure is the traffic an HBM-resident formulation "
-                              "would need, not bytes that cross HBM (see DESIGN.md section 5)"),
-                     "osd_kernel_ms_per_launch": prof["osd_ms"] / max(1, prof["osd_launches"]),
-                     # what actually bounds the LDS-resident kernel (from the committed SQ counter profile of this workload)
-                     "issue_bound": issue},
+        "roofline": roofline,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import oracle as orc
-        ns = min(args.cpu_shots, args.shots)
-        det_h = batches[args.warmup][0][:ns].cpu().numpy()
-        obs_h = batches[args.warmup][1][:ns].cpu().numpy()
-        from quits_amd.decoder.base import spacetime, window_count
-        ncr, _, _ = window_count(R, W, F)
-        checks, commits, priors, updates = spacetime(circ, hz, W, F, ncr)
-        wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None,
-                 "row0": F * k * hz.shape[0]} for k in range(len(checks))]
-        prm = orc.make_params(args.bp_method, args.schedule, args.max_iter, args.osd_method, args.osd_order, 1.0, orc.FORM_LDPC_F64)
-        t1 = time.perf_counter()
-        ref, cstat = orc.sliding_window_decode(wins, hz.shape[0], det_h, prm)
-        cpu_s = time.perf_counter() - t1
-        cpu_fail = int((ref != obs_h).any(axis=1).sum())
-        gpu_pred = plan.decode(batches[args.warmup][0][:ns]).cpu().numpy()
-        gpu_fail = int((gpu_pred != obs_h).any(axis=1).sum())
-        out["cpu_baseline"] = {
-            "value": ns / cpu_s, "unit": "shots/s", "cores": 1, "kind": "port",
-            "sample": "first %d shots of the first timed batch, same window plan and parameters; oracle/qd_oracle.c "
-                      "(double precision, ldpc's update order), one thread" % ns,
-            "ler": cpu_fail / ns, "gpu_ler_same_sample": gpu_fail / ns,
-            "shots_with_identical_prediction": float((ref == gpu_pred).all(axis=1).mean()),
-            "speedup_vs_cpu_core": value / (ns / cpu_s)}
+        out.update(cpu_baseline(args, circ, hz, R, W, F, batches[args.warmup], plan, value))
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -208,10 +208,63 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     std::vector<uint32_t> chk_adj32;
     if (adj32) chk_adj32.assign((size_t)max_rdeg_pad * m_pad, (uint32_t)(off_llr_ + dummy_bit * 4));
     else chk_adj16.assign((size_t)max_rdeg_pad * m_pad, (uint16_t)(off_llr_ + dummy_bit * 4));
+    // Order in which a check walks its edges.  Nothing the check pass computes depends on it (minimum, second minimum and the
+    // sign parity are symmetric; a tie for the minimum leaves min1 = min2, so it does not matter which edge carries the argmin
+    // label), so it is chosen for the LDS: step k of a wavefront is one ds_read_b32 gather, serviced in two groups of 32 lanes
+    // with bank = (address / 4) mod 32 (MI355X_MICROARCH.md, LDS), one extra cycle per additional distinct address on a bank.
+    // Greedy per group of 32 check slots: at every step each check takes, among its remaining edges, the one whose bank has
+    // the fewest distinct addresses so far in that step.  Headline window: 2918 -> 1463 LDS cycles per iteration for these
+    // gathers (1062 without any conflict; tools/lds_model.py).
+    std::vector<int32_t> step_of(nnz);              // CSR edge -> position in its check's walk
+    {
+        std::vector<std::vector<int>> rem(32);
+        std::vector<int> used_cnt(32), order32(32);
+        std::vector<std::vector<uint32_t>> used_addr(32);
+        for (int g0 = 0; g0 < m; g0 += 32) {
+            const int gn = std::min(32, m - g0);
+            int kmax = 0;
+            for (int l = 0; l < gn; ++l) {
+                const int i = chk_orig[g0 + l];
+                rem[l].clear();
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) rem[l].push_back(e);
+                kmax = std::max(kmax, rdeg[i]);
+            }
+            for (int k = 0; k < kmax; ++k) {
+                for (int b = 0; b < 32; ++b) { used_cnt[b] = 0; used_addr[b].clear(); }
+                int na = 0;
+                for (int l = 0; l < gn; ++l) if (!rem[l].empty()) order32[na++] = l;
+                std::stable_sort(order32.begin(), order32.begin() + na, [&](int a, int b) { return rem[a].size() > rem[b].size(); });
+                for (int x = 0; x < na; ++x) {
+                    std::vector<int> &r = rem[order32[x]];
+                    int best = 0, bestc = 1 << 30;
+                    for (int y = 0; y < (int)r.size(); ++y) {
+                        const uint32_t slot = (uint32_t)bit_slot_of[col_idx[r[y]]];
+                        const int b = (int)(slot & 31u);
+                        int c = used_cnt[b];
+                        for (uint32_t a : used_addr[b]) if (a == slot) { c = 0; break; }      // same address: a broadcast, free
+                        if (c < bestc) { bestc = c; best = y; if (c == 0) break; }
+                    }
+                    const uint32_t slot = (uint32_t)bit_slot_of[col_idx[r[best]]];
+                    bool dup = false;
+                    for (uint32_t a : used_addr[slot & 31u]) dup |= (a == slot);
+                    if (!dup) { used_addr[slot & 31u].push_back(slot); used_cnt[slot & 31u]++; }
+                    step_of[r[best]] = k;
+                    r.erase(r.begin() + best);
+                }
+            }
+        }
+    }
+    std::vector<int32_t> wpos(nnz);                 // CSC edge -> position in its check's walk (pos[] stays the natural position)
+    {
+        std::vector<int> fill(n, 0);
+        for (int i = 0; i < m; ++i)
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) wpos[cp[col_idx[e]] + fill[col_idx[e]]++] = step_of[e];
+    }
     for (int s = 0; s < m; ++s) {
         const int i = chk_orig[s];
-        for (int k = 0; k < rdeg[i]; ++k) {
-            const uint32_t off = (uint32_t)off_llr_ + (uint32_t)bit_slot_of[col_idx[row_ptr[i] + k]] * 4u;
+        for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+            const int k = step_of[e];
+            const uint32_t off = (uint32_t)off_llr_ + (uint32_t)bit_slot_of[col_idx[e]] * 4u;
             const size_t at = ((size_t)(k >> 2) * m_pad + s) * 4 + (k & 3);      // [group of 4 edges][slot][4]: one vector load per group
             if (adj32) chk_adj32[at] = off;
             else chk_adj16[at] = (uint16_t)off;
@@ -231,7 +284,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         std::memcpy(&bit_rec[rec_at(s, 0)], &l0, 4);
         for (int q = 0; q < cdeg[j]; ++q) {
             const int cs = chk_slot_of[ri[cp[j] + q]];
-            const int k = pos[cp[j] + q];
+            const int k = wpos[cp[j] + q];
             const int degp = chk_degp_w[cs / 64] & 0xFFFF;
             const int w = k >> 5, kend = std::min(degp - 32 * w, 32);
             const int sbit = kend - 1 - (k & 31);              // the check pass shifts signs in from bit 0 (v_alignbit)

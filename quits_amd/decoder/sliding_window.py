@@ -101,7 +101,7 @@ class DeviceWindowPlan:
                 Uk = csr_matrix(updates[k])
                 Uk = csr_matrix((Uk.data, Uk.indices, Uk.indptr), shape=(Uk.shape[0], graph.n))
                 U = GF2Matrix(Uk)
-            self.windows.append({"dec": dec, "graph": graph, "L": GF2Matrix(Lk), "U": U, "row0": int(row0[k])})
+            self.windows.append({"dec": dec, "graph": graph, "L": GF2Matrix(Lk), "U": U, "row0": int(row0[k]), "H": checks[k]})
         # the per-edge BP kernel (product_sum / serial) keeps its messages in HBM, one workspace per decoder: split a fixed
         # budget among the windows' decoders instead of letting each claim the single-decoder default
         decs = self.decoders()
@@ -110,6 +110,10 @@ class DeviceWindowPlan:
             budget = float(os.environ.get("QD_GENERAL_WS_GB", "96")) * (1 << 30)
             for d in decs:
                 d.set_workspace_limit(max(1 << 28, int(budget / len(decs))))
+
+    def window_matrices(self):
+        """Host copies of the window check matrices, in window order (bench.py derives its work model from them)."""
+        return [w["H"] for w in self.windows]
 
     def decoders(self):
         out = []

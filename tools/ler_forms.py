@@ -16,7 +16,7 @@ stand-in for ldpc.BpOsdDecoder:
   k1_grid / k1g_grid / k1_raw   (gpu mode) the HIP library itself: LDS kernel on its LLR grid (the product path), the
                 one-message-per-edge kernel on the same grid, and the LDS kernel with QD_FLAG_RAW_LLR (round-1 arithmetic)
 
-  python tools/ler_forms.py run <shots> <seed> <out.npz> [procs] [configs,comma,separated]      # CPU oracle
+  python tools/ler_forms.py run <shots> <seed> <out.npz> [procs] [configs,comma,separated] [first shot]   # CPU oracle
   python tools/ler_forms.py gpu <shots> <seed> <out.npz>                                        # on the GPU box
   python tools/ler_forms.py report <out.npz> [<out2.npz> ...]   # files of one seed are merged, seeds are pooled
 The GPU box grants 16 CPUs (cgroup), this container 8: a 10^6-shot double-precision column takes ~20 core-minutes."""
@@ -44,9 +44,9 @@ def _setup(names):
 
 
 def _chunk(args):
-    c, seed = args
+    c, seed, shot0 = args
     orc = _G["orc"]
-    det, obs, _ = orc.sample_dem(_G["H"], _G["L"], _G["pri"], seed=seed, shot0=c * CHUNK, B=CHUNK)
+    det, obs, _ = orc.sample_dem(_G["H"], _G["L"], _G["pri"], seed=seed, shot0=shot0 + c * CHUNK, B=CHUNK)
     out = {"obs": (obs.astype(np.int64) @ _G["w"]).astype(np.uint16)}
     for nm in _G["names"]:
         prm = orc.make_params("minimum_sum", "parallel", MAX_ITER, "osd_0", 0, 1.0, CONFIGS[nm][0])
@@ -58,14 +58,14 @@ def _chunk(args):
     return c, out
 
 
-def run(shots, seed, path, procs, names):
+def run(shots, seed, path, procs, names, shot0=0):
     import multiprocessing as mp
     nch = shots // CHUNK
     t0 = time.time()
     with mp.Pool(procs, initializer=_setup, initargs=(names,)) as pool:
-        res = sorted(pool.imap_unordered(_chunk, [(c, seed) for c in range(nch)], chunksize=1), key=lambda r: r[0])
+        res = sorted(pool.imap_unordered(_chunk, [(c, seed, shot0) for c in range(nch)], chunksize=1), key=lambda r: r[0])
     arrs = {"obs": np.concatenate([r[1]["obs"] for r in res])}
-    meta = {"config": NAME, "max_iter": MAX_ITER, "seed": seed, "shots": nch * CHUNK, "procs": procs,
+    meta = {"config": NAME, "max_iter": MAX_ITER, "seed": seed, "shot0": shot0, "shots": nch * CHUNK, "procs": procs,
             "seconds": time.time() - t0, "names": names, "max_abs_llr": {}}
     for nm in names:
         arrs[nm + "_pred"] = np.concatenate([r[1][nm][0] for r in res])
@@ -116,40 +116,58 @@ def gpu(shots, seed, path):
 
 
 def report(paths):
+    """Files are placed by (seed, first shot); a form counts on the shots every form of that seed covers."""
     from math import erfc, sqrt
     by_seed = {}
     for p in paths:
         z = np.load(p)
         m = json.loads(bytes(z["meta"]).decode())
-        ent = by_seed.setdefault(m["seed"], {"arr": {}, "names": [], "mx": {}, "shots": m["shots"], "extra": {}})
-        n = min(ent["shots"], m["shots"])
-        if "obs" in ent["arr"]:
-            assert np.array_equal(ent["arr"]["obs"][:n], z["obs"][:n]), "files of one seed disagree on the observables"
-        ent["shots"] = n
-        for k in z.files:
-            if k != "meta":
-                ent["arr"][k] = z[k]
-        ent["names"] += [nm for nm in m["names"] if nm not in ent["names"]]
-        ent["mx"].update(m["max_abs_llr"])
+        ent = by_seed.setdefault(m["seed"], {"pieces": [], "mx": {}, "extra": {}})
+        ent["pieces"].append((m.get("shot0", 0), m["shots"], m["names"], z))
+        for k, v in m["max_abs_llr"].items():
+            ent["mx"][k] = max(ent["mx"].get(k, 0.0), v)
         ent["extra"].update({k: v for k, v in m.items() if k.startswith("k1_")})
     seeds = sorted(by_seed)
-    names = [nm for nm in by_seed[seeds[0]]["names"] if all(nm in by_seed[sd]["names"] for sd in seeds)]
-    cat = lambda key: np.concatenate([by_seed[sd]["arr"][key][:by_seed[sd]["shots"]] for sd in seeds])
-    obs = cat("obs")
+    cols = {}
+    for sd in seeds:
+        ent = by_seed[sd]
+        n = max(a + b for a, b, _, _ in ent["pieces"])
+        obs, have_obs = np.zeros(n, np.uint16), np.zeros(n, bool)
+        arr = {}
+        for a, b, names, z in ent["pieces"]:
+            sl = slice(a, a + b)
+            assert not have_obs[sl].any() or np.array_equal(obs[sl][have_obs[sl]], z["obs"][:b][have_obs[sl]]), "observables disagree"
+            obs[sl] = z["obs"][:b]; have_obs[sl] = True
+            for nm in names:
+                pr_, it_, hv_ = arr.setdefault(nm, (np.zeros(n, np.uint16), np.zeros(n, np.uint8), np.zeros(n, bool)))
+                pr_[sl] = z[nm + "_pred"][:b]; it_[sl] = z[nm + "_iters"][:b]; hv_[sl] = True
+        ent["obs"], ent["arr"] = obs, arr
+    names = [nm for nm in by_seed[seeds[0]]["arr"] if all(nm in by_seed[sd]["arr"] for sd in seeds)]
+    obs_l, pred_l, it_l = [], {nm: [] for nm in names}, {nm: [] for nm in names}
+    for sd in seeds:
+        ent = by_seed[sd]
+        ok = np.ones(len(ent["obs"]), bool)
+        for nm in names:
+            ok &= ent["arr"][nm][2]
+        obs_l.append(ent["obs"][ok])
+        for nm in names:
+            pred_l[nm].append(ent["arr"][nm][0][ok]); it_l[nm].append(ent["arr"][nm][1][ok])
+        ent["covered"] = int(ok.sum())
+    obs = np.concatenate(obs_l)
     N = len(obs)
-    pred = {nm: cat(nm + "_pred") for nm in names}
+    pred = {nm: np.concatenate(pred_l[nm]) for nm in names}
+    iters = {nm: np.concatenate(it_l[nm]) for nm in names}
     fail = {nm: pred[nm] != obs for nm in names}
-    iters = {nm: cat(nm + "_iters") for nm in names}
     metas = [{"seed": sd, "max_abs_llr": by_seed[sd]["mx"]} for sd in seeds]
     ref = "ldpc_f64"
-    out = {"shots": N, "files": [os.path.basename(p) for p in paths], "seeds": seeds,
+    out = {"shots": N, "shots_per_seed": {str(sd): by_seed[sd]["covered"] for sd in seeds}, "files": len(paths), "seeds": seeds,
            "config": NAME + ", min-sum flooding max_iter=%d ms_scaling=1.0 + OSD-0" % MAX_ITER,
            "reference_form": ref, "device": {str(sd): by_seed[sd]["extra"] for sd in seeds}, "forms": {}}
     pr = fail[ref].mean()
     for nm in names:
         p = fail[nm].mean()
         rec = {"fails": int(fail[nm].sum()), "pL": p, "sigma_unpaired": sqrt(p * (1 - p) / N),
-               "max_abs_llr": max(m["max_abs_llr"][nm] for m in metas), "mean_iters": float(iters[nm].mean())}
+               "max_abs_llr": max(m["max_abs_llr"].get(nm, 0.0) for m in metas), "mean_iters": float(iters[nm].mean())}
         if nm != ref:
             b = int((fail[nm] & ~fail[ref]).sum())      # this form fails, the reference form does not
             c = int((~fail[nm] & fail[ref]).sum())
@@ -168,6 +186,7 @@ if __name__ == "__main__":
         gpu(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4])
     elif sys.argv[1] == "run":
         names = sys.argv[6].split(",") if len(sys.argv) > 6 else list(CONFIGS)
-        run(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else os.cpu_count(), names)
+        run(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else os.cpu_count(), names,
+            int(sys.argv[7]) if len(sys.argv) > 7 else 0)
     else:
         report(sys.argv[2:])
