@@ -115,12 +115,26 @@ def main():
     ap.add_argument("--window", type=int, nargs=2, default=None, metavar=("W", "F"))
     ap.add_argument("--cpu-shots", type=int, default=2000, help="bounded CPU-baseline sample (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dry-run-backend", default=None, help=argparse.SUPPRESS)   # tests: rank plumbing + collectives on CPU (gloo), no decoding
     args = ap.parse_args()
 
     from quits_amd import parallel
     rank, world, local_rank = parallel.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if args.dry_run_backend:
+        # the N > 1 branch without a GPU: join the group, barrier, the (errors, shots) SUM and the elapsed-time MAX
+        dist = parallel.init_distributed(args.dry_run_backend)
+        if dist is not None:
+            dist.barrier()
+        lo, hi = parallel.shard_range(args.shots * world, rank, world)
+        n_err, n_shots = parallel.reduce_counts(dist, rank + 1, hi - lo)
+        tmax = parallel.reduce_max(dist, float(rank + 1))
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "errors": n_err, "shots": n_shots, "tmax": tmax}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; the decoder has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -281,6 +281,9 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
 #define QD_OSD_TIER_FIRST 256
 #endif
 #define QD_OSD_KWR 6
+#ifndef QD_OSD_KWR0
+#define QD_OSD_KWR0 2
+#endif
 #define QD_OSD_KPT 20     // monotone keys a thread keeps in registers while a tier is drawn (n <= 20 * T; else re-read)
 
 // Sum of v over the workgroup; one barrier; `buf` = 2 x 64 words alternating with `phase` (entries beyond the wave count must be zero).
@@ -325,8 +328,11 @@ struct TierState { uint32_t lo_key, lo_idx; int sphase, exhausted, limit; };   /
 
 // Draws the next tier: the <= QD_OSD_TIER not yet consumed columns with the smallest (key, fault index), sorted, as fault
 // indices in order[0..cnt).  State: every column with (key, index) < (lo_key, lo_idx) has been consumed.
+#ifndef QD_OSD_TIER_INLINE
+#define QD_OSD_TIER_INLINE __forceinline__
+#endif
 template <int T>
-__device__ __noinline__ int qd_osd_draw_tier(const OsdRegArgs &a, const float *llr, uint64_t *sortbuf, uint16_t *order,
+__device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const OsdRegArgs &a, const float *llr, uint64_t *sortbuf, uint16_t *order,
                                              uint32_t *red, uint32_t *sumbuf, TierState &ts)
 {
     const int tid = threadIdx.x;
@@ -928,7 +934,10 @@ __device__ __noinline__ void qd_osd_sweep_pick(const OsdRegArgs &a, unsigned cha
 // the batch stays in Q planes 0..QD_PANEL_PLANES-1.  Returns the new pivot count; *done_out = syndrome explained.
 #define QD_PANEL_SLOTS 4
 #define QD_PANEL_PLANES 2   // (3 measured slower: late batches hold few pivots, the fixed cost of compaction + call exceeds a handful of barrier rounds)
-__device__ __noinline__ int qd_osd_panel_wave0(const OsdLds &S, const uint16_t *list, int nL, int npiv0, uint32_t outside_resid,
+#ifndef QD_OSD_PANEL_INLINE
+#define QD_OSD_PANEL_INLINE __forceinline__
+#endif
+__device__ QD_OSD_PANEL_INLINE int qd_osd_panel_wave0(const OsdLds &S, const uint16_t *list, int nL, int npiv0, uint32_t outside_resid,
                                                int m_pad, int *done_out)
 {
     const int lane = threadIdx.x & 63;
@@ -1025,7 +1034,7 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : T / 128)) qd_osd0_reg_ke
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     constexpr int NW = T / 64;
-    constexpr int KWR = QD_OSD_KWR;
+    constexpr int KWR = WFULL ? QD_OSD_KWR : QD_OSD_KWR0;      // Q planes kept in registers (OSD-0 stops after ~100 pivots at the usual operating points: two planes)
     const int nfail = *a.fail_count;
     OsdLds S;
     qd_osd_carve(smem, a.off, S);
@@ -1088,6 +1097,21 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : T / 128)) qd_osd0_reg_ke
             const int cnt = qd_osd_draw_tier<T>(a, llr, sortbuf, order, red, sumbuf, ts);
             lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
             if (ts.exhausted) break;
+            // The tier code is inlined and wants the registers (20 keys per thread): the elimination state is not carried
+            // across it but read back from its write-through LDS mirror, so nothing of it has to be spilled.
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = tid + i * T;
+                my_tb[i] = 0ull;
+#pragma unroll
+                for (int w = 0; w < KWR; ++w) my_q[i][w] = 0ull;
+                if (r < m) {
+                    my_tb[i] = S.tb[r];
+#pragma unroll
+                    for (int w = 0; w < KWR; ++w)
+                        if (w < kw_lds && w < ((npiv + 63) >> 6)) my_q[i][w] = S.q[(size_t)w * m_pad + r];
+                }
+            }
             QD_TICK(0)
             if (want_full && npiv >= a.rank) {
                 // factorisation complete: every further column of the order is a non-pivot column

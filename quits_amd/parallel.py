@@ -30,8 +30,10 @@ def init_distributed(backend: str = "nccl"):
     if world <= 1:
         return None
     import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")       # the container's hostname may not resolve
+    if "MASTER_PORT" not in os.environ:                     # the launcher (torch.distributed.run) owns the port
+        raise RuntimeError("WORLD_SIZE=%d but MASTER_PORT is not set: launch with `python -m torch.distributed.run --nnodes=1 "
+                           "--nproc-per-node N --master-addr 127.0.0.1 --master-port P ...`" % world)
     if not dist.is_initialized():
         dist.init_process_group(backend, rank=rank, world_size=world)
     return dist

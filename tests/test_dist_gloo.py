@@ -71,3 +71,39 @@ def test_two_ranks_equal_one_rank():
     assert one["shots"] == two["shots"] == 301
     assert one["errors"] == two["errors"]           # same global shot indices -> same syndromes -> same failures
     assert two["tmax"] == 2.0 and one["tmax"] == 1.0
+
+
+def _torchrun(world, script_args, port):
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("MASTER_PORT", None)
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args,
+                          env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_bench_rank_plumbing_two_processes():
+    """bench.py's N > 1 branch as the driver launches it (torch.distributed.run, one rank per GPU), up to the first CUDA call:
+    RANK / WORLD_SIZE / MASTER_* from the environment, the --gpus check, group start-up, barrier, the (errors, shots) SUM and the
+    elapsed-time MAX -- on gloo, because there is no GPU here."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    out = _torchrun(2, [bench, "--gpus", "2", "--shots", "1001", "--dry-run-backend", "gloo"], 29641)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"dry_run": True, "n_gpus": 2, "errors": 3, "shots": 2002, "tmax": 2.0}
+    bad = _torchrun(2, [bench, "--gpus", "1", "--dry-run-backend", "gloo"], 29643)
+    assert bad.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+    # without --dry-run-backend the next thing bench.py does is ask for a GPU, and says so
+    nogpu = _torchrun(2, [bench, "--gpus", "2"], 29645)
+    import torch
+    if not torch.cuda.is_available():
+        assert nogpu.returncode != 0 and "needs a GPU" in (nogpu.stderr + nogpu.stdout)
+
+
+def test_master_port_comes_from_the_launcher():
+    from quits_amd import parallel
+    env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    env.pop("MASTER_PORT", None)
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from quits_amd import parallel; parallel.init_distributed('gloo')" % ROOT],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "MASTER_PORT is not set" in out.stderr

@@ -9,7 +9,12 @@ from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
 name = sys.argv[1] if len(sys.argv) > 1 else "bb144_custom_r12_p0.003"
 shots = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 mi = int(sys.argv[3]) if len(sys.argv) > 3 else 50
-H, L, pri = helpers.dem_matrices(name)
+if os.path.exists(os.path.join(helpers.GOLD, "windows", name + ".npz")):
+    H, L, pri = helpers.dem_matrices(name)
+else:                                                    # any circuit fixture (e.g. bb144_custom_r12_p0.006): own DEM extractor
+    from quits_amd.decoder.base import detector_error_model_to_matrix
+    from quits_amd.dem import Circuit
+    H, L, pri = detector_error_model_to_matrix(Circuit(helpers.circuit_text(name)))
 det, obs = DemSampler(H, L, pri).sample(shots, seed=5)
 g = WindowGraph(H, pri); d = BatchDecoder(g, max_iter=mi, osd_method="osd_0")
 for stage, key in ((1, "bp_ms"), (3, "osd_ms")):

@@ -5,7 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, helpers
 from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
-H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+name = os.environ.get("FIXTURE", "bb144_custom_r12_p0.003")
+if os.path.exists(os.path.join(helpers.GOLD, "windows", name + ".npz")):
+    H, L, pri = helpers.dem_matrices(name)
+else:
+    from quits_amd.decoder.base import detector_error_model_to_matrix
+    from quits_amd.dem import Circuit
+    H, L, pri = detector_error_model_to_matrix(Circuit(helpers.circuit_text(name)))
 det, obs = DemSampler(H, L, pri).sample(int(os.environ.get("SHOTS", "32768")), seed=5)
 g = WindowGraph(H, pri); d = BatchDecoder(g, max_iter=50, osd_method=os.environ.get("OSD_METHOD", "osd_0"), osd_order=int(os.environ.get("OSD_ORDER", "0")))
 d.decode(det); torch.cuda.synchronize(); d.debug_counters()
