@@ -282,7 +282,7 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
 #endif
 #define QD_OSD_KWR 6
 #ifndef QD_OSD_KWR0
-#define QD_OSD_KWR0 2
+#define QD_OSD_KWR0 4
 #endif
 #define QD_OSD_KPT 20     // monotone keys a thread keeps in registers while a tier is drawn (n <= 20 * T; else re-read)
 
@@ -1034,7 +1034,7 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : T / 128)) qd_osd0_reg_ke
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;
     constexpr int NW = T / 64;
-    constexpr int KWR = WFULL ? QD_OSD_KWR : QD_OSD_KWR0;      // Q planes kept in registers (OSD-0 stops after ~100 pivots at the usual operating points: two planes)
+    constexpr int KWR = WFULL ? QD_OSD_KWR : QD_OSD_KWR0;      // Q planes kept in registers (~100 pivots at the headline, ~470 at p = 6e-3; 2, 4, 6 planes measured 10.5, 10.0, 10.6 ms at the headline and 178, 165, 161 ms at p = 6e-3)
     const int nfail = *a.fail_count;
     OsdLds S;
     qd_osd_carve(smem, a.off, S);
