@@ -89,7 +89,7 @@ def _forward_symptom(ops, num_det_of_meas, start, pauli):
     return flips
 
 
-@pytest.mark.parametrize("name", ["bb72_custom_r0_p0.003", "bb72_custom_r2_xbasis_mixed"])
+@pytest.mark.parametrize("name", ["bb72_custom_r0_p0.003", "bb72_custom_r2_xbasis_mixed", "bb72_custom_r2_alldet_p0.003"])
 def test_backward_extractor_against_forward_propagation(name):
     """Every fault component of every noise instruction, propagated forward by an independent Pauli-frame walk,
     must land on a DEM column with that symptom, and the merged probabilities must agree."""
@@ -220,3 +220,15 @@ def test_coordinates_are_ignored_and_noisy_measurements_rejected():
         with pytest.raises(NotImplementedError):
             flatten("R 0\n%s\nDETECTOR rec[-1]\n" % op)
     flatten("R 0\nM(0) 0\n")                                   # a zero argument is harmless
+
+
+def test_all_detectors_circuit_shapes():
+    """CircuitBuildOptions(get_all_detectors=True, noisy_zeroth_round=False, noisy_final_meas=True)
+    (qldpc_code/circuit_construction/circuit_build_options.py:13-15): X and Z detectors together.  The [[72,12,6]] code has 36
+    checks of each type; a Z-basis memory run of R = 2 rounds gives Z detectors in R + 2 blocks and X detectors in R blocks (the
+    first X measurement of a |0> state is random, and the final data measurement is in the Z basis)."""
+    dem = Circuit(helpers.circuit_text("bb72_custom_r2_alldet_p0.003")).detector_error_model()
+    assert dem.num_observables == 12
+    assert dem.num_detectors == 36 * (2 + 2) + 36 * 2, dem.num_detectors
+    H, L, pri = detector_error_model_to_matrix(dem)
+    assert H.shape[0] == dem.num_detectors and (np.diff(H.tocsc().indptr) > 0).all() and 0 < pri.min() and pri.max() < 0.5

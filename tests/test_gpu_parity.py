@@ -113,6 +113,7 @@ def test_osd_inconsistent_and_rank_deficient(gpu):
 @pytest.mark.parametrize("name,code,cases", [
     ("bb72_custom_r6_p0.003", "bb72", ((3, 1, 20), (5, 3, 12), (8, 1, 30), (9, 2, 30))),
     ("hgp225_cardinal_r3_p0.01", "hgp225", ((3, 1, 15), (2, 1, 15))),
+    ("bb72_custom_r2_xbasis_mixed", "bb72", ((2, 1, 15), (4, 1, 15), (3, 2, 15))),      # X-basis memory: hx / lx, four channel rates
 ])
 def test_sliding_window_matches_reference_loop(gpu, name, code, cases):
     """The batched device driver against the REFERENCE's own per-shot loop (golden G5: reference
@@ -124,6 +125,8 @@ def test_sliding_window_matches_reference_loop(gpu, name, code, cases):
     shp = tuple(z["shape"])
     synd = np.unpackbits(z["syndromes"], axis=1)[:, :shp[1]]
     cd = helpers.code(code)
+    if "xbasis" in name:
+        cd = {"hz": cd["hx"], "lz": cd["lx"]}
     circ = Circuit(helpers.circuit_text(name))
     for (W, F, mi) in cases:
         with warnings.catch_warnings():
@@ -479,3 +482,25 @@ def test_config4_qlp_sliding_window_bit_exact(gpu, osd, order, shots, max_iter):
     ref, stats = orc.sliding_window_decode(wins, nz, det, prm, device_grid=True)
     assert stats["osd_calls"] > shots, "OSD is not exercised"
     assert pred.shape == (shots, lz.shape[0]) and np.array_equal(pred, ref.astype(np.int64))
+
+
+def test_all_detectors_circuit_decodes(gpu):
+    """a circuit built with CircuitBuildOptions(get_all_detectors=True, noisy_zeroth_round=False,
+    noisy_final_meas=True): X and Z detectors in one record.  The reference's window slicer assumes one detector type per
+    round, so such a record is decoded as one BP-OSD problem over the whole DEM (ldpc's surface, B1): device against the
+    oracle, every output reproduces its syndrome, and using the X detectors too does not hurt the logical error rate."""
+    from quits_amd.decoder import BpOsdDecoder
+    circ, (H, L, pri) = _circuit_dem("bb72_custom_r2_alldet_p0.003")
+    assert H.shape[0] == 216
+    synd, obs, _ = orc.sample_dem(H, L, pri, seed=9, shot0=0, B=300)
+    err, status, _ = _gpu_decode(H, pri, synd, 30, osd="osd_0")
+    g, prm = _oracle(H, pri, 30, "osd_0")
+    ref, flags = g.decode_batch(synd, prm)
+    assert np.array_equal(err, ref) and np.array_equal((status >> 16) & 1, flags[:, 0])
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+    Ld = np.asarray(L.todense(), dtype=np.int64)
+    fails = ((err.astype(np.int64) @ Ld.T) % 2 != obs).any(axis=1).mean()
+    assert fails < 0.1, fails
+    dec = BpOsdDecoder(H, channel_probs=pri, max_iter=30, bp_method="minimum_sum", schedule="parallel", osd_method="osd_0", osd_order=0)
+    assert np.array_equal(dec.decode(synd[5].astype(int)), ref[5])

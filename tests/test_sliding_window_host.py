@@ -17,7 +17,16 @@ from quits_amd.decoder.sliding_window import phenom_window_matrices
 from quits_amd.dem import Circuit
 
 CASES = [("bb72_custom_r6_p0.003", "bb72", 6, ((3, 1, 20), (5, 3, 12), (8, 1, 30), (9, 2, 30)), 64),
-         ("hgp225_cardinal_r3_p0.01", "hgp225", 3, ((3, 1, 15), (2, 1, 15)), 24)]
+         ("hgp225_cardinal_r3_p0.01", "hgp225", 3, ((3, 1, 15), (2, 1, 15)), 24),
+         # X-basis memory experiment (basis="X": X-check detectors, lx observables) with four different channel rates
+         ("bb72_custom_r2_xbasis_mixed", "bb72", 2, ((2, 1, 15), (4, 1, 15), (3, 2, 15)), 48)]
+
+
+def _mats(code, name):
+    """(check matrix, logicals) the decoder is handed: hx / lx for an X-basis circuit, hz / lz otherwise (the reference's
+    argument names say `hz, lz` either way, decoder/bposd.py:54)."""
+    cd = helpers.code(code)
+    return (cd["hx"], cd["lx"]) if "xbasis" in name else (cd["hz"], cd["lz"])
 
 
 def _golden(name):
@@ -29,7 +38,8 @@ def _golden(name):
 @pytest.mark.parametrize("name,code,R,cases,nshots", CASES)
 def test_host_loop_matches_reference_loop(name, code, R, cases, nshots):
     z, synd = _golden(name)
-    cd = helpers.code(code)
+    hz, lz = _mats(code, name)
+    cd = {"hz": hz, "lz": lz}
     circ = Circuit(helpers.circuit_text(name))
     for (W, F, mi) in cases:
         for grid, tag in ((None, "f64"), ("device", "grid")):
@@ -50,7 +60,8 @@ def test_host_loop_matches_reference_loop(name, code, R, cases, nshots):
 @pytest.mark.parametrize("name,code,R,cases,nshots", CASES)
 def test_oracle_c_loop_matches_reference_loop(name, code, R, cases, nshots):
     z, synd = _golden(name)
-    cd = helpers.code(code)
+    hz, lz = _mats(code, name)
+    cd = {"hz": hz, "lz": lz}
     circ = Circuit(helpers.circuit_text(name))
     nz = cd["hz"].shape[0]
     for (W, F, mi) in cases:
@@ -67,7 +78,8 @@ def test_oracle_c_loop_matches_reference_loop(name, code, R, cases, nshots):
 @pytest.mark.parametrize("name,code,R,cases,nshots", CASES)
 def test_phenom_host_loop_matches_reference_loop(name, code, R, cases, nshots):
     z, synd = _golden(name)
-    cd = helpers.code(code)
+    hz, lz = _mats(code, name)
+    cd = {"hz": hz, "lz": lz}
     for (W, F, mi) in cases[:2]:
         opts = dict(bp_method="minimum_sum", max_iter=mi, schedule="parallel", osd_method="osd_0", osd_order=0,
                     error_rate=0.03, form=orc.FORM_LDPC_F64, llr_grid="device")

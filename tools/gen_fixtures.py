@@ -89,6 +89,15 @@ def gen_codes(with_qlp=False):
     c = code.build_circuit(strategy="custom", error_model=ErrorModel(0.002, 0.001, 0.003, 0.004), num_rounds=2, basis="X")
     _save_text("bb72_custom_r2_xbasis_mixed", c)
     meta["bb72_custom_r2_xbasis_mixed"] = dict(code="bb72", rounds=2, p=[0.002, 0.001, 0.003, 0.004], basis="X")
+    # every CircuitBuildOptions switch away from its default (circuit_build_options.py:13-15): X and Z detectors together,
+    # noiseless zeroth round, noisy final measurement
+    from quits.qldpc_code.circuit_construction.circuit_build_options import CircuitBuildOptions
+    c = code.build_circuit(strategy="custom", error_model=ErrorModel(0.003, 0.003, 0.003, 0.003), num_rounds=2, basis="Z",
+                           circuit_build_options=CircuitBuildOptions(get_all_detectors=True, noisy_zeroth_round=False,
+                                                                     noisy_final_meas=True))
+    _save_text("bb72_custom_r2_alldet_p0.003", c)
+    meta["bb72_custom_r2_alldet_p0.003"] = dict(code="bb72", rounds=2, p=0.003, basis="Z", get_all_detectors=True,
+                                                noisy_zeroth_round=False, noisy_final_meas=True)
     c = code.build_circuit(strategy="custom", error_model=ErrorModel(0.003, 0.003, 0.003, 0.003), num_rounds=0, basis="Z")
     _save_text("bb72_custom_r0_p0.003", c)
     meta["bb72_custom_r0_p0.003"] = dict(code="bb72", rounds=0, p=0.003)
@@ -239,10 +248,11 @@ def gen_loop():
     os.makedirs(os.path.join(GOLD, "loop"), exist_ok=True)
     for cname, code, R, N, cases in (
             ("bb72_custom_r6_p0.003", "bb72", 6, 192, ((3, 1, 20), (5, 3, 12), (8, 1, 30), (9, 2, 30))),
-            ("hgp225_cardinal_r3_p0.01", "hgp225", 3, 48, ((3, 1, 15), (2, 1, 15)))):
+            ("hgp225_cardinal_r3_p0.01", "hgp225", 3, 48, ((3, 1, 15), (2, 1, 15))),
+            ("bb72_custom_r2_xbasis_mixed", "bb72", 2, 96, ((2, 1, 15), (4, 1, 15), (3, 2, 15)))):      # X-basis memory: hx, lx
         circ = Circuit(_load_text(cname))
         cd = _load_code(code)
-        hz, lz = cd["hz"], cd["lz"]
+        hz, lz = (cd["hx"], cd["lx"]) if "xbasis" in cname else (cd["hz"], cd["lz"])
         H, L, pri = detector_error_model_to_matrix(circ.detector_error_model())
         synd, obs, _ = orc.sample_dem(H, L, pri, seed=20260929, shot0=0, B=N)
         out = {"syndromes": np.packbits(synd, axis=1), "observables": np.packbits(obs, axis=1),
