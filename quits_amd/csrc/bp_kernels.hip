@@ -39,6 +39,15 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
 #define QD_BP_MINWAVES 8   // waves per SIMD the register allocator must leave room for (8 = two 1024-thread workgroups per CU)
 #endif
 
+// min(a, |b|) as the single instruction it is: fminf() makes the compiler quiet a possible signalling NaN first
+// (v_max_f32 x, x, x -- one more 4-clock instruction per four edges); neither operand can be a NaN here.
+__device__ __forceinline__ float qd_min_abs(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // One edge of the check pass.
 //   off  = LDS address of the fault's posterior (doubles as the edge's label for the argmin bookkeeping); the kernel's
 //          dynamic LDS starts at address 0 (checked on entry), so the packed 16-bit offsets are used as addresses as they are
@@ -57,7 +66,7 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
         neww = __builtin_amdgcn_alignbit(neww, __float_as_uint(bm_) - 1u, 31);   /* neww = neww << 1 | (bm_ <= 0) */ \
         idx = (ab_ < a1) ? (off) : idx;                                                                      \
         a2 = __builtin_amdgcn_fmed3f(a1, a2, ab_);                                                           \
-        a1 = fminf(a1, ab_);                                                                                 \
+        a1 = qd_min_abs(a1, bm_);                                                                            \
     }
 
 // Bit pass, one edge.  rec = (LDS byte offset of the check state) << 16 | where its sign lives.

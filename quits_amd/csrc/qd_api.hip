@@ -179,7 +179,9 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int neg_words_ = (max_rdeg_pad + 31) / 32;
     const int off_chk_ = 0, off_cneg_ = (m_pad + 4) * 16;
     const int off_llr_ = off_cneg_ + (sign_mode == 2 ? align16((neg_words_ - 1) * m_pad * 4) : 0);
-    const int adj32 = (off_llr_ + (n_pad + 1) * 4 > 65535) ? 1 : 0;
+    // 32-bit offsets always: the 16-bit packing halves 66 KB of L2-resident adjacency but costs one unpacking instruction per
+    // edge in a loop that is bound by vector-ALU issue (headline BP 62.0 -> 60.4 ms per 65536 shots); QD_ADJ16 brings it back
+    const int adj32 = (off_llr_ + (n_pad + 1) * 4 > 65535 || !std::getenv("QD_ADJ16")) ? 1 : 0;
     const int rec_words = ((1 + max_cdeg) + 3) & ~3;
     std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0);
     std::vector<int32_t> chk_degp_w(m_pad / 64, 0);
