@@ -58,7 +58,6 @@ __device__ __forceinline__ float qd_min_abs(float a, float b)
 #define QD_CHECK_EDGE(off, sb)                                                                               \
     {                                                                                                        \
         const float L_ = *(const __attribute__((address_space(3))) float *)(uintptr_t)(uint32_t)(off);       \
-        us ^= (L_ <= 0.f);                                                                                   \
         const float mag_ = ((off) == idx_old) ? st.y : st.x;                                                 \
         const float prev_ = __uint_as_float(((sgnw >> (sb)) & 1u) << 31 | __float_as_uint(mag_));            \
         const float bm_ = L_ - prev_;                  /* bit->check message, "total minus own" */            \
@@ -89,6 +88,7 @@ __device__ __forceinline__ qd_u32x4 qd_lds_gather16(uint32_t lds_addr)
 #define QD_BIT_WAIT2(a, b) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory")
 #define QD_BIT_WAIT3(a, b, c) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory")
 #define QD_BIT_WAIT4(a, b, c, d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory")
+#define QD_BIT_FLIP(rec) __hip_atomic_fetch_xor((__attribute__((address_space(3))) uint32_t *)(uintptr_t)(((rec) >> 16) + 12u), 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #define QD_BIT_USE(rec, st_)                                                                                 \
     {                                                                                                        \
         const uint32_t meta_ = (st_).w;                                                     \
@@ -110,7 +110,8 @@ __device__ __forceinline__ qd_u32x4 qd_lds_gather16(uint32_t lds_addr)
 // State of a check in LDS (16 bytes, one ds_read_b128):  x = min1 * alpha,  y = min2 * alpha,
 //   z = SIGN bits of the outgoing messages on edges 0..31; inside a word, edge k sits at bit (edges_in_word - 1 - k)
 //       (sign of check->bit message k = syndrome ^ parity of all incoming signs ^ incoming sign k),
-//   w = slot of the argmin fault (bits 0..15) | (sign mode 1: sign bits of edges 32..46) << 16 | syndrome bit << 31.
+//   w = slot of the argmin fault (bits 0..15) | (sign mode 1: sign bits of edges 32..43) << 16 | parity of the hard decisions of
+//       the check's faults << 30 (flipped by the bit pass) | syndrome bit << 31.
 // Sign mode 2 (checks wider than 44): edges 32.. keep their sign words in `csgn_hi`.
 template <int T, int NCH, int SM, typename ADJ4, int MW>
 __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, DecodeArgs a)
@@ -192,13 +193,15 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
             const uint32_t synd = meta >> 31;
             const int dw = g.chk_degp_w[__builtin_amdgcn_readfirstlane(c) >> 6];       // scalar load
             const int degp = dw & 0xFFFF, wmax = dw >> 16;                             // trip count (multiple of 4), largest degree in this wavefront
-            bool us = (synd != 0u);
+            // syndrome of the hard decision: the bit pass flips bit 30 of this word once for every fault on this check that it
+            // decided to be 1 (a few dozen faults per shot), so the parity test costs nothing per edge here
+            const bool us = (((meta >> 31) ^ (meta >> 30)) & 1u) != 0u;
             uint32_t idx = llr_base + (0xFFFFu << 2);
             float a1 = FLT_MAX, a2 = FLT_MAX;
             uint32_t neg0 = 0u, neg1 = 0u, npar = 0u;
             for (int k0 = 0; k0 < degp; k0 += 32) {
                 uint32_t sgnw = __float_as_uint(st.z);
-                if (SM == 1 && k0 != 0) sgnw = (meta >> 16) & 0x7FFFu;
+                if (SM == 1 && k0 != 0) sgnw = (meta >> 16) & 0x0FFFu;
                 if (SM == 2 && k0 != 0) sgnw = csgn_hi[((k0 >> 5) - 1) * m_pad + c];
                 uint32_t neww = 0u;
                 const int kend = min(degp - k0, 32);                // multiple of 4
@@ -236,7 +239,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
             if (SM == 2)
                 for (int k0 = 32; k0 < degp; k0 += 32) csgn_hi[((k0 >> 5) - 1) * m_pad + c] ^= flip;
             uint32_t nmeta = ((idx - llr_base) >> 2) | (synd << 31);
-            if (SM == 1) nmeta |= ((neg1 ^ flip) & 0x7FFFu) << 16;
+            if (SM == 1) nmeta |= ((neg1 ^ flip) & 0x0FFFu) << 16;      // at most 44 edges: signs 32..43 in bits 16..27; bit 30 is the decision parity
             chk[c] = make_float4(a1 * alpha, a2 * alpha, __uint_as_float(neg0 ^ flip), __uint_as_float(nmeta));
         }
         QD_BP_TICK(0)
@@ -298,6 +301,15 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
             }
             llr[b] = acc;
             trip |= (sabs >= s_lim);
+            if (acc <= 0.f) {
+                // hard decision 1 (rare): tell the fault's checks -- one LDS atomic per edge on bit 30 of the state's last word
+                // (records beyond the degree point at the dummy check; readers of the word ignore that bit)
+                QD_BIT_FLIP(r0.y) QD_BIT_FLIP(r0.z) QD_BIT_FLIP(r0.w)
+                if (NCH > 1 && b0 < g.bit_thr[3]) { QD_BIT_FLIP(r1.x) QD_BIT_FLIP(r1.y) QD_BIT_FLIP(r1.z) QD_BIT_FLIP(r1.w) }
+                if (NCH > 2 && b0 < g.bit_thr[7]) { QD_BIT_FLIP(r2.x) QD_BIT_FLIP(r2.y) QD_BIT_FLIP(r2.z) QD_BIT_FLIP(r2.w) }
+                if (NCH > 3 && b0 < g.bit_thr[11]) { QD_BIT_FLIP(r3.x) QD_BIT_FLIP(r3.y) QD_BIT_FLIP(r3.z) QD_BIT_FLIP(r3.w) }
+                if (NCH > 4 && b0 < g.bit_thr[15]) { QD_BIT_FLIP(r4.x) }
+            }
         }
         QD_BP_TICK(2)
         __syncthreads();

@@ -13,7 +13,7 @@ Cross-compiles for gfx950; needs no GPU."""
 import argparse, json, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "quits_amd", "csrc")
-DEFAULT = "qd_bp_minsum_kernelILi1024ELi2ELi1E15HIP_vector_typeIjLj2EELi8E"      # the headline window's instantiation
+DEFAULT = "qd_bp_minsum_kernelILi1024ELi2ELi1E15HIP_vector_typeIjLj4EELi8E"      # the headline window's instantiation
 
 SLOW = re.compile(r"^v_(cmp|cmpx|cndmask|min|max|med3|lshl_or|and_or|or3|xad|bfi|bfe|alignbit|alignbyte|lshl_add|add_lshl|add3|"
                   r"lshlrev_b64|lshrrev_b64|ashrrev_i64|readfirstlane|readlane|writelane|mad_|mul_lo|mul_hi|perm|sad|pk_|"
