@@ -504,3 +504,41 @@ def test_all_detectors_circuit_decodes(gpu):
     assert fails < 0.1, fails
     dec = BpOsdDecoder(H, channel_probs=pri, max_iter=30, bp_method="minimum_sum", schedule="parallel", osd_method="osd_0", osd_order=0)
     assert np.array_equal(dec.decode(synd[5].astype(int)), ref[5])
+
+
+def test_ler_agreement_with_double_precision_oracle_2e5_shots(gpu):
+    """north_star: logical error rate within Monte-Carlo error of the reference arithmetic on identical syndromes.  Golden: the
+    oracle's DOUBLE-precision ldpc-order decoder on the first 200 000 Philox-sampled shots (seed 1) of the headline configuration,
+    on the exact channel LLRs (`ldpc_f64`) and on the 2^-11 grid (`ldpc_f64_q11`); made by tools/ler_forms.py in 20 core-minutes.
+      * the device's predictions equal the grid column on every one of the 200 000 shots (iteration counts too);
+      * its logical error rate is within one sigma of the exact-LLR column, paired (McNemar) and unpaired.
+    (10^6 and 2 x 10^6 shot versions of the same comparison: profiles/r02_ler_forms_*.json.)"""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, DemSampler, GF2Matrix, WindowGraph
+    z = np.load(helpers.GOLD + "/ler/bb144_p0.003_seed1_first200k.npz")
+    N = len(z["obs"])
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    smp, g, Lm = DemSampler(H, L, pri), WindowGraph(H, pri), GF2Matrix(L)
+    dec = BatchDecoder(g, max_iter=50, osd_method="osd_0")
+    assert dec.info()["llr_grid_bits"] == 11
+    w = (1 << torch.arange(L.shape[0], device="cuda")).to(torch.int32)
+    pred, its, obs = [], [], []
+    for c0 in range(0, N, 50000):
+        det, ob = smp.sample(50000, seed=1, shot0=c0)
+        bits, status = dec.decode(det)
+        assert not (status & (3 << 14)).any()
+        p = torch.zeros((50000, L.shape[0]), dtype=torch.uint8, device="cuda")
+        Lm.xor_apply(bits, p, accumulate=False)
+        pred.append((p.to(torch.int32) * w).sum(1).cpu().numpy().astype(np.uint16))
+        obs.append((ob.to(torch.int32) * w).sum(1).cpu().numpy().astype(np.uint16))
+        its.append((status & 0x3FFF).cpu().numpy().astype(np.uint8))
+    pred, obs, its = np.concatenate(pred), np.concatenate(obs), np.concatenate(its)
+    assert np.array_equal(obs, z["obs"]), "the device sampler and the oracle's sampler disagree"
+    assert np.array_equal(pred, z["ldpc_f64_q11_pred"]) and np.array_equal(its, z["ldpc_f64_q11_iters"])
+    f_dev, f_ref = pred != obs, z["ldpc_f64_pred"] != obs
+    n_dev, n_ref = int(f_dev.sum()), int(f_ref.sum())
+    p_ref = n_ref / N
+    sigma = np.sqrt(p_ref * (1 - p_ref) / N)
+    b, c = int((f_dev & ~f_ref).sum()), int((~f_dev & f_ref).sum())
+    assert abs(n_dev - n_ref) / N <= sigma, (n_dev, n_ref, sigma * N)
+    assert abs(b - c) <= np.sqrt(b + c), (b, c)
