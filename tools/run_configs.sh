@@ -11,9 +11,9 @@ $B --window 5 3 --shots 65536 2>/dev/null                                  # hea
 for p in 0.001 0.002 0.004 0.005 0.006; do $B --p $p --shots 65536 --no-cpu 2>/dev/null; done   # configs[3] p-sweep (1 GPU)
 # configs[4]: QLP [[1020,136]], cardinal circuit, R=20, W=3 F=1 (20 windows of 1350 x 18900); LER saturates at p=3e-3, so lower rates too
 $B --code qlp1020 --window 3 1 --shots 8192 --no-cpu 2>/dev/null
-$B --code qlp1020 --window 3 1 --shots 8192 --p-override 0.001 --no-cpu 2>/dev/null
+$B --code qlp1020 --window 3 1 --shots 8192 --p-override 0.001 --cpu-shots 24 2>/dev/null                                   # (CPU leg: 16 x 24 shots)
 $B --code qlp1020 --window 3 1 --shots 8192 --p-override 0.0005 --no-cpu 2>/dev/null
-$B --code qlp1020 --window 3 1 --shots 4096 --p-override 0.001 --osd-method osd_cs --osd-order 1 --no-cpu 2>/dev/null     # configs[4]: OSD-CS leg
+$B --code qlp1020 --window 3 1 --shots 4096 --steps 1 --p-override 0.001 --osd-method osd_cs --osd-order 1 --cpu-shots 2 2>/dev/null     # configs[4]: OSD-CS leg (CPU leg: 16 x 2 shots)
 $B --osd-method osd_cs --osd-order 1 --shots 32768 --cpu-shots 100 2>/dev/null                                            # headline code with OSD-CS(1)
 # the general (one message per edge) BP kernel at the headline code: the reference wrapper's other bp_method / schedule options
 $B --bp-method product_sum --schedule serial --max-iter 10 --cpu-shots 100 2>/dev/null
