@@ -17,7 +17,7 @@ _LIB = None
 BP_METHOD = {"product_sum": 0, "ps": 0, "prod_sum": 0, "minimum_sum": 1, "min_sum": 1, "ms": 1}
 SCHEDULE = {"parallel": 0, "p": 0, "serial": 1, "s": 1}
 OSD_METHOD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "osd_e": 2, "osde": 2, "exhaustive": 2,
-              "osd_cs": 3, "osdcs": 3, "combination_sweep": 3}
+              "osd_cs": 3, "osdcs": 3, "combination_sweep": 3, "lsd_0": 4, "lsd0": 4}
 FORM_LDPC_F64, FORM_COMPRESSED_F32, FORM_COMPRESSED_F64, FORM_LDPC_F32 = 0, 1, 2, 3
 
 
@@ -57,6 +57,7 @@ def lib():
         L.oq_osd_column_order.argtypes = [C.c_int, f64p, i32p]
         L.oq_gf2_rank.argtypes = [C.c_void_p]
         L.oq_osd0.argtypes = [C.c_void_p, u8p, f64p, C.c_int, u8p, i32p]
+        L.oq_lsd0.argtypes = [C.c_void_p, u8p, f64p, u8p, i32p]
         L.oq_osd_w.argtypes = [C.c_void_p, u8p, f64p, C.c_int, C.c_int, u8p]
         L.oq_osd_w_fixed.argtypes = [C.c_void_p, u8p, f64p, C.c_int, C.c_int, u8p, i32p]
         L.oq_fixed_weight.restype = C.c_uint32
@@ -145,6 +146,14 @@ class Graph:
         st = np.zeros(4, np.int32)
         lib().oq_osd0(self._h, s, np.ascontiguousarray(llr, dtype=np.float64), int(stop_early), err, st)
         return err, {"pivots": int(st[0]), "cols_examined": int(st[1]), "inconsistent": bool(st[2])}
+
+    def lsd0(self, syndrome, llr):
+        """BP-LSD's post-processing alone (LSD-0, one fault per growth step) on given soft information."""
+        s = np.ascontiguousarray(np.asarray(syndrome) % 2, dtype=np.uint8)
+        err = np.zeros(self.n, np.uint8)
+        st = np.zeros(4, np.int32)
+        lib().oq_lsd0(self._h, s, np.ascontiguousarray(llr, dtype=np.float64), err, st)
+        return err, {"pivots": int(st[0]), "added": int(st[1]), "inconsistent": bool(st[2]), "rounds": int(st[3])}
 
     def osd_w(self, syndrome, llr, osd_method="osd_cs", osd_order=1, fixed=False):
         """OSD-CS / OSD-E.  fixed=True: integer candidate costs (the HIP kernel's arithmetic); returns (err, stats)."""

@@ -40,6 +40,7 @@
 #define OQ_OSD_0 1
 #define OQ_OSD_E 2
 #define OQ_OSD_CS 3
+#define OQ_LSD_0 4            /* BP-LSD, lsd_order 0 (ldpc.bplsd_decoder.BpLsdDecoder) */
 #define OQ_FORM_LDPC_F64 0      /* per-edge messages, double, ldpc's update order              */
 #define OQ_FORM_COMPRESSED_F32 1 /* compressed min-sum state, float: bit-exact mirror of the HIP kernel */
 #define OQ_FORM_COMPRESSED_F64 2
@@ -366,6 +367,132 @@ int oq_osd0(oq_graph *g, const uint8_t *synd, const double *llr, int stop_early,
     return 0;
 }
 
+/* ---------------------------------------------------------------------------------------------------------- */
+/* BP-LSD: localized statistics decoding after a failed BP (Hillmann, Berent, Quintavalle, Eisert, Wille, Roffe 2024;
+ * ldpc 2.x src_cpp/lsd.hpp, LsdDecoder::lsd_decode, as the reference reaches it through ldpc.bplsd_decoder.BpLsdDecoder:
+ * quits/decoder/bplsd.py:5,51,86).  PARITY UNPINNED like the rest of the ldpc arithmetic (no ldpc here): restated from the
+ * published algorithm with ldpc's defaults bits_per_step = 1, lsd_order = 0 (LSD-0), deterministic where ldpc is not:
+ *
+ *   - every unsatisfied check seeds a cluster (id = its index);
+ *   - while invalid clusters exist: the clusters that are invalid at the start of the round grow by ONE fault each, in order
+ *     of (number of faults, id) ascending (ldpc: std::sort by bit_nodes.size(), ties unspecified); a cluster that became
+ *     valid or was absorbed earlier in the round is skipped;
+ *   - growth: among the faults not yet in any cluster that touch a check of the cluster, the one with the LOWEST posterior
+ *     LLR joins (ties: lowest index; ldpc sorts its candidate list with std::sort); all its checks join the cluster, and a
+ *     cluster owning one of them is absorbed (its faults keep their order);
+ *   - a cluster is valid when its part of the syndrome lies in the span of its faults' columns, decided by on-the-fly
+ *     elimination: each new column is reduced against the pivots found so far; clusters own disjoint checks, so one
+ *     elimination over all rows serves every cluster (T-form bookkeeping as in elim_run; pivot row = lowest candidate);
+ *   - the correction is, cluster by cluster, the solution on the pivot columns in order of addition (what ldpc's PLU
+ *     lu_solve returns): err[pcol[k]] = transformed syndrome at pivot row k.
+ * A cluster whose checks have no fault left to add while still invalid can never become valid (syndrome outside the column
+ * space): it is retired and the shot flagged.  stats: pivots, faults added, inconsistent flag, growth rounds. */
+static void elim_init(const oq_graph *g, const uint8_t *synd, oq_elim *E)
+{
+    const int m = g->m, mw = (m + 63) / 64;
+    E->mw = mw;
+    E->Q = (uint64_t *)calloc((size_t)m * (size_t)mw + 1, sizeof(uint64_t));
+    E->sp = (uint8_t *)malloc((size_t)m + 1);
+    E->rowpiv = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    E->prow = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    E->pcol = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    E->npiv = 0; E->ncols_examined = 0;
+    for (int r = 0; r < m; r++) { E->sp[r] = synd[r] & 1; E->rowpiv[r] = -1; }
+}
+
+/* one column through the elimination; returns 1 if it became a pivot column */
+static int elim_add_column(const oq_graph *g, oq_elim *E, int col, uint8_t *t /* m bytes of scratch */)
+{
+    const int m = g->m, mw = E->mw;
+    memset(t, 0, (size_t)m);
+    int nmask = 0, maskk[OQ_MAX_COL_DEG];
+    for (int e = g->cp[col]; e < g->cp[col + 1]; e++) {
+        int r = g->ri[e];
+        t[r] ^= 1;
+        if (E->rowpiv[r] >= 0) maskk[nmask++] = E->rowpiv[r];
+    }
+    if (nmask)
+        for (int r = 0; r < m; r++) {
+            const uint64_t *q = E->Q + (size_t)r * mw;
+            int b = 0;
+            for (int x = 0; x < nmask; x++) b ^= (int)((q[maskk[x] >> 6] >> (maskk[x] & 63)) & 1);
+            t[r] ^= (uint8_t)b;
+        }
+    int p = -1;
+    for (int r = 0; r < m; r++) if (t[r] && E->rowpiv[r] < 0) { p = r; break; }
+    if (p < 0) return 0;
+    int k = E->npiv++;
+    const uint64_t *qp = E->Q + (size_t)p * mw;
+    int kw = k >> 6; uint64_t kb = 1ull << (k & 63);
+    for (int r = 0; r < m; r++) {
+        if (!t[r] || r == p) continue;
+        uint64_t *q = E->Q + (size_t)r * mw;
+        for (int w = 0; w <= kw; w++) q[w] ^= qp[w];
+        q[kw] ^= kb;
+        if (E->sp[p]) E->sp[r] ^= 1;
+    }
+    E->rowpiv[p] = k; E->prow[k] = p; E->pcol[k] = col;
+    return 1;
+}
+
+int oq_lsd0(oq_graph *g, const uint8_t *synd, const double *llr, uint8_t *err, int32_t *stats)
+{
+    const int m = g->m, n = g->n;
+    oq_elim E;
+    elim_init(g, synd, &E);
+    uint8_t *t = (uint8_t *)malloc((size_t)m + 1);
+    uint8_t *added = (uint8_t *)calloc((size_t)n + 1, 1);
+    int *owner = (int *)malloc(sizeof(int) * (size_t)(m + 1));      /* check -> cluster id, -1 = free */
+    int *nbits = (int *)calloc((size_t)m + 1, sizeof(int));          /* per cluster id */
+    uint8_t *state = (uint8_t *)calloc((size_t)m + 1, 1);            /* per cluster id: 0 none, 1 active+invalid, 2 active+valid, 3 gone */
+    int *round = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    int nadded = 0, inconsistent = 0, rounds = 0;
+    for (int i = 0; i < m; i++) { owner[i] = (synd[i] & 1) ? i : -1; state[i] = (synd[i] & 1) ? 1 : 0; }
+    for (;;) {
+        int nr = 0;
+        for (int c = 0; c < m; c++) if (state[c] == 1) round[nr++] = c;
+        if (!nr) break;
+        rounds++;
+        /* (size, id) ascending, sizes as they are at the start of the round: insertion sort, the lists are short */
+        for (int a = 1; a < nr; a++) {
+            int c = round[a], b = a - 1;
+            while (b >= 0 && (nbits[round[b]] > nbits[c])) { round[b + 1] = round[b]; b--; }
+            round[b + 1] = c;
+        }
+        for (int x = 0; x < nr; x++) {
+            const int c = round[x];
+            if (state[c] != 1) continue;
+            int best = -1;
+            for (int i = 0; i < m; i++) {
+                if (owner[i] != c) continue;
+                for (int e = g->rp[i]; e < g->rp[i + 1]; e++) {
+                    int j = g->ci[e];
+                    if (added[j]) continue;
+                    if (best < 0 || llr[j] < llr[best] || (llr[j] == llr[best] && j < best)) best = j;
+                }
+            }
+            if (best < 0) { state[c] = 3; inconsistent = 1; continue; }
+            added[best] = 1; nadded++; nbits[c]++;
+            for (int e = g->cp[best]; e < g->cp[best + 1]; e++) {
+                int i = g->ri[e], d = owner[i];
+                if (d == c) continue;
+                if (d < 0) { owner[i] = c; continue; }
+                for (int r = 0; r < m; r++) if (owner[r] == d) owner[r] = c;     /* absorb cluster d */
+                nbits[c] += nbits[d]; state[d] = 3;
+            }
+            elim_add_column(g, &E, best, t);
+            int bad = 0;
+            for (int r = 0; r < m; r++) if (owner[r] == c && E.rowpiv[r] < 0 && E.sp[r]) { bad = 1; break; }
+            state[c] = bad ? 1 : 2;
+        }
+    }
+    memset(err, 0, (size_t)n);
+    for (int k = 0; k < E.npiv; k++) err[E.pcol[k]] = E.sp[E.prow[k]];
+    if (stats) { stats[0] = E.npiv; stats[1] = nadded; stats[2] = inconsistent; stats[3] = rounds; }
+    elim_free(&E); free(t); free(added); free(owner); free(nbits); free(state); free(round);
+    return 0;
+}
+
 /* Candidate cost.  ldpc sums log(1/p_j) in double (osd.hpp).  `fixed` != 0 switches to the integer weights the HIP
  * kernel uses -- round(log(1/p_j) * 2^18) -- so that sums are exact and independent of summation order; the two only
  * differ on candidates whose costs tie to within ~1e-5. */
@@ -492,7 +619,8 @@ int oq_bposd_decode(oq_graph *g, const oq_params *prm, const uint8_t *synd, uint
         oq_graph_quantize_llr(g, fine);
     }
     if (!conv && prm->osd_method != OQ_OSD_OFF) {
-        if (prm->osd_method == OQ_OSD_0 || prm->osd_order == 0) oq_osd0(g, synd, llr, 1, err, st);
+        if (prm->osd_method == OQ_LSD_0) oq_lsd0(g, synd, llr, err, st);
+        else if (prm->osd_method == OQ_OSD_0 || prm->osd_order == 0) oq_osd0(g, synd, llr, 1, err, st);
         else osd_w_impl(g, synd, llr, prm->osd_method, prm->osd_order,
                         prm->form == OQ_FORM_COMPRESSED_F32 || prm->form == OQ_FORM_LDPC_F32 || g->llr_frac_bits >= 0
                         /* the device's arithmetic (float forms, or any form on the LLR grid): integer candidate costs */, err, NULL);

@@ -16,6 +16,8 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
                                 int schedule, int64_t shot0, int nshots, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s);
+hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks, hipStream_t s);
+int qd_lsd_lds_bytes(int m_pad, int n, int out_words);
 hipError_t qd_launch_stage_llr(const float *llr_in, int n, int n_pad, const uint32_t *bit_orig, int64_t B, float *llr_ws,
                                int32_t *fail_list, int32_t *fail_count, int32_t *status, hipStream_t s);
 hipError_t qd_launch_spmv(const SpmatDev &A, const uint32_t *err, int64_t err_stride, int64_t B, uint8_t *out,
@@ -89,6 +91,9 @@ struct qd_decoder {
     int osd_blocks_fast = 0;
     int osd_w = 0;
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
+    int lsd = 0;                // 1: BP-LSD post-processing (lsd_kernels.hip) instead of OSD
+    int lsd_blocks = 0;
+    uint64_t *lsd_ws = nullptr; // [lsd_blocks][mw][m_pad] Q planes
     int64_t gen_ws_limit = 0;   // bytes; 0 = default
     GenWs gws{};
     // ---- LLR grid (flooding min-sum, ms_scaling 1): decoder-owned prior arrays on the fine and the coarse grid
@@ -503,7 +508,12 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     if (p->bp_method != QD_BP_MINIMUM_SUM && p->bp_method != QD_BP_PRODUCT_SUM) return fail(QD_EINVAL, "unknown bp_method %d", p->bp_method);
     if (p->schedule != QD_SCHEDULE_PARALLEL && p->schedule != QD_SCHEDULE_SERIAL) return fail(QD_EINVAL, "unknown schedule %d", p->schedule);
     if (p->reserved & ~(QD_FLAG_EDGE_MESSAGES | QD_FLAG_RAW_LLR)) return fail(QD_EINVAL, "unknown flag bits 0x%x", p->reserved);
-    const bool osd0 = p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
+    const bool lsd = p->osd_method == QD_LSD_0;
+    if (lsd && p->osd_order != 0)
+        return fail(QD_EUNSUPPORTED, "BP-LSD: lsd_order %d > 0 is not implemented on the device path (LSD-0 only)", p->osd_order);
+    if (lsd && qd_lsd_lds_bytes(g->bp.m_pad, g->n, g->bp.out_words) > QD_LDS_BYTES)
+        return fail(QD_ECAPACITY, "window %d x %d does not fit the LSD kernel's LDS layout", g->m, g->n);
+    const bool osd0 = lsd || p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
     if (p->osd_method != QD_OSD_OFF && !osd0) {
         if (p->osd_method != QD_OSD_CS && p->osd_method != QD_OSD_E) return fail(QD_EINVAL, "unknown osd_method %d", p->osd_method);
         if (p->osd_order < 0) return fail(QD_EINVAL, "negative osd_order");
@@ -514,11 +524,11 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
         if (p->osd_method == QD_OSD_E && p->osd_order > 15)
             return fail(QD_EUNSUPPORTED, "osd_e: osd_order %d > 15 is not implemented on the device path", p->osd_order);
     }
-    if (p->osd_method != QD_OSD_OFF && g->osd.lds_bytes == 0 && g->osd.f_lds_bytes == 0)
+    if (p->osd_method != QD_OSD_OFF && !lsd && g->osd.lds_bytes == 0 && g->osd.f_lds_bytes == 0)
         return fail(QD_ECAPACITY, "window %d x %d does not fit either OSD kernel's LDS layout", g->m, g->n);
     if (p->max_iter < 0 || p->ms_scaling_factor < 0) return fail(QD_EINVAL, "negative max_iter / ms_scaling_factor");
     qd_decoder *d = new qd_decoder();
-    d->g = g; d->prm = *p;
+    d->g = g; d->prm = *p; d->lsd = lsd ? 1 : 0;
     d->general = (p->bp_method != QD_BP_MINIMUM_SUM || p->schedule != QD_SCHEDULE_PARALLEL || (p->reserved & QD_FLAG_EDGE_MESSAGES)) ? 1 : 0;
     d->osd_w = osd0 || p->osd_method == QD_OSD_OFF ? 0 : (p->osd_method == QD_OSD_CS ? 1 : 2);
     if (d->osd_w) host_rank(const_cast<qd_graph *>(g));     // the sweep needs the complete factorisation: rank pivots
@@ -584,6 +594,8 @@ static void free_ws(qd_decoder *d)
     if (d->hard_list) (void)hipFree(d->hard_list);
     if (d->hard_list2) (void)hipFree(d->hard_list2);
     if (d->redo_list) (void)hipFree(d->redo_list);
+    if (d->lsd_ws) (void)hipFree(d->lsd_ws);
+    d->lsd_ws = nullptr;
     d->redo_list = nullptr; d->redo_cap = 0;
     d->hard_list = nullptr; d->hard_list2 = nullptr;
     d->llr_ws = nullptr; d->fail_list = nullptr; d->fail_count = nullptr; d->order_ws = nullptr; d->q_spill = nullptr;
@@ -628,6 +640,11 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
             if (v > 0) d->osd_blocks_fast = ncu * v;
         }
         if (d->osd_w) d->osd_blocks_fast = ncu;                         // higher-order OSD: one workgroup per CU (w_* layout)
+        if (d->lsd) {
+            const int lds = qd_lsd_lds_bytes(g->bp.m_pad, g->n, g->bp.out_words);
+            d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
+            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * (size_t)d->lsd_blocks * g->osd.mw * g->osd.m_pad));
+        }
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
             HIP_TRY(hipMalloc((void **)&d->q_spill_fast, sizeof(uint64_t) * (size_t)d->osd_blocks_fast * spill_fast * g->osd.m_pad));
@@ -771,8 +788,11 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
     if ((stage & 2) && osd) {
         hipEvent_t t0 = nullptr;
         if (int rc = span(1, t0)) return rc;
-        HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
-                               (int)std::min<int64_t>(B, d->osd_blocks), s));
+        if (d->lsd)
+            HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, (int)std::min<int64_t>(B, d->lsd_blocks), s));
+        else
+            HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
+                                   (int)std::min<int64_t>(B, d->osd_blocks), s));
         if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
     }
     return QD_OK;
@@ -798,6 +818,7 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
 {
     if (!d || !d_det || !d_llr || !d_err_bits || !d_status) return fail(QD_EINVAL, "null argument");
     if (d->prm.osd_method == QD_OSD_OFF) return fail(QD_EINVAL, "decoder was created with osd_method = off");
+    const bool lsd_only = d->lsd != 0;
     if (B < 0 || B > 0x7FFFFFFF) return fail(QD_EINVAL, "batch size out of range");
     if (B == 0) return QD_OK;
     if (det_offset < 0 || det_stride < det_offset + d->g->m) return fail(QD_EINVAL, "detector slice exceeds the row stride");
@@ -820,8 +841,11 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
     HIP_TRY(qd_launch_stage_llr(d_llr, d->g->n, d->g->bp.n_pad, d->g->bp.bit_orig, B, d->llr_ws, d->fail_list, d->fail_count,
                                 d_status, s));
-    HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
-                           (int)std::min<int64_t>(B, d->osd_blocks), s));
+    if (lsd_only)
+        HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, (int)std::min<int64_t>(B, d->lsd_blocks), s));
+    else
+        HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
+                               (int)std::min<int64_t>(B, d->osd_blocks), s));
     return QD_OK;
 }
 

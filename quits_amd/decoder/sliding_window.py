@@ -149,6 +149,11 @@ class DeviceWindowPlan:
 
 def _kwargs_for_device(d):
     allowed = ("bp_method", "schedule", "max_iter", "osd_method", "osd_order", "ms_scaling_factor")
+    d = dict(d)
+    if "lsd_method" in d or "lsd_order" in d:        # BpLsdDecoder's options (reference bplsd.py:38-49,74-83)
+        from .bplsd import lsd_to_device_method
+        d["osd_method"] = lsd_to_device_method(d.pop("lsd_method", "lsd_0"), d.pop("lsd_order", 0), d.pop("bits_per_step", 1))
+        d["osd_order"] = 0
     extra = [k for k in d if k not in allowed + ("error_rate", "channel_probs", "error_channel")]
     if extra:
         raise TypeError("unsupported decoder option(s) for the device path: %s" % ", ".join(sorted(extra)))

@@ -62,8 +62,36 @@ def test_package_surface_mirrors_reference():
     assert list(sig.parameters) == ["zcheck_samples", "circuit", "hz", "lz", "W", "F", "decoder1", "decoder2", "dict1",
                                     "dict2", "error_rate_name1", "error_rate_name2", "function_name1", "function_name2",
                                     "tqdm_on"]
+    # BP-LSD (reference bplsd.py:10,54): same names, positional order, keyword names and defaults
+    sig = inspect.signature(d.sliding_window_bplsd_circuit_mem)
+    assert list(sig.parameters) == ["zcheck_samples", "circuit", "hz", "lz", "W", "F", "max_iter", "lsd_order",
+                                    "bp_method", "schedule", "lsd_method", "tqdm_on"]
+    assert [sig.parameters[k].default for k in ("max_iter", "lsd_order", "bp_method", "schedule", "lsd_method", "tqdm_on")] \
+        == [2, 0, "product_sum", "serial", "lsd_cs", False]
+    sig = inspect.signature(d.sliding_window_bplsd_phenom_mem)
+    assert list(sig.parameters) == ["zcheck_samples", "hz", "lz", "W", "F", "eff_error_rate_per_fault", "max_iter",
+                                    "lsd_order", "bp_method", "schedule", "lsd_method", "tqdm_on", "error_rate"]
+    assert issubclass(d.BpLsdDecoder, d.BpOsdDecoder)
+
+
+def test_bplsd_options_outside_the_device_path_fail_loudly():
+    """lsd_order > 0 / bits_per_step != 1 are legal for ldpc and not implemented on the device: NotImplementedError, raised
+    before anything touches the GPU; a missing error rate is the reference's ValueError (bplsd.py:35-36)."""
+    import helpers
+    from quits_amd.decoder import sliding_window_bplsd_circuit_mem, sliding_window_bplsd_phenom_mem
+    from quits_amd.decoder.bplsd import lsd_to_device_method
+    from quits_amd.dem import Circuit
+    cd = helpers.code("bb72")
+    det = np.zeros((4, 36 * 8), np.uint8)
+    with pytest.raises(NotImplementedError, match="lsd_order"):
+        sliding_window_bplsd_circuit_mem(det, Circuit(helpers.circuit_text("bb72_custom_r6_p0.003")), cd["hz"], cd["lz"], 3, 1, lsd_order=1)
+    with pytest.raises(ValueError, match="eff_error_rate_per_fault"):
+        sliding_window_bplsd_phenom_mem(det, cd["hz"], cd["lz"], 3, 1)
+    assert lsd_to_device_method("lsd_cs", 0) == lsd_to_device_method("lsd_e", 0) == lsd_to_device_method("lsd_0", 0) == "lsd_0"
     with pytest.raises(NotImplementedError):
-        d.sliding_window_bplsd_circuit_mem()
+        lsd_to_device_method("lsd_0", 0, bits_per_step=2)
+    with pytest.raises(ValueError):
+        lsd_to_device_method("osd_cs", 0)
 
 
 def test_dict_helpers():

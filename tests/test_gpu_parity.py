@@ -542,3 +542,90 @@ def test_ler_agreement_with_double_precision_oracle_2e5_shots(gpu):
     b, c = int((f_dev & ~f_ref).sum()), int((~f_dev & f_ref).sum())
     assert abs(n_dev - n_ref) / N <= sigma, (n_dev, n_ref, sigma * N)
     assert abs(b - c) <= np.sqrt(b + c), (b, c)
+
+
+# ---- BP-LSD (quits/decoder/bplsd.py; csrc/lsd_kernels.hip) -------------------------------------------------------------------
+@pytest.mark.parametrize("name,shots,max_iter", [
+    ("bb72_custom_r6_p0.003", 1500, 8),
+    ("hgp225_cardinal_r3_p0.01", 150, 10),
+    ("bb144_custom_r12_p0.003", 400, 30),
+])
+def test_bplsd_bit_exact(gpu, name, shots, max_iter):
+    """BP on the device, then LSD-0 (cluster growth + on-the-fly elimination, one wavefront per shot) against the oracle's
+    restatement: corrections, pivot counts and the inconsistent flag, bit for bit; every output reproduces its syndrome."""
+    H, L, pri = helpers.dem_matrices(name)
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=12, shot0=0, B=shots)
+    synd[1] = 0
+    err, status, dec = _gpu_decode(H, pri, synd, max_iter, osd="lsd_0")
+    g, prm = _oracle(H, pri, max_iter, "lsd_0")
+    ref, flags = g.decode_batch(synd, prm)
+    used = (status >> 17) & 1
+    assert np.array_equal(used, 1 - flags[:, 0]) and used.sum() > 10
+    assert np.array_equal((status >> 20) & 0xFFF, np.minimum(flags[:, 2], 4095)), "pivot counts differ"
+    assert np.array_equal((status >> 18) & 1, flags[:, 3])
+    bad = np.flatnonzero((err != ref).any(axis=1))
+    assert bad.size == 0, "LSD output differs on shots %s" % bad[:10]
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+
+
+def test_bplsd_crafted_soft_information_and_inconsistent(gpu):
+    """LSD alone (qd_osd0_batch on a BP-LSD decoder) on soft information that forces ties (flat LLRs: growth by index), big
+    merges (random LLRs) and syndromes outside the column space (flagged, no hang)."""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    m, n = H.shape
+    rng = np.random.default_rng(8)
+    B = 24
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=3, shot0=0, B=B)
+    synd[B - 4:] = (rng.random((4, m)) < 0.2).astype(np.uint8)            # arbitrary: mostly inconsistent (rank 1002 < 1008)
+    llr = rng.normal(size=(B, n)).astype(np.float32)
+    llr[:6] = 2.5
+    llr[6:12] = rng.choice(np.array([-1.0, 0.25, 3.0], np.float32), size=(6, n))
+    wg = WindowGraph(H, pri)
+    dec = BatchDecoder(wg, max_iter=1, osd_method="lsd_0")
+    bits, status = dec.osd0(torch.from_numpy(synd).cuda(), torch.from_numpy(llr).cuda())
+    err, status = unpack_bits(bits, n).cpu().numpy(), status.cpu().numpy()
+    g = orc.Graph(H, pri)
+    for b in range(B):
+        ref, st = g.lsd0(synd[b], llr[b].astype(np.float64))
+        assert np.array_equal(err[b], ref), b
+        assert ((status[b] >> 20) & 0xFFF) == min(st["pivots"], 4095) and bool(status[b] & (1 << 18)) == st["inconsistent"], (b, st)
+    assert (status[B - 4:] & (1 << 18)).any()
+
+
+def test_bplsd_sliding_window_functions(gpu):
+    """sliding_window_bplsd_circuit_mem / _phenom_mem (reference bplsd.py:10,54) on the device against the oracle's loop."""
+    from quits_amd.decoder import BpLsdDecoder, sliding_window_bplsd_circuit_mem, sliding_window_bplsd_phenom_mem
+    from quits_amd.decoder.base import spacetime, window_count
+    from quits_amd.dem import Circuit
+    name = "bb72_custom_r6_p0.003"
+    cd = helpers.code("bb72")
+    hz, lz = cd["hz"], cd["lz"]
+    nz = hz.shape[0]
+    H, L, pri = helpers.dem_matrices(name)
+    det, obs, _ = orc.sample_dem(H, L, pri, seed=4, shot0=0, B=300)
+    circ = Circuit(helpers.circuit_text(name))
+    pred = sliding_window_bplsd_circuit_mem(det, circ, hz, lz, 3, 1, max_iter=10, lsd_order=0, bp_method="minimum_sum",
+                                            schedule="parallel", lsd_method="lsd_cs")
+    ncr, _, _ = window_count(6, 3, 1)
+    checks, commits, priors, updates = spacetime(circ, hz, 3, 1, ncr)
+    wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None, "row0": k * nz}
+            for k in range(len(checks))]
+    ref, stats = orc.sliding_window_decode(wins, nz, det, orc.make_params("minimum_sum", "parallel", 10, "lsd_0", 0, 1.0, orc.FORM_LDPC_F64),
+                                           device_grid=True)
+    assert stats["osd_calls"] > 50 and pred.dtype == np.int64 and np.array_equal(pred, ref.astype(np.int64))
+    assert (pred != obs).any(axis=1).mean() < 0.2
+    # the reference wrapper's own defaults (product_sum, serial, max_iter 2, lsd_cs order 0): the general BP kernel + LSD-0
+    pred2 = sliding_window_bplsd_circuit_mem(det[:96], circ, hz, lz, 3, 1)
+    ref2, _ = orc.sliding_window_decode(wins, nz, det[:96], orc.make_params("product_sum", "serial", 2, "lsd_0", 0, 1.0, orc.FORM_LDPC_F32))
+    assert np.array_equal(pred2, ref2.astype(np.int64))
+    # phenomenological variant runs and returns the right shape; plug-in class per shot
+    pp = sliding_window_bplsd_phenom_mem(det[:64], hz, lz, 3, 1, eff_error_rate_per_fault=0.03, max_iter=10,
+                                         bp_method="minimum_sum", schedule="parallel")
+    assert pp.shape == (64, lz.shape[0]) and pp.dtype == np.int64
+    d1 = BpLsdDecoder(checks[1], channel_probs=priors[1], max_iter=10, bp_method="minimum_sum", schedule="parallel", lsd_method="lsd_cs", lsd_order=0)
+    go, prm = _oracle(checks[1], priors[1], 10, "lsd_0")
+    s1 = det[7, nz:4 * nz]
+    assert np.array_equal(d1.decode(s1.astype(int)), go.decode_batch(s1.reshape(1, -1), prm)[0][0])

@@ -242,3 +242,38 @@ def test_grid_bound_sends_a_shot_to_the_coarse_grid():
     e32, fl32, gr32 = g.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 40, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32), return_grid=True)
     assert np.array_equal(e32, e) and np.array_equal(gr32, gr)
     assert orc.grid_bits(np.array([0.003]), 50) == (11, 7) and orc.grid_bits(np.array([0.5 - 1e-9]), 1)[0] == 20
+
+
+def test_lsd0_invariants():
+    """The oracle's BP-LSD (LSD-0): every output reproduces its syndrome, the correction lives on the faults the clusters
+    took in, a single-fault syndrome whose BP is cut short is repaired by a one-fault cluster, and an inconsistent syndrome is
+    flagged instead of looping."""
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    synd, obs, _ = orc.sample_dem(H, L, pri, seed=23, shot0=0, B=300)
+    g = orc.Graph(H, pri).device_grid(8)
+    prm = orc.make_params("minimum_sum", "parallel", 8, "lsd_0", 0, 1.0, orc.FORM_LDPC_F64)
+    err, flags = g.decode_batch(synd, prm)
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+    assert (flags[:, 0] == 0).sum() > 30                      # LSD really ran
+    err_osd, _ = g.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 8, "osd_0", 0, 1.0, orc.FORM_LDPC_F64))
+    Ld = np.asarray(L.todense(), dtype=np.int64)
+    f_lsd = ((err.astype(np.int64) @ Ld.T) % 2 != obs).any(axis=1).mean()
+    f_osd = ((err_osd.astype(np.int64) @ Ld.T) % 2 != obs).any(axis=1).mean()
+    assert abs(f_lsd - f_osd) < 0.06, (f_lsd, f_osd)         # same ballpark as OSD-0 on the same posteriors
+    # one fault, flat soft information: the cluster seeded at its lowest check takes the lowest-index fault touching it ...
+    j = 100
+    s1 = np.asarray(H[:, j].todense()).ravel().astype(np.uint8)
+    e1, st1 = g.lsd0(s1, np.full(H.shape[1], 3.0))
+    assert np.array_equal((e1.astype(np.int64) @ Hd.T) % 2, s1) and st1["added"] >= 1 and not st1["inconsistent"]
+    # ... and with the fault marked likely, it is found in one step per seed at most
+    llr = np.full(H.shape[1], 3.0); llr[j] = -1.0
+    e2, st2 = g.lsd0(s1, llr)
+    assert e2[j] == 1 and e2.sum() == 1 and st2["added"] == 1 and st2["pivots"] == 1
+    # inconsistent: H of bb144 has rank 1002 < 1008
+    H2, _, pri2 = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    g2 = orc.Graph(H2, pri2)
+    rng = np.random.default_rng(5)
+    bad = (rng.random(H2.shape[0]) < 0.4).astype(np.uint8)
+    e3, st3 = g2.lsd0(bad, rng.normal(size=H2.shape[1]))
+    assert st3["inconsistent"]
