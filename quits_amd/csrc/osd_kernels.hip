@@ -28,6 +28,8 @@
 //   qd_osd0_full_kernel  sorts every column up front, all state in LDS, one workgroup per CU; used when a window has
 //                        more than 2048 detectors.  Same results by construction: both consume the same column order.
 #include "qd_internal.h"
+#include <cstdlib>
+#include <algorithm>
 
 #define QD_NOKEY 0xFFFFFFFFu
 
@@ -317,6 +319,7 @@ struct OsdRegArgs {
     int64_t det_stride, det_offset, upd_stride;
     const float *llr_ws;
     const int32_t *fail_list, *fail_count;
+    const int32_t *slot_list, *slot_count;      // when set: only these fail-list slots (the shots osd_wave.hip handed over)
     uint64_t *q_spill_fast;
     uint64_t *mt_ws;
     uint32_t *err_bits;
@@ -1035,7 +1038,7 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : T / 128)) qd_osd0_reg_ke
     const int tid = threadIdx.x;
     constexpr int NW = T / 64;
     constexpr int KWR = WFULL ? QD_OSD_KWR : QD_OSD_KWR0;      // Q planes kept in registers (~100 pivots at the headline, ~470 at p = 6e-3; 2, 4, 6 planes measured 10.5, 10.0, 10.6 ms at the headline and 178, 165, 161 ms at p = 6e-3)
-    const int nfail = *a.fail_count;
+    const int nfail = a.slot_list ? *a.slot_count : *a.fail_count;
     OsdLds S;
     qd_osd_carve(smem, a.off, S);
     uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + a.off_sort);       // [QD_OSD_TIER]
@@ -1049,7 +1052,8 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : T / 128)) qd_osd0_reg_ke
     const int lam_max = want_full ? min(a.osd_order, 64) : 0;
     const int m = a.m, m_pad = a.m_pad, kw_lds = a.f_kw;
     uint64_t *qglb = a.q_spill_fast ? a.q_spill_fast + (int64_t)blockIdx.x * (int64_t)(a.mw - kw_lds) * m_pad : nullptr;
-    for (int slot = blockIdx.x; slot < nfail; slot += gridDim.x) {
+    for (int item = blockIdx.x; item < nfail; item += gridDim.x) {
+        const int slot = a.slot_list ? a.slot_list[item] : item;
         const int64_t shot = a.fail_list[slot];
         const float *llr = a.llr_ws + (int64_t)slot * a.n_pad;
         const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
@@ -1479,8 +1483,11 @@ __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphD
     }
 }
 
+hipError_t qd_launch_osd0_wave(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &d, int blocks, hipStream_t s);
+int qd_osd_wave_lds_bytes(int m, int m_pad, int max_cdeg, int out_words);
+
 template <int TF, int RPT>
-static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s)
+static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s, bool handed_over)
 {
     const bool wl = a.osd_w != 0;                              // higher-order OSD uses the one-workgroup-per-CU layout
     auto k = wl ? qd_osd0_reg_kernel<TF, RPT, true> : qd_osd0_reg_kernel<TF, RPT, false>;
@@ -1495,6 +1502,7 @@ static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const D
     r.csc_ptr = g.csc_ptr; r.csc_row = g.csc_row; r.bit_orig = bg.bit_orig;
     r.det = a.det; r.upd = a.upd; r.det_stride = a.det_stride; r.det_offset = a.det_offset; r.upd_stride = a.upd_stride;
     r.llr_ws = a.llr_ws; r.fail_list = a.fail_list; r.fail_count = a.fail_count; r.q_spill_fast = a.q_spill_fast; r.mt_ws = a.mt_ws;
+    if (handed_over) { r.slot_list = a.hard_list; r.slot_count = a.hard_count; }
     r.err_bits = a.err_bits; r.status = a.status; r.dbg = a.dbg;
     r.off_pivmask = wl ? g.w_off_pivmask : g.f_off_pivmask; r.off_npl = wl ? g.w_off_npl : g.f_off_npl;
     r.osd_w = a.osd_w; r.osd_order = a.osd_order; r.rank = a.rank; r.wfix = g.wfix; r.bit_slot_of = bg.bit_slot_of;
@@ -1517,20 +1525,34 @@ hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const Deco
                           int blocks_full, hipStream_t s)
 {
     if (g.f_lds_bytes > 0) {
+        // OSD-0, opt-in (QD_OSD_WAVE=1): the one-wavefront-per-shot kernel of osd_wave.hip takes every shot first and hands over
+        // the ones that need more than the head of the column order or more than 128 pivots.  Same bits, measured SLOWER at
+        // the headline (wave kernel 8.3 ms + 21 % of the shots handed over 6.1 ms vs 10.0 ms for this kernel alone: a single
+        // wavefront pays ~1.5 us of dependent LDS round trips per column, and 33 KB of LDS per shot allow only five per CU),
+        // so it is off by default; tests/test_gpu_parity.py::test_osd_wave_path_bit_exact keeps it honest.
+        bool ho = false;
+        const int wlds = qd_osd_wave_lds_bytes(g.m, g.m_pad, g.max_cdeg, bg.out_words);
+        const bool wave_on = std::getenv("QD_OSD_WAVE") && std::atoi(std::getenv("QD_OSD_WAVE")) == 1;
+        if (a.osd_w == 0 && wlds > 0 && wlds <= QD_LDS_BYTES && a.hard_list && wave_on) {
+            const int per_cu = std::max(1, std::min(8, QD_LDS_BYTES / wlds));
+            hipError_t e = qd_launch_osd0_wave(g, bg, a, 256 * per_cu, s);
+            if (e != hipSuccess) return e;
+            ho = true;
+        }
         const int rpt = (g.m + g.f_threads - 1) / g.f_threads;
         if (g.f_threads == 256) {
             switch (rpt) {
-            case 1: return launch_reg<256, 1>(g, bg, a, blocks_fast, s);
-            case 2: return launch_reg<256, 2>(g, bg, a, blocks_fast, s);
-            case 3: return launch_reg<256, 3>(g, bg, a, blocks_fast, s);
-            default: return launch_reg<256, 4>(g, bg, a, blocks_fast, s);
+            case 1: return launch_reg<256, 1>(g, bg, a, blocks_fast, s, ho);
+            case 2: return launch_reg<256, 2>(g, bg, a, blocks_fast, s, ho);
+            case 3: return launch_reg<256, 3>(g, bg, a, blocks_fast, s, ho);
+            default: return launch_reg<256, 4>(g, bg, a, blocks_fast, s, ho);
             }
         }
         switch (rpt) {
-        case 1: return launch_reg<512, 1>(g, bg, a, blocks_fast, s);
-        case 2: return launch_reg<512, 2>(g, bg, a, blocks_fast, s);
-        case 3: return launch_reg<512, 3>(g, bg, a, blocks_fast, s);
-        default: return launch_reg<512, 4>(g, bg, a, blocks_fast, s);
+        case 1: return launch_reg<512, 1>(g, bg, a, blocks_fast, s, ho);
+        case 2: return launch_reg<512, 2>(g, bg, a, blocks_fast, s, ho);
+        case 3: return launch_reg<512, 3>(g, bg, a, blocks_fast, s, ho);
+        default: return launch_reg<512, 4>(g, bg, a, blocks_fast, s, ho);
         }
     }
     switch (g.threads) {

@@ -629,3 +629,18 @@ def test_bplsd_sliding_window_functions(gpu):
     go, prm = _oracle(checks[1], priors[1], 10, "lsd_0")
     s1 = det[7, nz:4 * nz]
     assert np.array_equal(d1.decode(s1.astype(int)), go.decode_batch(s1.reshape(1, -1), prm)[0][0])
+
+
+def test_osd_wave_path_bit_exact(gpu, monkeypatch):
+    """The opt-in one-wavefront-per-shot OSD-0 kernel (csrc/osd_wave.hip, QD_OSD_WAVE=1; shots it cannot finish go to the
+    workgroup-per-shot kernel): same corrections, pivot counts and flags as the default path and as the oracle."""
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=77, shot0=0, B=600)
+    err0, st0, _ = _gpu_decode(H, pri, synd, 30, osd="osd_0")
+    monkeypatch.setenv("QD_OSD_WAVE", "1")
+    err1, st1, _ = _gpu_decode(H, pri, synd, 30, osd="osd_0")
+    assert np.array_equal(err0, err1) and np.array_equal(st0, st1)
+    g, prm = _oracle(H, pri, 30, "osd_0")
+    ref, flags = g.decode_batch(synd, prm)
+    assert np.array_equal(err1, ref) and np.array_equal((st1 >> 20) & 0xFFF, np.minimum(flags[:, 2], 4095))
+    assert ((st1 >> 17) & 1).sum() > 100
