@@ -16,7 +16,7 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
                                 int schedule, int64_t shot0, int nshots, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s);
-hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks, hipStream_t s);
+hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks, hipStream_t s);
 int qd_lsd_lds_bytes(int m_pad, int n, int out_words);
 hipError_t qd_launch_stage_llr(const float *llr_in, int n, int n_pad, const uint32_t *bit_orig, int64_t B, float *llr_ws,
                                int32_t *fail_list, int32_t *fail_count, int32_t *status, hipStream_t s);
@@ -93,7 +93,7 @@ struct qd_decoder {
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
     int lsd = 0;                // 1: BP-LSD post-processing (lsd_kernels.hip) instead of OSD
     int lsd_blocks = 0;
-    uint64_t *lsd_ws = nullptr; // [lsd_blocks][mw][m_pad] Q planes
+    uint64_t *lsd_ws = nullptr; // [lsd_blocks][mw][m_pad] Q planes, then the work counter
     int64_t gen_ws_limit = 0;   // bytes; 0 = default
     GenWs gws{};
     // ---- LLR grid (flooding min-sum, ms_scaling 1): decoder-owned prior arrays on the fine and the coarse grid
@@ -316,6 +316,18 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         rcg |= g->mem.upload(rp_v, &gg.rp); rcg |= g->mem.upload(ci_v, &gg.ci);
         rcg |= g->mem.upload(cp, &gg.cp); rcg |= g->mem.upload(ri, &gg.ri);
         rcg |= g->mem.upload(c2r, &gg.c2r); rcg |= g->mem.upload(l0, &gg.llr0);
+        {
+            gg.ell_w = (max_rdeg + 63) / 64 * 64;
+            std::vector<int32_t> ell((size_t)m * gg.ell_w * 2, 0);
+            for (int i = 0; i < m; ++i)
+                for (int x = 0; x < gg.ell_w; ++x) {
+                    const int e = row_ptr[i] + x;
+                    const bool in = e < row_ptr[i + 1];
+                    ell[((size_t)i * gg.ell_w + x) * 2] = in ? col_idx[e] : -1;
+                    ell[((size_t)i * gg.ell_w + x) * 2 + 1] = in ? bit_slot_of[col_idx[e]] : 0;
+                }
+            rcg |= g->mem.upload(ell, &gg.ell);
+        }
         {
             std::vector<int32_t> last(m, 0), lev(n, 0);
             int nlev = 0;
@@ -643,7 +655,8 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         if (d->lsd) {
             const int lds = qd_lsd_lds_bytes(g->bp.m_pad, g->n, g->bp.out_words);
             d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
-            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * (size_t)d->lsd_blocks * g->osd.mw * g->osd.m_pad));
+            d->lsd_ws = nullptr;
+            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * ((size_t)d->lsd_blocks * g->osd.mw * g->osd.m_pad + 32)));   // + the work counter (+ debug timers)
         }
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
@@ -789,7 +802,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         hipEvent_t t0 = nullptr;
         if (int rc = span(1, t0)) return rc;
         if (d->lsd)
-            HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, (int)std::min<int64_t>(B, d->lsd_blocks), s));
+            HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), s));
         else
             HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                    (int)std::min<int64_t>(B, d->osd_blocks), s));
@@ -843,7 +856,7 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     HIP_TRY(qd_launch_stage_llr(d_llr, d->g->n, d->g->bp.n_pad, d->g->bp.bit_orig, B, d->llr_ws, d->fail_list, d->fail_count,
                                 d_status, s));
     if (lsd_only)
-        HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, (int)std::min<int64_t>(B, d->lsd_blocks), s));
+        HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), s));
     else
         HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                (int)std::min<int64_t>(B, d->osd_blocks), s));

@@ -46,6 +46,8 @@ struct GenGraphDev {
     const int32_t *cp, *ri;     // [n + 1], [nnz]   CSC, rows ascending in a column
     const int32_t *c2r;         // [nnz]            CSC edge -> CSR edge
     const float *llr0;          // [n]              (float)log((1 - p) / p), the log in double
+    const int32_t *ell;         // [m][ell_w][2]    rows in ELL form for BP-LSD: {fault, its posterior column}, {-1, 0} padding
+    int ell_w;                  //                  max row weight rounded up to a multiple of 64
     // serial schedule: faults grouped into dependency levels.  Two faults that share no check commute, so natural order
     // is reproduced by any order that keeps every pair of faults with a common check in index order; level(j) = 1 + the
     // highest level among earlier faults on j's checks.  Faults of one level are mutually independent.
