@@ -29,39 +29,46 @@
 #define QL_NOKEY64 0xFFFFFFFFFFFFFFFFull
 
 struct LsdArgs {
-    int m, n, m_pad, n_pad, mw, out_words, upd_rows, max_cdeg;
-    const int32_t *rp, *ci;        // CSR of the window matrix (fault indices)
-    const int32_t *cp, *ri;        // CSC
-    const uint32_t *bit_slot_of;   // fault -> column of the posterior rows
+    int m, n, n_pad, mw, out_words, upd_rows;
+    const int32_t *cp, *ri;        // CSC of the window matrix
+    const int2 *ell;               // [m][ell_w] rows in ELL form: {fault, its posterior column}, {-1, 0} padding
+    int ell_w;                     // multiple of 64
     const uint8_t *det, *upd;
     int64_t det_stride, det_offset, upd_stride;
     const float *llr_ws;           // [fail slot][n_pad]
     const int32_t *fail_list, *fail_count;
-    uint64_t *q_ws;                // [blocks][mw][m_pad]
+    uint64_t *q_ws;                // [blocks][mw][64 * NR] Q planes (planes 0 and 1 unused: they live in LDS)
+    int32_t *next_slot;            // work counter, zero at launch
     uint32_t *err_bits;
     int32_t *status;
-    // LDS carve-up (bytes)
-    const int2 *ell;               // [m][ell_w] rows in ELL form: {fault, its posterior column}, {-1, 0} padding
-    int ell_w;                     // multiple of 64
-    int32_t *next_slot;            // work counter, zero at launch
-    int chunk_shift;               // member masks: chunk = 2^chunk_shift checks, at most 32 chunks
-    int off_owner, off_best, off_q, off_added, off_sp, off_rowpiv, off_pcol, off_cstate, off_cnbits, off_cmask, off_rl, off_rs, off_t, off_out;
 };
+
+// LDS carve-up for NR checks per lane: compile-time offsets, so that a lane's block of NR consecutive rows is read with
+// 128-bit LDS loads.  The two bitmaps (sizes depend on n) come last.
+template <int NR> struct QlLay {
+    static constexpr int MP = 64 * NR;
+    static constexpr int o_ql = 0;                       // u64 [2][MP]  Q planes 0 and 1 (pivot orders 0..127)
+    static constexpr int o_bkey = o_ql + 16 * MP;        // u32 [MP]     check -> LLR key of its best unused fault
+    static constexpr int o_rl = o_bkey + 4 * MP;         // u32 [MP]     the round: size at its start << 16 | cluster id
+    static constexpr int o_owner = o_rl + 4 * MP;        // u16 [MP]     check -> cluster id (= seed check), QL_NONE = free
+    static constexpr int o_bj = o_owner + 2 * MP;        // u16 [MP]     check -> its best unused fault
+    static constexpr int o_rowpiv = o_bj + 2 * MP;       // i16 [MP]     check -> pivot order, -1 = not a pivot row
+    static constexpr int o_pcol = o_rowpiv + 2 * MP;     // u16 [MP]     pivot row -> its fault
+    static constexpr int o_cnbits = o_pcol + 2 * MP;     // u16 [MP]     per cluster id: faults added
+    static constexpr int o_flags = o_cnbits + 2 * MP;    // u8  [MP]     bit 0 transformed syndrome, 1 image of the column at hand, 2 pivot row
+    static constexpr int o_cstate = o_flags + MP;        // u8  [MP]     per cluster id: 0 none, 1 invalid, 2 valid, 3 gone
+    static constexpr int o_rs = o_cstate + MP;           // u32 [32]     checks whose candidate has to be (re)computed
+    static constexpr int o_added = o_rs + 128;           // u32 [ceil(n / 32)] fault bitmap, then the output words
+};
+#define QL_F_SP 1u
+#define QL_F_T 2u
+#define QL_F_PIV 4u
 
 __device__ __forceinline__ uint32_t ql_mono_key(float llr)
 {
     const float f = llr + 0.0f;                    // -0 -> +0: they tie on the index like the oracle's '<' on doubles
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-// minimum of 48-bit keys (32-bit LLR key << 16 | 16-bit index) over the wavefront; uniform result
-__device__ __forceinline__ uint64_t ql_wave_min48(uint64_t key)
-{
-    const uint32_t hi = (uint32_t)(key >> 16), mh = qd_wave_umin(hi);
-    const uint32_t lo = (hi == mh) ? (uint32_t)(key & 0xFFFFu) : 0xFFFFFFFFu;
-    const uint32_t ml = qd_wave_umin(lo);
-    return (mh == 0xFFFFFFFFu && ml >= 0xFFFFu) ? QL_NOKEY64 : (((uint64_t)mh << 16) | (ml & 0xFFFFu));
 }
 
 #ifdef QD_LSD_TIMING       // debug build: cycles per phase, summed over all shots, printed after the launch
@@ -75,33 +82,37 @@ __device__ __forceinline__ uint64_t ql_wave_min48(uint64_t key)
 #endif
 #define QL_NB 8            // rows per batch of the candidate scan: their loads are in flight together
 
-// rows of the chunks named by `mask` (uniform), lane-strided; chunk = 2^sh consecutive checks
-#define QL_FOR_ROWS(mask, r)                                                                                      \
-    for (uint32_t mm_ = (mask); mm_; mm_ &= mm_ - 1u)                                                             \
-        for (int r = ((int)__builtin_ctz(mm_) << sh) + lane, re_ = min(((int)__builtin_ctz(mm_) + 1) << sh, m); r < re_; r += 64)
-
+template <int NR>
 __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
 {
+    using Lay = QlLay<NR>;
+    constexpr int MP = Lay::MP;
+    struct alignas(16) BlkU64 { uint64_t v[NR]; };
+    struct alignas(16) BlkU32 { uint32_t v[NR]; };
+    struct alignas(16) BlkU16 { uint16_t v[NR]; };
+    struct alignas(8) BlkU8 { uint8_t v[NR]; };
     extern __shared__ __align__(16) unsigned char smem[];
-    uint16_t *owner = reinterpret_cast<uint16_t *>(smem + a.off_owner);      // check -> cluster id (= seed check), QL_NONE = free
-    uint64_t *best = reinterpret_cast<uint64_t *>(smem + a.off_best);        // check -> best unused fault as a 48-bit key
-    uint64_t *ql = reinterpret_cast<uint64_t *>(smem + a.off_q);             // Q planes 0 and 1 (pivot orders 0..127)
-    uint32_t *added = reinterpret_cast<uint32_t *>(smem + a.off_added);      // fault bitmap
-    uint8_t *sp = smem + a.off_sp;
-    int16_t *rowpiv = reinterpret_cast<int16_t *>(smem + a.off_rowpiv);      // check -> pivot order, -1 = not a pivot row
-    uint16_t *pcol = reinterpret_cast<uint16_t *>(smem + a.off_pcol);        // pivot row -> its fault
-    uint8_t *cstate = smem + a.off_cstate;                                   // per cluster id: 0 none, 1 invalid, 2 valid, 3 gone
-    uint16_t *cnbits = reinterpret_cast<uint16_t *>(smem + a.off_cnbits);
-    uint32_t *cmask = reinterpret_cast<uint32_t *>(smem + a.off_cmask);      // per cluster id: chunks of checks holding its members
-    uint32_t *rl = reinterpret_cast<uint32_t *>(smem + a.off_rl);            // the round: size at its start << 16 | cluster id
-    uint16_t *rs = reinterpret_cast<uint16_t *>(smem + a.off_rs);            // checks whose candidate has to be (re)computed
-    uint8_t *tb = smem + a.off_t;                                            // image of the column being eliminated, per row
-    uint32_t *outw = reinterpret_cast<uint32_t *>(smem + a.off_out);
-    const int lane = threadIdx.x;
-    const int m = a.m, m_pad = a.m_pad, sh = a.chunk_shift;
+    uint64_t *ql = reinterpret_cast<uint64_t *>(smem + Lay::o_ql);
+    uint32_t *bkey = reinterpret_cast<uint32_t *>(smem + Lay::o_bkey);
+    uint32_t *rl = reinterpret_cast<uint32_t *>(smem + Lay::o_rl);
+    uint16_t *owner = reinterpret_cast<uint16_t *>(smem + Lay::o_owner);
+    uint16_t *bj = reinterpret_cast<uint16_t *>(smem + Lay::o_bj);
+    int16_t *rowpiv = reinterpret_cast<int16_t *>(smem + Lay::o_rowpiv);
+    uint16_t *pcol = reinterpret_cast<uint16_t *>(smem + Lay::o_pcol);
+    uint16_t *cnbits = reinterpret_cast<uint16_t *>(smem + Lay::o_cnbits);
+    uint8_t *flags = smem + Lay::o_flags;
+    uint8_t *cstate = smem + Lay::o_cstate;
+    uint32_t *rs = reinterpret_cast<uint32_t *>(smem + Lay::o_rs);
+    uint32_t *added = reinterpret_cast<uint32_t *>(smem + Lay::o_added);
+    const int added_words = ((a.n + 31) / 32 + 3) & ~3;
+    uint32_t *outw = added + added_words;
+    const int lane = threadIdx.x, base = lane * NR;                           // the lane's block of rows
+    const int m = a.m;
     const int nfail = *a.fail_count;
-    uint64_t *Q = a.q_ws + (size_t)blockIdx.x * (size_t)a.mw * m_pad;         // planes >= 2 (rare): HBM, per resident slot
+    uint64_t *Q = a.q_ws + (size_t)blockIdx.x * (size_t)a.mw * MP;            // planes >= 2 (rare): HBM, per resident slot
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    BlkU16 &own_blk = *reinterpret_cast<BlkU16 *>(owner + base);
+    BlkU8 &fl_blk = *reinterpret_cast<BlkU8 *>(flags + base);
 #ifdef QD_LSD_TIMING
     long long tacc[16] = {0};
 #endif
@@ -118,15 +129,15 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
         const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
         const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
 
-        // best unused fault of the checks rs[0..cnt): lane = entry of the row, QL_NB rows per trip so that a trip costs two
+        // best unused fault of the checks list[0..cnt): lane = entry of the row, QL_NB rows per trip so that a trip costs two
         // memory latencies (row entries, then their LLRs) whatever the number of rows
-        auto scan_list = [&](int cnt) {
+        auto scan_list = [&](const uint32_t *list, int cnt) {
             for (int b0 = 0; b0 < cnt; b0 += QL_NB) {
                 int row[QL_NB];
                 uint64_t key[QL_NB];
 #pragma unroll
                 for (int b = 0; b < QL_NB; ++b) {
-                    row[b] = b0 + b < cnt ? __builtin_amdgcn_readfirstlane((int)rs[b0 + b]) : -1;
+                    row[b] = b0 + b < cnt ? __builtin_amdgcn_readfirstlane((int)(list[b0 + b] & 0xFFFFu)) : -1;
                     key[b] = QL_NOKEY64;
                 }
                 for (int wc = 0; wc < a.ell_w; wc += 64) {
@@ -149,38 +160,53 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
 #pragma unroll
                 for (int b = 0; b < QL_NB; ++b) {
                     if (row[b] < 0) break;                                     // uniform
-                    const uint64_t k = ql_wave_min48(key[b]);
-                    if (lane == 0) best[row[b]] = k;
+                    const uint32_t hi = (uint32_t)(key[b] >> 16), mh = qd_wave_umin(hi);
+                    const uint32_t lo = (hi == mh) ? (uint32_t)(key[b] & 0xFFFFu) : 0xFFFFu;
+                    const uint32_t ml = qd_wave_umin(lo);
+                    if (lane == 0) { bkey[row[b]] = mh; bj[row[b]] = (uint16_t)ml; }     // nothing left: 0xFFFFFFFF, 0xFFFF
                 }
             }
             __syncthreads();
         };
-        auto q_ld = [&](int w, int r) -> uint64_t { return w < 2 ? ql[w * m_pad + r] : Q[(size_t)w * m_pad + r]; };
-        auto q_st = [&](int w, int r, uint64_t v) { if (w < 2) ql[w * m_pad + r] = v; else Q[(size_t)w * m_pad + r] = v; };
 
+        // ---- per shot: every unsatisfied check seeds a cluster
         int nseed = 0;
-        for (int r0 = 0; r0 < m_pad; r0 += 64) {
-            const int r = r0 + lane;
-            uint32_t s = 0;
-            if (r < m) {
-                s = det[r] & 1u;
-                if (upd && r < a.upd_rows) s ^= upd[r] & 1u;
+        {
+            BlkU16 own, allff;
+            BlkU8 fl, cs;
+            BlkU32 kff;
+            BlkU64 zero;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int r = base + k;
+                uint32_t s = 0;
+                if (r < m) {
+                    s = det[r] & 1u;
+                    if (upd && r < a.upd_rows) s ^= upd[r] & 1u;
+                }
+                own.v[k] = s ? (uint16_t)r : (uint16_t)QL_NONE; fl.v[k] = (uint8_t)s; cs.v[k] = s ? 1 : 0;
+                allff.v[k] = 0xFFFFu; kff.v[k] = 0xFFFFFFFFu; zero.v[k] = 0ull;
+                const unsigned long long bs = __ballot(s != 0u);
+                if (s) rl[nseed + __popcll(bs & lt_mask)] = (uint32_t)r;       // size 0 << 16 | id
+                nseed += __popcll(bs);
             }
-            sp[r] = (uint8_t)s; rowpiv[r] = -1; owner[r] = s ? (uint16_t)r : (uint16_t)QL_NONE;
-            cstate[r] = s ? 1 : 0; cnbits[r] = 0; best[r] = QL_NOKEY64; tb[r] = 0; cmask[r] = 1u << (r >> sh);
-            ql[r] = 0ull; ql[m_pad + r] = 0ull;                                // later planes are cleared when first used
-            const unsigned long long bs = __ballot(s != 0u);
-            if (s) {
-                const int at = nseed + __popcll(bs & lt_mask);
-                rs[at] = (uint16_t)r; rl[at] = (uint32_t)r;
-            }
-            nseed += __popcll(bs);
+            own_blk = own; fl_blk = fl;
+            *reinterpret_cast<BlkU8 *>(cstate + base) = cs;
+            *reinterpret_cast<BlkU16 *>(bj + base) = allff;
+            *reinterpret_cast<BlkU16 *>(rowpiv + base) = allff;                // -1
+            *reinterpret_cast<BlkU32 *>(bkey + base) = kff;
+            *reinterpret_cast<BlkU64 *>(ql + base) = zero;
+            *reinterpret_cast<BlkU64 *>(ql + MP + base) = zero;                // later planes are cleared when first used
+            BlkU16 z16;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) z16.v[k] = 0;
+            *reinterpret_cast<BlkU16 *>(cnbits + base) = z16;
         }
-        for (int w = lane; w < (a.n + 31) / 32; w += 64) added[w] = 0u;
+        for (int w = lane; w < added_words; w += 64) added[w] = 0u;
         for (int w = lane; w < a.out_words; w += 64) outw[w] = 0u;
         __syncthreads();
         QL_T(0);
-        scan_list(nseed);                                                      // seeds: the candidate of every unsatisfied check
+        scan_list(rl, nseed);                                                  // seeds: the candidate of every unsatisfied check
         QL_T(1); QL_CNT(12, 1);
 
         int npiv = 0, inconsistent = 0, nrl = nseed;
@@ -202,122 +228,179 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
             if (nrl == 0) break;
             long long last = -1;
             for (;;) {
-                uint32_t k = 0xFFFFFFFFu;
-                for (int idx = lane; idx < nrl; idx += 64) { const uint32_t v = rl[idx]; if ((long long)v > last) k = min(k, v); }
-                k = qd_wave_umin(k);
-                if (k == 0xFFFFFFFFu) break;
-                last = (long long)k;
-                const int c = (int)(k & 0xFFFFu);
+                uint32_t kk = 0xFFFFFFFFu;
+                for (int idx = lane; idx < nrl; idx += 64) { const uint32_t v = rl[idx]; if ((long long)v > last) kk = min(kk, v); }
+                kk = qd_wave_umin(kk);
+                if (kk == 0xFFFFFFFFu) break;
+                last = (long long)kk;
+                const int c = (int)(kk & 0xFFFFu);
                 QL_T(3);
-                if (cstate[c] != 1) continue;                                  // became valid or was absorbed earlier in the round
+                if (__builtin_amdgcn_readfirstlane((int)cstate[c]) != 1) continue;   // became valid or was absorbed earlier in the round
                 QL_CNT(14, 1);
-                uint32_t cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmask[c]);
                 // ---- the fault that joins: lowest (LLR, index) among the cached candidates of the cluster's checks
-                uint64_t key = QL_NOKEY64;
-                QL_FOR_ROWS(cm, r)
-                    if (owner[r] == (uint16_t)c) { const uint64_t b = best[r]; key = b < key ? b : key; }
-                key = ql_wave_min48(key);
-                if (key == QL_NOKEY64) {                                       // nothing left to add: the syndrome is outside the column space
-                    if (lane == 0) cstate[c] = 3;
-                    inconsistent = 1;
-                    __syncthreads();
-                    continue;
+                int j;
+                {
+                    const BlkU16 own = own_blk;
+                    const BlkU32 bk = *reinterpret_cast<const BlkU32 *>(bkey + base);
+                    uint32_t kmin = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) if (own.v[k] == (uint16_t)c) kmin = min(kmin, bk.v[k]);
+                    const uint32_t K = qd_wave_umin(kmin);
+                    if (K == 0xFFFFFFFFu) {                                    // nothing left to add: the syndrome is outside the column space
+                        if (lane == 0) cstate[c] = 3;
+                        inconsistent = 1;
+                        __syncthreads();
+                        continue;
+                    }
+                    const BlkU16 bjb = *reinterpret_cast<const BlkU16 *>(bj + base);
+                    uint32_t jm = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) if (own.v[k] == (uint16_t)c && bk.v[k] == K) jm = min(jm, (uint32_t)bjb.v[k]);
+                    j = (int)qd_wave_umin(jm);
                 }
-                const int j = (int)(key & 0xFFFFu);
                 QL_T(4);
                 if (lane == 0) { added[j >> 5] |= 1u << (j & 31); cnbits[c] = (uint16_t)(cnbits[c] + 1); }
                 const int c0 = a.cp[j], c1 = a.cp[j + 1], deg = c1 - c0;
                 // the column's rows, once, into the first lanes (one vector load instead of a dependent scalar load per row)
                 const int myrow = lane < deg ? a.ri[c0 + lane] : -1;
                 __syncthreads();
-                // ---- its checks join; clusters owning one of them are absorbed; cached candidates that were this fault are redone
-                int nrs = 0;
-                for (int x = 0; x < deg; ++x) {
-                    const int i = __builtin_amdgcn_readlane(myrow, x);
-                    const int d = owner[i];
-                    if (d == QL_NONE) {
-                        if (lane == 0) owner[i] = (uint16_t)c;
-                        cm |= 1u << (i >> sh);
-                    } else if (d != c) {
-                        const uint32_t dm = (uint32_t)__builtin_amdgcn_readfirstlane((int)cmask[d]);
-                        QL_FOR_ROWS(dm, r) if (owner[r] == (uint16_t)d) owner[r] = (uint16_t)c;
-                        if (lane == 0) { cnbits[c] = (uint16_t)(cnbits[c] + cnbits[d]); cstate[d] = 3; }
-                        cm |= dm;
-                    }
-                    if (d == QL_NONE || (int)(best[i] & 0xFFFFu) == j) { if (lane == 0) rs[nrs] = (uint16_t)i; ++nrs; }
-                    __syncthreads();
+                // ---- its checks join; clusters owning one of them are absorbed; cached candidates that were this fault are redone.
+                // Lane x < deg holds row x of the column: owners and cached candidates are read once, free checks join in one
+                // store, and only the absorptions (about one per step) walk the owner blocks.
+                const int dv = lane < deg ? (int)owner[myrow] : (int)c;
+                const int bjv = lane < deg ? (int)bj[myrow] : -1;
+                if (lane < deg && dv == QL_NONE) owner[myrow] = (uint16_t)c;
+                const unsigned long long bres = __ballot(lane < deg && (dv == QL_NONE || bjv == j));
+                if ((bres >> lane) & 1ull) rs[__popcll(bres & lt_mask)] = (uint32_t)myrow;
+                const int nrs = __popcll(bres);
+                for (unsigned long long bm = __ballot(dv != QL_NONE && dv != c); bm; ) {
+                    const int d = __builtin_amdgcn_readlane(dv, (int)__builtin_ctzll(bm));
+                    bm &= ~__ballot(dv == d);                                  // every row of the column owned by d
+                    BlkU16 o2 = own_blk;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) o2.v[k] = o2.v[k] == (uint16_t)d ? (uint16_t)c : o2.v[k];
+                    own_blk = o2;
+                    if (lane == 0) { cnbits[c] = (uint16_t)(cnbits[c] + cnbits[d]); cstate[d] = 3; }
                 }
-                if (lane == 0) cmask[c] = cm;
+                __syncthreads();
                 QL_T(5);
-                scan_list(nrs);
+                // the rescans: their loads are issued here and consumed after the elimination (nothing in between reads
+                // the cached candidates), so the two memory latencies overlap with it
+                const bool overlap = nrs <= QL_NB && a.ell_w == 64;
+                if (!overlap) scan_list(rs, nrs);
+                int srow[QL_NB];
+                int2 sent[QL_NB];
+#pragma unroll
+                for (int b = 0; b < QL_NB; ++b) {
+                    srow[b] = overlap && b < nrs ? __builtin_amdgcn_readfirstlane((int)rs[b]) : -1;
+                    sent[b] = srow[b] >= 0 ? a.ell[(size_t)srow[b] * 64 + lane] : make_int2(-1, 0);
+                }
                 QL_T(6);
-                // ---- the column through the elimination
+                // ---- the column through the elimination: t = column + the pivot columns of its pivoted rows, on the cluster's rows
                 const int mypk = lane < deg ? (int)rowpiv[myrow] : -1;
-                if (lane < deg) tb[myrow] = 1;
-                uint64_t mk[2] = {0ull, 0ull};                                 // pivot orders of the column's pivoted rows, planes 0 and 1
-                int hi_planes = 0;                                             // a pivot order beyond plane 1: take the general loop
+                if (lane < deg) flags[myrow] |= (uint8_t)QL_F_T;
                 const unsigned long long bpk = __ballot(mypk >= 0);
-                for (unsigned long long bb = bpk; bb; bb &= bb - 1ull) {
-                    const int pk = __builtin_amdgcn_readlane(mypk, (int)__builtin_ctzll(bb));
-                    if (pk < 128) mk[pk >> 6] |= 1ull << (pk & 63); else hi_planes = 1;
-                }
                 __syncthreads();
-                uint32_t pkey = 0xFFFFFFFFu;
-                QL_FOR_ROWS(cm, r) {
-                    if (owner[r] != (uint16_t)c) continue;
-                    uint32_t t = tb[r];
-                    if (!hi_planes) {
-                        if (mk[0]) t ^= (uint32_t)__popcll(ql[r] & mk[0]) & 1u;
-                        if (mk[1]) t ^= (uint32_t)__popcll(ql[m_pad + r] & mk[1]) & 1u;
-                    } else {
-                        for (unsigned long long bb = bpk; bb; bb &= bb - 1ull) {            // (v_readlane reads any lane, active or not)
-                            const int pk = __builtin_amdgcn_readlane(mypk, (int)__builtin_ctzll(bb));
-                            t ^= (uint32_t)((q_ld(pk >> 6, r) >> (pk & 63)) & 1ull);
-                        }
+                const BlkU16 own = own_blk;
+                BlkU8 fl = fl_blk;
+                uint32_t memb = 0, tbits = 0, pivb = 0, spb = 0;              // bit k: row base + k
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const uint32_t f = fl.v[k];
+                    if (own.v[k] == (uint16_t)c) memb |= 1u << k;
+                    tbits |= ((f >> 1) & 1u) << k; pivb |= ((f >> 2) & 1u) << k; spb |= (f & 1u) << k;
+                }
+                tbits &= memb;
+                const int kwmax = (npiv + 63) / 64 - 1;
+                for (int w = 0; w <= kwmax; ++w) {
+                    uint64_t mkw = 0ull;                                       // orders, in plane w, of the column's pivoted rows
+                    for (unsigned long long bb = bpk; bb; bb &= bb - 1ull) {
+                        const int pk = __builtin_amdgcn_readlane(mypk, (int)__builtin_ctzll(bb));
+                        if ((pk >> 6) == w) mkw |= 1ull << (pk & 63);
                     }
-                    tb[r] = (uint8_t)t;
-                    if (t && rowpiv[r] < 0) pkey = min(pkey, (uint32_t)r);
+                    if (mkw == 0ull || memb == 0u) continue;
+                    BlkU64 qb;
+                    if (w < 2) qb = *reinterpret_cast<const BlkU64 *>(ql + w * MP + base);
+                    else qb = *reinterpret_cast<const BlkU64 *>(Q + (size_t)w * MP + base);
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) tbits ^= ((uint32_t)__popcll(qb.v[k] & mkw) & 1u) << k;
+                    tbits &= memb;
                 }
-                pkey = qd_wave_umin(pkey);
-                __syncthreads();
+                const uint32_t cand = tbits & ~pivb;                           // rows that may become the pivot: lowest index wins
+                const uint32_t pkey = qd_wave_umin(cand ? (uint32_t)(base + __builtin_ctz(cand)) : 0xFFFFFFFFu);
+                float slv[QL_NB];
+#pragma unroll
+                for (int b = 0; b < QL_NB; ++b) slv[b] = sent[b].x >= 0 ? llr[sent[b].y] : 0.0f;
                 QL_T(7);
                 if (pkey != 0xFFFFFFFFu) {
                     const int p = (int)pkey, K = npiv, kw = K >> 6;
                     const uint64_t kbit = 1ull << (K & 63);
                     if ((K & 63) == 0 && kw >= 2) {                            // a new HBM plane comes into use: clear it
-                        for (int r = lane; r < m_pad; r += 64) Q[(size_t)kw * m_pad + r] = 0ull;
+                        BlkU64 zero;
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) zero.v[k] = 0ull;
+                        *reinterpret_cast<BlkU64 *>(Q + (size_t)kw * MP + base) = zero;
                         __syncthreads();
                     }
-                    const uint32_t spp = sp[p];
-                    QL_FOR_ROWS(cm, r) {
-                        if (owner[r] != (uint16_t)c || !tb[r] || r == p) continue;
-                        for (int w = 0; w <= kw; ++w) {
-                            uint64_t v = q_ld(w, r) ^ q_ld(w, p);
-                            if (w == kw) v ^= kbit;
-                            q_st(w, r, v);
+                    const uint32_t mine = (p >= base && p < base + NR) ? 1u << (p - base) : 0u;
+                    const uint32_t spp = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags[p]) & QL_F_SP;
+                    const uint32_t updm = tbits & ~mine;                       // rows the pivot row is added to
+                    for (int w = 0; w <= kw; ++w) {
+                        if (w < 2) {
+                            uint64_t *qw = ql + w * MP;
+                            uint64_t x = qw[p];
+                            if (w == kw) x ^= kbit;
+                            if (updm) {
+                                BlkU64 qb = *reinterpret_cast<const BlkU64 *>(qw + base);
+#pragma unroll
+                                for (int k = 0; k < NR; ++k) qb.v[k] ^= ((updm >> k) & 1u) ? x : 0ull;
+                                *reinterpret_cast<BlkU64 *>(qw + base) = qb;
+                            }
+                        } else {
+                            uint64_t *qw = Q + (size_t)w * MP;
+                            uint64_t x = qw[p];
+                            if (w == kw) x ^= kbit;
+                            if (updm) {
+                                BlkU64 qb = *reinterpret_cast<const BlkU64 *>(qw + base);
+#pragma unroll
+                                for (int k = 0; k < NR; ++k) qb.v[k] ^= ((updm >> k) & 1u) ? x : 0ull;
+                                *reinterpret_cast<BlkU64 *>(qw + base) = qb;
+                            }
                         }
-                        if (spp) sp[r] ^= 1;
                     }
+                    if (spp) spb ^= updm;
+                    pivb |= mine;
                     if (lane == 0) { rowpiv[p] = (int16_t)K; pcol[p] = (uint16_t)j; }
                     npiv = K + 1;
                 }
+                // ---- flags back (image cleared); valid once no unpivoted check of the cluster carries syndrome
+#pragma unroll
+                for (int k = 0; k < NR; ++k) fl.v[k] = (uint8_t)(((spb >> k) & 1u) | (((pivb >> k) & 1u) << 2));
+                fl_blk = fl;
+                const bool anybad = __ballot((memb & spb & ~pivb) != 0u) != 0ull;
+                if (lane == 0) cstate[c] = anybad ? 1 : 2;
+                QL_T(9);
+#pragma unroll
+                for (int b = 0; b < QL_NB; ++b) {
+                    if (srow[b] < 0) break;                                    // uniform
+                    const uint32_t jj = (uint32_t)sent[b].x;
+                    const bool ok = sent[b].x >= 0 && !((added[jj >> 5] >> (jj & 31u)) & 1u);
+                    const uint32_t hi = ok ? ql_mono_key(slv[b]) : 0xFFFFFFFFu, mh = qd_wave_umin(hi);
+                    const uint32_t ml = qd_wave_umin((ok && hi == mh) ? jj : 0xFFFFu);
+                    if (lane == 0) { bkey[srow[b]] = mh; bj[srow[b]] = (uint16_t)ml; }
+                }
                 __syncthreads();
                 QL_T(8);
-                // ---- valid once no unpivoted check of the cluster carries syndrome
-                int bad = 0;
-                QL_FOR_ROWS(cm, r) {
-                    if (owner[r] == (uint16_t)c) { if (rowpiv[r] < 0 && sp[r]) bad = 1; tb[r] = 0; }
-                }
-                const bool anybad = __ballot(bad) != 0ull;
-                if (lane == 0) cstate[c] = anybad ? 1 : 2;
-                __syncthreads();
-                QL_T(9);
             }
             QL_T(3);
             __syncthreads();
         }
-        for (int r = lane; r < m; r += 64)                                     // err[pivot column] = transformed syndrome at the pivot row
-            if (rowpiv[r] >= 0 && sp[r]) { const uint32_t j = pcol[r]; atomicOr(&outw[j >> 5], 1u << (j & 31u)); }
+        {                                                                      // err[pivot column] = transformed syndrome at the pivot row
+            const BlkU8 fl = fl_blk;
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+                if ((fl.v[k] & (QL_F_SP | QL_F_PIV)) == (QL_F_SP | QL_F_PIV)) { const uint32_t j = pcol[base + k]; atomicOr(&outw[j >> 5], 1u << (j & 31u)); }
+        }
         __syncthreads();
         for (int w = lane; w < a.out_words; w += 64) a.err_bits[shot * a.out_words + w] = outw[w];
         if (lane == 0)
@@ -335,7 +418,7 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
 #ifdef QD_LSD_TIMING
 __global__ void qd_lsd_timing_print(unsigned long long *t)
 {
-    static const char *nm[16] = {"init", "seed scan", "round list", "select", "key scan", "join", "rescan", "elim t", "pivot upd", "validity",
+    static const char *nm[16] = {"init", "seed scan", "round list", "select", "key scan", "join", "rescan", "elim t", "rescan end", "pivot+valid",
                                  "output", "idle tail", "shots", "rounds", "steps", "-"};
     unsigned long long tot = 0;
     for (int k = 0; k < 12; ++k) tot += t[k];
@@ -344,59 +427,53 @@ __global__ void qd_lsd_timing_print(unsigned long long *t)
 }
 #endif
 
-// LDS footprint of one shot; fills the offsets of `a`
-static int lsd_layout(LsdArgs &a)
+// rows per lane for a window of m checks (0: too many), and the LDS footprint of one shot
+static int lsd_nr(int m) { return m <= 512 ? 8 : m <= 1024 ? 16 : m <= 1536 ? 24 : m <= 2048 ? 32 : 0; }
+static int lsd_lds(int nr, int n, int out_words)
 {
-    auto al = [](int x) { return (x + 15) & ~15; };
-    int o = 0;
-    a.off_best = o; o += al(a.m_pad * 8);
-    a.off_q = o; o += al(a.m_pad * 16);
-    a.off_cmask = o; o += al(a.m_pad * 4);
-    a.off_rl = o; o += al(a.m_pad * 4);
-    a.off_added = o; o += al(((a.n + 31) / 32) * 4);
-    a.off_out = o; o += al(a.out_words * 4);
-    a.off_owner = o; o += al(a.m_pad * 2);
-    a.off_rowpiv = o; o += al(a.m_pad * 2);
-    a.off_pcol = o; o += al(a.m_pad * 2);
-    a.off_cnbits = o; o += al(a.m_pad * 2);
-    a.off_rs = o; o += al(a.m_pad * 2);
-    a.off_sp = o; o += al(a.m_pad);
-    a.off_cstate = o; o += al(a.m_pad);
-    a.off_t = o; o += al(a.m_pad);
-    a.chunk_shift = 6;
-    while ((a.m_pad >> a.chunk_shift) > 32) ++a.chunk_shift;
-    return o;
+    const int fixed = nr == 8 ? QlLay<8>::o_added : nr == 16 ? QlLay<16>::o_added : nr == 24 ? QlLay<24>::o_added : QlLay<32>::o_added;
+    return fixed + ((((n + 31) / 32 + 3) & ~3) + ((out_words + 3) & ~3)) * 4;
 }
 
-int qd_lsd_lds_bytes(int m_pad, int n, int out_words)
+int qd_lsd_lds_bytes(int m, int n, int out_words)
 {
-    LsdArgs a{};
-    a.m_pad = m_pad; a.n = n; a.out_words = out_words;
-    if (n > 65535) return 1 << 30;                  // candidate keys carry the fault in 16 bits
-    return lsd_layout(a);
+    if (n > 65535 || lsd_nr(m) == 0) return 1 << 30;                           // candidate keys carry the fault in 16 bits
+    return lsd_lds(lsd_nr(m), n, out_words);
 }
+
+// rows of one Q plane in the HBM workspace
+int qd_lsd_plane_rows(int m) { return 64 * lsd_nr(m); }
 
 hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks, hipStream_t s)
 {
     LsdArgs a{};
-    a.m = gg.m; a.n = gg.n; a.m_pad = bg.m_pad; a.n_pad = bg.n_pad; a.mw = (gg.m + 63) / 64; a.out_words = bg.out_words;
-    a.upd_rows = d.upd_rows; a.max_cdeg = bg.max_cdeg;
-    a.rp = gg.rp; a.ci = gg.ci; a.cp = gg.cp; a.ri = gg.ri; a.bit_slot_of = bg.bit_slot_of;
+    const int nr = lsd_nr(gg.m);
+    if (nr == 0 || gg.n > 65535) return hipErrorInvalidValue;
+    a.m = gg.m; a.n = gg.n; a.n_pad = bg.n_pad; a.mw = (gg.m + 63) / 64; a.out_words = bg.out_words;
+    a.upd_rows = d.upd_rows;
+    a.cp = gg.cp; a.ri = gg.ri;
     a.ell = reinterpret_cast<const int2 *>(gg.ell); a.ell_w = gg.ell_w;
     a.det = d.det; a.upd = d.upd; a.det_stride = d.det_stride; a.det_offset = d.det_offset; a.upd_stride = d.upd_stride;
     a.llr_ws = d.llr_ws; a.fail_list = d.fail_list; a.fail_count = d.fail_count; a.q_ws = q_ws;
     a.err_bits = d.err_bits; a.status = d.status;
-    const int lds = lsd_layout(a);
-    a.next_slot = reinterpret_cast<int32_t *>(q_ws + (size_t)blocks_alloc * a.mw * a.m_pad);
+    const int lds = lsd_lds(nr, gg.n, bg.out_words);
+    a.next_slot = reinterpret_cast<int32_t *>(q_ws + (size_t)blocks_alloc * a.mw * 64 * nr);
 #ifdef QD_LSD_TIMING
     hipError_t e = hipMemsetAsync(a.next_slot, 0, sizeof(uint64_t) * 17, s);
 #else
     hipError_t e = hipMemsetAsync(a.next_slot, 0, sizeof(uint64_t), s);
 #endif
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute((const void *)qd_lsd0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const void *fn = nr == 8 ? (const void *)qd_lsd0_kernel<8> : nr == 16 ? (const void *)qd_lsd0_kernel<16>
+                   : nr == 24 ? (const void *)qd_lsd0_kernel<24> : (const void *)qd_lsd0_kernel<32>;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(qd_lsd0_kernel, dim3((unsigned)blocks), dim3(64), lds, s, a);
+    switch (nr) {
+    case 8: hipLaunchKernelGGL(qd_lsd0_kernel<8>, dim3((unsigned)blocks), dim3(64), lds, s, a); break;
+    case 16: hipLaunchKernelGGL(qd_lsd0_kernel<16>, dim3((unsigned)blocks), dim3(64), lds, s, a); break;
+    case 24: hipLaunchKernelGGL(qd_lsd0_kernel<24>, dim3((unsigned)blocks), dim3(64), lds, s, a); break;
+    default: hipLaunchKernelGGL(qd_lsd0_kernel<32>, dim3((unsigned)blocks), dim3(64), lds, s, a); break;
+    }
 #ifdef QD_LSD_TIMING
     hipLaunchKernelGGL(qd_lsd_timing_print, dim3(1), dim3(1), 0, s, reinterpret_cast<unsigned long long *>(a.next_slot) + 1);
 #endif

@@ -17,7 +17,8 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s);
 hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks, hipStream_t s);
-int qd_lsd_lds_bytes(int m_pad, int n, int out_words);
+int qd_lsd_lds_bytes(int m, int n, int out_words);
+int qd_lsd_plane_rows(int m);
 hipError_t qd_launch_stage_llr(const float *llr_in, int n, int n_pad, const uint32_t *bit_orig, int64_t B, float *llr_ws,
                                int32_t *fail_list, int32_t *fail_count, int32_t *status, hipStream_t s);
 hipError_t qd_launch_spmv(const SpmatDev &A, const uint32_t *err, int64_t err_stride, int64_t B, uint8_t *out,
@@ -523,7 +524,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     const bool lsd = p->osd_method == QD_LSD_0;
     if (lsd && p->osd_order != 0)
         return fail(QD_EUNSUPPORTED, "BP-LSD: lsd_order %d > 0 is not implemented on the device path (LSD-0 only)", p->osd_order);
-    if (lsd && qd_lsd_lds_bytes(g->bp.m_pad, g->n, g->bp.out_words) > QD_LDS_BYTES)
+    if (lsd && qd_lsd_lds_bytes(g->m, g->n, g->bp.out_words) > QD_LDS_BYTES)
         return fail(QD_ECAPACITY, "window %d x %d does not fit the LSD kernel's LDS layout", g->m, g->n);
     const bool osd0 = lsd || p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
     if (p->osd_method != QD_OSD_OFF && !osd0) {
@@ -653,10 +654,10 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         }
         if (d->osd_w) d->osd_blocks_fast = ncu;                         // higher-order OSD: one workgroup per CU (w_* layout)
         if (d->lsd) {
-            const int lds = qd_lsd_lds_bytes(g->bp.m_pad, g->n, g->bp.out_words);
+            const int lds = qd_lsd_lds_bytes(g->m, g->n, g->bp.out_words);
             d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
             d->lsd_ws = nullptr;
-            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * ((size_t)d->lsd_blocks * g->osd.mw * g->osd.m_pad + 32)));   // + the work counter (+ debug timers)
+            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * ((size_t)d->lsd_blocks * ((g->m + 63) / 64) * qd_lsd_plane_rows(g->m) + 32)));   // + the work counter (+ debug timers)
         }
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
