@@ -595,6 +595,45 @@ def test_bplsd_crafted_soft_information_and_inconsistent(gpu):
     assert (status[B - 4:] & (1 << 18)).any()
 
 
+@pytest.mark.parametrize("rows", [1296, 1708])
+def test_bplsd_wide_windows(gpu, rows):
+    """The LSD kernel's other row-block instantiations (24 and 32 checks per lane: 1025..1536 and 1537..2048 checks), LSD alone
+    on crafted soft information over block-diagonal matrices assembled from the committed windows; vs the oracle, bit for bit."""
+    import torch
+    from scipy.sparse import block_diag, csc_matrix
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    Ha, La, pa = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    if rows == 1296:
+        Hb, Lb, pb = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    else:
+        Hb, pb = csc_matrix(Ha[:700]), pa
+    H = csc_matrix(block_diag([Ha, Hb], format="csc"))
+    pri = np.concatenate([pa, pb])
+    m, n = H.shape
+    assert m == rows and n <= 65535
+    rng = np.random.default_rng(rows)
+    B = 12
+    e = (rng.random((B, n)) < np.minimum(4 * pri, 0.4)).astype(np.uint8)
+    synd = np.ascontiguousarray(np.asarray((csc_matrix(e) @ H.T).todense()) % 2, dtype=np.uint8)
+    llr = rng.normal(size=(B, n)).astype(np.float32) + 2.0
+    llr[:3] = np.log((1 - pri) / pri).astype(np.float32)
+    llr[e.astype(bool)] -= 3.0
+    wg = WindowGraph(H, pri)
+    dec = BatchDecoder(wg, max_iter=1, osd_method="lsd_0")
+    bits, status = dec.osd0(torch.from_numpy(synd).cuda(), torch.from_numpy(llr).cuda())
+    err, status = unpack_bits(bits, n).cpu().numpy(), status.cpu().numpy()
+    g = orc.Graph(H, pri)
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    big = 0
+    for b in range(B):
+        ref, st = g.lsd0(synd[b], llr[b].astype(np.float64))
+        assert np.array_equal(err[b], ref), b
+        assert ((status[b] >> 20) & 0xFFF) == min(st["pivots"], 4095) and not st["inconsistent"], (b, st)
+        big = max(big, st["pivots"])
+    assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+    assert big > 128, "no shot reached the Q planes kept in HBM"
+
+
 def test_bplsd_sliding_window_functions(gpu):
     """sliding_window_bplsd_circuit_mem / _phenom_mem (reference bplsd.py:10,54) on the device against the oracle's loop."""
     from quits_amd.decoder import BpLsdDecoder, sliding_window_bplsd_circuit_mem, sliding_window_bplsd_phenom_mem
