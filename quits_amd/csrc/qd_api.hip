@@ -458,6 +458,23 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         for (int per_cu = 2; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu)
             od.f_lds_bytes = lay(per_cu, false, od.f_off, od.f_off_sort, od.f_off_order, od.f_off_pivmask, od.f_off_npl, od.f_kw);
         od.w_lds_bytes = lay(1, true, od.w_off, od.w_off_sort, od.w_off_order, od.w_off_pivmask, od.w_off_npl, od.w_kw);
+        // the column-form kernel (osd_kernels.hip, qd_osdw_col_kernel): 512 threads, 2 columns of 16 words each (m <= 1024, two
+        // workgroups per CU by registers) or 3 of 22 (m <= 1408, one per CU); the Q region holds 64 pending columns, one word
+        // per pivot and a few vectors
+        od.c_lds_bytes = 0; od.c_cpt = 0; od.c_per_cu = 0;
+        if (od.w_lds_bytes > 0 && od.f_threads == 512 && m <= 1408) {
+            const int cpt = m <= 1024 ? 2 : 3, nwd = m <= 1024 ? 16 : 22;
+            const int need = (64 * nwd + 512 * cpt + 2 * nwd) * 8 + 512;
+            int o = carve(od.c_off, need, 0);
+            od.c_off_sort = o; o += sort_b;
+            od.c_off_order = o; o += order_b;
+            od.c_off_pivmask = o; o += align16(bp.out_words * 4);
+            od.c_off_npl = o; o += 256;
+            if (o <= QD_LDS_BYTES) {
+                od.c_lds_bytes = o; od.c_cpt = cpt;
+                od.c_per_cu = std::max(1, std::min(cpt == 2 ? 2 : 1, QD_LDS_BYTES / o));
+            }
+        }
     }
     // the full kernel sorts all n columns in LDS; windows too large for that rely on the register kernel alone
     if (od.lds_bytes == 0 && od.f_lds_bytes == 0) od.threads = 0;
@@ -652,7 +669,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
             const int v = std::atoi(ev);
             if (v > 0) d->osd_blocks_fast = ncu * v;
         }
-        if (d->osd_w) d->osd_blocks_fast = ncu;                         // higher-order OSD: one workgroup per CU (w_* layout)
+        if (d->osd_w) d->osd_blocks_fast = ncu * std::max(1, g->osd.c_per_cu);   // higher-order OSD: w_* layout (one workgroup per CU) or the column kernel's
         if (d->lsd) {
             const int lds = qd_lsd_lds_bytes(g->m, g->n, g->bp.out_words);
             d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
