@@ -1506,6 +1506,10 @@ __global__ void __launch_bounds__(T, WPS) qd_osdw_col_kernel(OsdRegArgs a)
         const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
         const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
 
+#ifdef QD_OSD_TIMING
+        unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long tick_ = wall_clock64();
+#endif
         uint64_t mycol[CPT][NWD];
 #pragma unroll
         for (int i = 0; i < CPT; ++i)
@@ -1527,8 +1531,10 @@ __global__ void __launch_bounds__(T, WPS) qd_osdw_col_kernel(OsdRegArgs a)
         uint32_t lo_key = 0, lo_idx = 0;
         for (;;) {
             TierState ts{lo_key, lo_idx, sphase, 0, QD_OSD_TIER};
+            QD_TICK(10)
             const int cnt = qd_osd_draw_tier<T>(a, llr, sortbuf, order, red, sumbuf, ts);
             lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
+            QD_TICK(0)
             if (ts.exhausted) break;
             if (npiv >= a.rank) {                              // factorisation complete: every further column is a non-pivot column
                 if (tid == 0)
@@ -1571,17 +1577,25 @@ __global__ void __launch_bounds__(T, WPS) qd_osdw_col_kernel(OsdRegArgs a)
                         }
                 }
                 __syncthreads();
+                QD_TICK(1)
                 // ---- pivots of the batch, in column order
                 int cur = 0, ph = 0;
+                constexpr int XI = (64 * NWD + T - 1) / T;     // pending words per thread
+                bool fresh[XI];                                // the column of my word changed (or is new): its first unpivoted row has to be found again
+#pragma unroll
+                for (int q = 0; q < XI; ++q) fresh[q] = true;
                 for (;;) {
-                    for (int x = tid; x < 64 * NWD; x += T) {
-                        const int c = x / NWD, w = x - c * NWD;
-                        if (c >= cur && c < nb) {
+#pragma unroll
+                    for (int q = 0; q < XI; ++q) {
+                        const int x = tid + q * T, c = x / NWD, w = x - c * NWD;
+                        if (x < 64 * NWD && fresh[q] && c >= cur && c < nb) {
                             const uint64_t nz = TB[x] & ~pivm[w];
                             if (nz) atomicMin(&cand[ph * 64 + c], (uint32_t)(w * 64 + (int)__builtin_ctzll(nz)));
                         }
                     }
+                    QD_TICK(4)
                     __syncthreads();
+                    QD_TICK(5)
                     const uint32_t cv = cand[ph * 64 + lane];
                     const unsigned long long live = __ballot(cv != QD_NOKEY);
                     const bool more = live != 0ull && npiv < a.rank;
@@ -1596,35 +1610,63 @@ __global__ void __launch_bounds__(T, WPS) qd_osdw_col_kernel(OsdRegArgs a)
                     const int K = npiv, pw = p >> 6;
                     const uint64_t pb = 1ull << (p & 63);
                     const uint64_t *tq = TB + cstar * NWD;     // nobody writes this column any more
+                    // t' = the column's image without bit p.  Every vector that has bit p set gets the image added as it is and bit p
+                    // toggled back; so does the new column K (all zero until now: it becomes t').  The word that holds bit p is
+                    // picked by a scalar switch (pw is wave-uniform): registers cannot be indexed, and a select chain costs 2 NWD
+                    // instructions per column and round.
+                    uint64_t sel[CPT];
+#pragma unroll
+                    for (int i = 0; i < CPT; ++i) sel[i] = 0ull;
+                    switch (pw) {
+#define QD_X(W) case W: if constexpr (W < NWD) { _Pragma("unroll") for (int i = 0; i < CPT; ++i) sel[i] = mycol[i][W < NWD ? W : 0]; } break;
+                        QD_X(0) QD_X(1) QD_X(2) QD_X(3) QD_X(4) QD_X(5) QD_X(6) QD_X(7) QD_X(8) QD_X(9) QD_X(10) QD_X(11)
+                        QD_X(12) QD_X(13) QD_X(14) QD_X(15) QD_X(16) QD_X(17) QD_X(18) QD_X(19) QD_X(20) QD_X(21) QD_X(22) QD_X(23)
+#undef QD_X
+                        default: break;
+                    }
+                    uint64_t tog[CPT];
 #pragma unroll
                     for (int i = 0; i < CPT; ++i) {
                         const int k = tid + i * T;
-                        uint64_t sel = 0ull;
+                        tog[i] = 0ull;
+                        if ((k < K && (sel[i] & pb)) || k == K) {   // (a wavefront whose columns all lie beyond K, or miss bit p, skips this)
 #pragma unroll
-                        for (int w = 0; w < NWD; ++w) sel = (w == pw) ? mycol[i][w] : sel;
-                        if (k < K && (sel & pb)) {
-#pragma unroll
-                            for (int w = 0; w < NWD; ++w) mycol[i][w] ^= (w == pw) ? (tq[w] & ~pb) : tq[w];
-                        } else if (k == K) {
-#pragma unroll
-                            for (int w = 0; w < NWD; ++w) mycol[i][w] = (w == pw) ? (tq[w] & ~pb) : tq[w];
+                            for (int w = 0; w < NWD; ++w) mycol[i][w] ^= tq[w];
+                            tog[i] = pb;
                         }
                     }
-                    for (int x = tid; x < 64 * NWD; x += T) {
-                        const int c = x / NWD, w = x - c * NWD;
-                        if (c > cstar && c < nb && (TB[c * NWD + pw] & pb)) TB[x] ^= (w == pw) ? (tq[w] & ~pb) : tq[w];
+                    switch (pw) {
+#define QD_X(W) case W: if constexpr (W < NWD) { _Pragma("unroll") for (int i = 0; i < CPT; ++i) mycol[i][W < NWD ? W : 0] ^= tog[i]; } break;
+                        QD_X(0) QD_X(1) QD_X(2) QD_X(3) QD_X(4) QD_X(5) QD_X(6) QD_X(7) QD_X(8) QD_X(9) QD_X(10) QD_X(11)
+                        QD_X(12) QD_X(13) QD_X(14) QD_X(15) QD_X(16) QD_X(17) QD_X(18) QD_X(19) QD_X(20) QD_X(21) QD_X(22) QD_X(23)
+#undef QD_X
+                        default: break;
                     }
-                    if (tid < NWD && (sv[pw] & pb)) sv[tid] ^= (tid == pw) ? (tq[tid] & ~pb) : tq[tid];
+#pragma unroll
+                    for (int q = 0; q < XI; ++q) {
+                        const int x = tid + q * T, c = x / NWD, w = x - c * NWD;
+                        fresh[q] = false;
+                        if (x < 64 * NWD && c < nb) {
+                            const bool hit = c > cstar && (TB[c * NWD + pw] & pb);
+                            if (hit) TB[x] ^= tq[w] ^ ((w == pw) ? pb : 0ull);
+                            fresh[q] = hit;
+                            // next round's candidates: kept for the columns this pivot leaves alone
+                            if (w == 0) cand[(ph ^ 1) * 64 + c] = (c > cstar && !hit) ? cand[ph * 64 + c] : QD_NOKEY;
+                        }
+                    }
+                    if (tid < NWD && (sv[pw] & pb)) sv[tid] ^= tq[tid] ^ ((tid == pw) ? pb : 0ull);
                     if (tid == T - 1) {
                         const uint32_t pc = S.bcols[cstar];
                         S.rowpiv[p] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = pc;
                         atomicOr(&pivmask[pc >> 5], 1u << (pc & 31u));
                     }
                     if (tid == T - 2) pivm[pw] |= pb;
-                    if (tid < 64) cand[(ph ^ 1) * 64 + tid] = QD_NOKEY;
                     npiv = K + 1; cur = cstar + 1; ph ^= 1;
+                    QD_TICK(7)
                     __syncthreads();
+                    QD_TICK(6)
                 }
+                QD_TICK(2)
                 __syncthreads();
                 if (npiv >= a.rank) {                          // the rest of this tier is non-pivot as well
                     const int rest0 = base + 64;
@@ -1653,10 +1695,18 @@ __global__ void __launch_bounds__(T, WPS) qd_osdw_col_kernel(OsdRegArgs a)
             }
         }
         __syncthreads();
+        QD_TICK(2)
         if (NWD <= 16) qd_osd_sweep_t<T, 16, true>(a, smem, llr, nullptr, mt, npiv, nnp);
         else qd_osd_sweep_t<T, 32, true>(a, smem, llr, nullptr, mt, npiv, nnp);
         for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = S.outw[w];
         if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
+        QD_TICK(3)
+#ifdef QD_OSD_TIMING
+        if (tid == 0) {
+            for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc_[i]);
+            atomicAdd(&a.dbg[8], 1ull); atomicAdd(&a.dbg[9], (unsigned long long)npiv); atomicAdd(&a.dbg[10], acc_[10]);
+        }
+#endif
         __syncthreads();   // LDS is recycled by the next shot
     }
 }
