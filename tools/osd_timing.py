@@ -6,7 +6,12 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch, helpers
 from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
 name = os.environ.get("FIXTURE", "bb144_custom_r12_p0.003")
-if os.path.exists(os.path.join(helpers.GOLD, "windows", name + ".npz")):
+if os.environ.get("WINDOW"):                      # WINDOW=W,F,k: window k of the reference's spacetime(W, F) for the fixture
+    W_, F_, k_ = (int(v) for v in os.environ["WINDOW"].split(","))
+    win = helpers.window_set(name, W_, F_)[k_]
+    H, pri = win["H"], win["priors"]
+    L = H[:8]                                     # (the window's commit matrix covers fewer columns; the observables are not used here)
+elif os.path.exists(os.path.join(helpers.GOLD, "windows", name + ".npz")):
     H, L, pri = helpers.dem_matrices(name)
 else:
     from quits_amd.decoder.base import detector_error_model_to_matrix
