@@ -44,7 +44,7 @@ def random_graph(rng):
 
 def run(trials=200, seed=1):
     rng = np.random.default_rng(seed)
-    t0 = time.time(); ok = 0; skipped = 0
+    t0 = time.time(); ok = 0; skipped = 0; inexact = 0; inexact_same = 0
     configs = [("minimum_sum", "parallel", False), ("minimum_sum", "parallel", True), ("product_sum", "parallel", True),
                ("product_sum", "serial", True), ("minimum_sum", "serial", True)]
     for t in range(trials):
@@ -61,7 +61,8 @@ def run(trials=200, seed=1):
         if rng.random() < 0.3:
             synd[rng.integers(0, B)] = 0
         method, sched, edge = configs[int(rng.integers(0, len(configs)))]
-        osd, order = [("osd_0", 0), ("osd_off", 0), ("osd_cs", int(rng.integers(0, 6))), ("osd_e", int(rng.integers(0, 5))), ("osd_0", 0)][int(rng.integers(0, 5))]
+        osd, order = [("osd_0", 0), ("osd_off", 0), ("osd_cs", int(rng.integers(0, 6))), ("osd_e", int(rng.integers(0, 5))), ("osd_0", 0),
+                      ("lsd_0", 0), ("osd_cs", int(rng.integers(1, 12)))][int(rng.integers(0, 7))]
         max_iter = int(rng.integers(1, 25)) if sched == "parallel" else int(rng.integers(1, 6))
         alpha = float(rng.choice([1.0, 1.0, 0.0, 0.625]))
         try:
@@ -78,23 +79,31 @@ def run(trials=200, seed=1):
         if edge and form == orc.FORM_COMPRESSED_F32:
             form = orc.FORM_LDPC_F32
         ref, flags, grid = go.decode_batch(synd, orc.make_params(method, sched, max_iter, osd, order, alpha, form), return_grid=True)
+        exact = np.ones(B, bool)
         if not edge and go.grid[0] >= 0:
             assert np.array_equal((st >> 14) & 1, (grid[:, 0] != go.grid[0]).astype(int)), ("coarse grid", (t, m, n))
+            # QD_STATUS_INEXACT: the exactness bound tripped on the coarse grid too (messages of weight-1 checks are +-FLT_MAX,
+            # sums of them overflow).  The oracle's own bound must say the same; such shots are outside the bit-exact contract.
+            assert np.array_equal((st >> 15) & 1, grid[:, 1]), ("inexact flag", (t, m, n))
+            exact = grid[:, 1] == 0
+            inexact += int((~exact).sum())
+            inexact_same += int(((err == ref).all(axis=1) & ~exact).sum())
         elif edge and go.grid[0] >= 0 and (grid[:, 0] != go.grid[0]).any():
             skipped += 1; continue                   # the edge kernel has no coarse-grid pass: such a batch is not comparable
         tag = (t, m, n, B, method, sched, edge, osd, order, max_iter, alpha)
-        assert np.array_equal((st >> 16) & 1, flags[:, 0]), ("converged", tag)
-        nz = synd.any(axis=1)
+        assert np.array_equal(((st >> 16) & 1)[exact], flags[exact, 0]), ("converged", tag)
+        nz = synd.any(axis=1) & exact
         assert np.array_equal((st & 0x3FFF)[nz], flags[nz, 1]), ("iterations", tag)
-        assert np.array_equal(err, ref), ("decisions", tag, np.nonzero((err != ref).any(axis=1))[0][:5])
+        assert np.array_equal(err[exact], ref[exact]), ("decisions", tag, np.nonzero((err != ref).any(axis=1) & exact)[0][:5])
         if osd != "osd_off":
-            assert np.array_equal((st >> 17) & 1, 1 - flags[:, 0]), ("osd flag", tag)
-            if osd == "osd_0" or order == 0:
-                used = ((st >> 17) & 1) == 1
+            assert np.array_equal(((st >> 17) & 1)[exact], (1 - flags[:, 0])[exact]), ("osd flag", tag)
+            if osd in ("osd_0", "lsd_0") or order == 0:
+                used = (((st >> 17) & 1) == 1) & exact
                 assert np.array_equal(((st >> 20) & 0xFFF)[used], np.minimum(flags[used, 2], 4095)), ("pivots", tag)
                 assert np.array_equal(((st >> 18) & 1)[used], (flags[used, 3] != 0).astype(int)), ("inconsistent", tag)
         ok += 1
-    print("stress parity: %d cases identical, %d skipped (unsupported by the device path), %.0f s" % (ok, skipped, time.time() - t0))
+    print("stress parity: %d cases identical, %d skipped (unsupported by the device path), %d shots flagged QD_STATUS_INEXACT by device and oracle alike (outside the contract; %d of them decoded identically anyway), %.0f s"
+          % (ok, skipped, inexact, inexact_same, time.time() - t0))
     return ok, skipped
 
 
