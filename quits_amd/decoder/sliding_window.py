@@ -127,8 +127,10 @@ class DeviceWindowPlan:
 
         Windows outer, shots inner, in chunks of `_CHUNK` shots; everything stays on the caller's stream.  `stats`, if
         given, receives (window index, status tensor) pairs.  (Overlapping the OSD of one sub-batch with the BP of the
-        next on a second stream -- qd_decode_stage exists for that -- was measured and bought nothing: both kernels are
-        bound by vector-ALU issue, so they simply slow each other down)"""
+        next on a second stream -- qd_decode_stage exists for that -- was measured again in round 2 (tools/overlap_probe.py,
+        two decoders = two workspaces): 70.6 -> 68.0 ms per 65 536 headline shots, 3.7 %.  Two BP workgroups fill a CU's
+        32 wavefront slots, so an OSD workgroup only gets in by displacing one of them; not worth a second set of
+        workspaces in the driver.)"""
         import torch
         N = det.shape[0]
         pred = torch.zeros((N, self.nobs), dtype=torch.uint8, device=det.device)
