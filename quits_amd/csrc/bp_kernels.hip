@@ -55,9 +55,10 @@ __device__ __forceinline__ float qd_min_abs(float a, float b)
 // Branch-free: the second minimum is the median of (min1, min2, |b|); the new sign bits are shifted in from bit 0.
 // (b <= 0) is taken as the sign bit of (bits(b) - 1): exact for every float except -0.0, which cannot occur here -- a
 // posterior is a sum that starts from a non-zero prior, and x - y only yields -0 from (-0) - (+0).
-#define QD_CHECK_EDGE(off, sb)                                                                               \
+#define QD_CHECK_EDGE(off, sb) QD_CHECK_EDGE_L(off, sb, (*(const __attribute__((address_space(3))) float *)(uintptr_t)(uint32_t)(off)))
+#define QD_CHECK_EDGE_L(off, sb, Lval)                                                                       \
     {                                                                                                        \
-        const float L_ = *(const __attribute__((address_space(3))) float *)(uintptr_t)(uint32_t)(off);       \
+        const float L_ = (Lval);                                                                             \
         const float mag_ = ((off) == idx_old) ? st.y : st.x;                                                 \
         const float prev_ = __uint_as_float(((sgnw >> (sb)) & 1u) << 31 | __float_as_uint(mag_));            \
         const float bm_ = L_ - prev_;                  /* bit->check message, "total minus own" */            \
@@ -213,10 +214,26 @@ __global__ void __launch_bounds__(T, MW) qd_bp_minsum_kernel(BpGraphDev g, Decod
                     const ADJ4 cur = nx;
                     nx = ap[(size_t)((kk >> 2) + 1) * m_pad];                       // next four fault offsets while these are processed
                     const int sb = kend - 1 - kk;
+                    if constexpr (SM == 2) {
+                    // wide checks (> 44 faults: the QLP windows, one workgroup per CU, four wavefronts per SIMD): the four
+                    // posteriors of the trip are gathered before any is used.  +3 % there; -3 % at the headline window, where
+                    // eight wavefronts per SIMD hide the gather's latency and the early loads only add register pressure.
+                    float g0_, g1_, g2_, g3_;
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(g0_) : "v"((uint32_t)qd_adj_get<0>(cur)) : "memory");
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(g1_) : "v"((uint32_t)qd_adj_get<1>(cur)) : "memory");
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(g2_) : "v"((uint32_t)qd_adj_get<2>(cur)) : "memory");
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(g3_) : "v"((uint32_t)qd_adj_get<3>(cur)) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(g0_), "+v"(g1_), "+v"(g2_), "+v"(g3_) : : "memory");
+                    QD_CHECK_EDGE_L(qd_adj_get<0>(cur), sb, g0_)
+                    QD_CHECK_EDGE_L(qd_adj_get<1>(cur), sb - 1, g1_)
+                    QD_CHECK_EDGE_L(qd_adj_get<2>(cur), sb - 2, g2_)
+                    QD_CHECK_EDGE_L(qd_adj_get<3>(cur), sb - 3, g3_)
+                    } else {
                     QD_CHECK_EDGE(qd_adj_get<0>(cur), sb)
                     QD_CHECK_EDGE(qd_adj_get<1>(cur), sb - 1)
                     QD_CHECK_EDGE(qd_adj_get<2>(cur), sb - 2)
                     QD_CHECK_EDGE(qd_adj_get<3>(cur), sb - 3)
+                    }
                 }
                 {
                     // last group: edges beyond the wavefront's largest degree are padding for every lane (posterior +inf:
