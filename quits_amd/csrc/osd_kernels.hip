@@ -1760,7 +1760,7 @@ static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const D
     // higher-order OSD: elimination by column (qd_osdw_col_kernel) when the host laid it out (c_* layout)
     int colk = 0;
     if constexpr (TF == 512) {
-        static const bool row_form = std::getenv("QD_OSDW_ROWS") && std::atoi(std::getenv("QD_OSDW_ROWS")) == 1;   // the round-1 kernel, for A/B runs
+        const bool row_form = std::getenv("QD_OSDW_ROWS") && std::atoi(std::getenv("QD_OSDW_ROWS")) == 1;   // the round-1 kernel, for A/B runs
         if (wl && a.mt_ws && !row_form && g.c_lds_bytes > 0) colk = g.c_cpt;
     }
     const int lds = colk ? g.c_lds_bytes : wl ? g.w_lds_bytes : g.f_lds_bytes;

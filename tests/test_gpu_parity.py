@@ -670,6 +670,35 @@ def test_bplsd_sliding_window_functions(gpu):
     assert np.array_equal(d1.decode(s1.astype(int)), go.decode_batch(s1.reshape(1, -1), prm)[0][0])
 
 
+def test_osdw_row_form_and_column_form_agree(gpu, monkeypatch):
+    """Higher-order OSD has two full-rank eliminations: by column (qd_osdw_col_kernel, the default where the window fits it)
+    and by row (qd_osd0_reg_kernel<.., true>: QD_OSDW_ROWS=1, and every window of more than 1408 checks).  Same pivots, same
+    sweep, same bits -- on the headline window both ways, and on a 1708-check block-diagonal window (row form only) vs the oracle."""
+    import torch
+    from scipy.sparse import block_diag, csc_matrix
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    Ha, La, pa = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    for H, pri, shots in ((Ha, pa, 8), (csc_matrix(block_diag([Ha, csc_matrix(Ha[:700])], format="csc")), np.concatenate([pa, pa]), 4)):
+        m, n = H.shape
+        rng = np.random.default_rng(m)
+        e = (rng.random((shots, n)) < 2 * pri).astype(np.uint8)
+        synd = np.ascontiguousarray(np.asarray((csc_matrix(e) @ H.T).todense()) % 2, dtype=np.uint8)
+        llr = (np.log((1 - pri) / pri)[None, :] + rng.normal(size=(shots, n))).astype(np.float32)
+        llr[e.astype(bool)] -= 4.0
+        wg = WindowGraph(H, pri)
+        out = []
+        for rows in ("0", "1"):
+            monkeypatch.setenv("QD_OSDW_ROWS", rows)
+            dec = BatchDecoder(wg, max_iter=1, osd_method="osd_cs", osd_order=3)
+            bits, status = dec.osd0(torch.from_numpy(synd).cuda(), torch.from_numpy(llr).cuda())
+            out.append((unpack_bits(bits, n).cpu().numpy(), status.cpu().numpy()))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        g = orc.Graph(H, pri)
+        for b in range(shots):
+            ref, st = g.osd_w(synd[b], llr[b].astype(np.float64), "osd_cs", 3, fixed=True)
+            assert np.array_equal(out[0][0][b], ref), (m, b, st)
+
+
 def test_osd_wave_path_bit_exact(gpu, monkeypatch):
     """The opt-in one-wavefront-per-shot OSD-0 kernel (csrc/osd_wave.hip, QD_OSD_WAVE=1; shots it cannot finish go to the
     workgroup-per-shot kernel): same corrections, pivot counts and flags as the default path and as the oracle."""
