@@ -14,14 +14,15 @@
 //   - correction: err[pivot column k] = transformed syndrome at pivot row k.
 //
 // Mapping: the work of one shot is a chain of ~100 dependent growth steps on clusters of a few dozen checks -- far too little
-// for a workgroup, so a shot gets one wavefront (lane = check for the scans over the m rows, lane = row entry when a check's
-// best candidate is recomputed) and a CU runs several shots side by side (about 40 KB of LDS per shot at the headline
-// window).  Each check caches its best candidate (lowest (LLR, index) among its unused faults) in LDS, so a growth step is
-// a wave-minimum over the cluster's checks, plus a rescan of the checks that joined or whose cached candidate was just used.
-// A step is a chain of dependent memory round trips, so everything a step touches sits in LDS -- including the first two Q
-// planes (pivot orders 0..127; later planes, rarely reached, live in a per-slot HBM workspace) -- and the only global loads
-// left, the rescans, are batched: rows in ELL form {fault, posterior column}, QL_NB rows in flight at a time, two latencies
-// (entries, then LLRs) per batch.
+// for a workgroup, so a shot gets one wavefront and a CU runs eight shots side by side (19.7 KB of LDS per shot at the headline
+// window; shots are handed out through a work counter, they differ by 10x in steps).  A lane owns a BLOCK of NR consecutive
+// checks, so every scan over the rows (best candidate of a cluster, absorbing a cluster, image of the new column, pivot update,
+// validity) is a few 128-bit LDS loads plus register work.  Each check caches its best candidate (lowest (LLR, index) among its
+// unused faults); rescans -- checks that joined, or whose cached fault was just used -- read the row in ELL form {fault,
+// posterior column}, QL_NB rows in flight at a time, two memory latencies per batch, overlapped with the step's elimination.
+// The Q planes live in a per-slot HBM workspace (L2-resident; a lane reads and writes its own block of rows with 128-bit
+// accesses): keeping two of them in LDS (39 KB per shot, four shots per CU) measured 38.4 ms per 65536 headline shots, none
+// 32.6 ms -- a growth step is a chain of dependent instructions, and what hides it is more shots per SIMD.
 #include "qd_internal.h"
 #include "../../include/quits_amd.h"
 
@@ -39,26 +40,29 @@ struct LsdArgs {
     const int32_t *fail_list, *fail_count;
     uint64_t *q_ws;                // [blocks][mw][64 * NR] Q planes (planes 0 and 1 unused: they live in LDS)
     int32_t *next_slot;            // work counter, zero at launch
+    uint16_t *pcol_ws;             // [blocks][64 * NR] pivot row -> its fault
     uint32_t *err_bits;
     int32_t *status;
 };
 
 // LDS carve-up for NR checks per lane: compile-time offsets, so that a lane's block of NR consecutive rows is read with
 // 128-bit LDS loads.  The two bitmaps (sizes depend on n) come last.
+#ifndef QL_LDS_PLANES
+#define QL_LDS_PLANES 0    // Q planes kept in LDS (pivot orders 0 .. 64 * QL_LDS_PLANES - 1); the rest lives in the HBM slot
+#endif
 template <int NR> struct QlLay {
     static constexpr int MP = 64 * NR;
     static constexpr int o_ql = 0;                       // u64 [2][MP]  Q planes 0 and 1 (pivot orders 0..127)
-    static constexpr int o_bkey = o_ql + 16 * MP;        // u32 [MP]     check -> LLR key of its best unused fault
+    static constexpr int o_bkey = o_ql + 8 * QL_LDS_PLANES * MP;        // u32 [MP]     check -> LLR key of its best unused fault
     static constexpr int o_rl = o_bkey + 4 * MP;         // u32 [MP]     the round: size at its start << 16 | cluster id
     static constexpr int o_owner = o_rl + 4 * MP;        // u16 [MP]     check -> cluster id (= seed check), QL_NONE = free
     static constexpr int o_bj = o_owner + 2 * MP;        // u16 [MP]     check -> its best unused fault
     static constexpr int o_rowpiv = o_bj + 2 * MP;       // i16 [MP]     check -> pivot order, -1 = not a pivot row
-    static constexpr int o_pcol = o_rowpiv + 2 * MP;     // u16 [MP]     pivot row -> its fault
-    static constexpr int o_cnbits = o_pcol + 2 * MP;     // u16 [MP]     per cluster id: faults added
+    static constexpr int o_cnbits = o_rowpiv + 2 * MP;   // u16 [MP]     per cluster id: faults added
     static constexpr int o_flags = o_cnbits + 2 * MP;    // u8  [MP]     bit 0 transformed syndrome, 1 image of the column at hand, 2 pivot row
     static constexpr int o_cstate = o_flags + MP;        // u8  [MP]     per cluster id: 0 none, 1 invalid, 2 valid, 3 gone
     static constexpr int o_rs = o_cstate + MP;           // u32 [32]     checks whose candidate has to be (re)computed
-    static constexpr int o_added = o_rs + 128;           // u32 [ceil(n / 32)] fault bitmap, then the output words
+    static constexpr int o_added = o_rs + 128;           // u32 [ceil(n / 32)] fault bitmap
 };
 #define QL_F_SP 1u
 #define QL_F_T 2u
@@ -98,14 +102,13 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
     uint16_t *owner = reinterpret_cast<uint16_t *>(smem + Lay::o_owner);
     uint16_t *bj = reinterpret_cast<uint16_t *>(smem + Lay::o_bj);
     int16_t *rowpiv = reinterpret_cast<int16_t *>(smem + Lay::o_rowpiv);
-    uint16_t *pcol = reinterpret_cast<uint16_t *>(smem + Lay::o_pcol);
+    uint16_t *pcol = a.pcol_ws + (size_t)blockIdx.x * MP;                     // pivot row -> its fault: written once per pivot, read at the end (HBM)
     uint16_t *cnbits = reinterpret_cast<uint16_t *>(smem + Lay::o_cnbits);
     uint8_t *flags = smem + Lay::o_flags;
     uint8_t *cstate = smem + Lay::o_cstate;
     uint32_t *rs = reinterpret_cast<uint32_t *>(smem + Lay::o_rs);
     uint32_t *added = reinterpret_cast<uint32_t *>(smem + Lay::o_added);
     const int added_words = ((a.n + 31) / 32 + 3) & ~3;
-    uint32_t *outw = added + added_words;
     const int lane = threadIdx.x, base = lane * NR;                           // the lane's block of rows
     const int m = a.m;
     const int nfail = *a.fail_count;
@@ -195,15 +198,15 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
             *reinterpret_cast<BlkU16 *>(bj + base) = allff;
             *reinterpret_cast<BlkU16 *>(rowpiv + base) = allff;                // -1
             *reinterpret_cast<BlkU32 *>(bkey + base) = kff;
-            *reinterpret_cast<BlkU64 *>(ql + base) = zero;
-            *reinterpret_cast<BlkU64 *>(ql + MP + base) = zero;                // later planes are cleared when first used
+#pragma unroll
+            for (int w = 0; w < QL_LDS_PLANES; ++w) *reinterpret_cast<BlkU64 *>(ql + w * MP + base) = zero;   // later planes are cleared when first used
             BlkU16 z16;
 #pragma unroll
             for (int k = 0; k < NR; ++k) z16.v[k] = 0;
             *reinterpret_cast<BlkU16 *>(cnbits + base) = z16;
         }
         for (int w = lane; w < added_words; w += 64) added[w] = 0u;
-        for (int w = lane; w < a.out_words; w += 64) outw[w] = 0u;
+        for (int w = lane; w < a.out_words; w += 64) a.err_bits[shot * a.out_words + w] = 0u;   // the correction is ORed in at the end
         __syncthreads();
         QL_T(0);
         scan_list(rl, nseed);                                                  // seeds: the candidate of every unsatisfied check
@@ -320,7 +323,7 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                     }
                     if (mkw == 0ull || memb == 0u) continue;
                     BlkU64 qb;
-                    if (w < 2) qb = *reinterpret_cast<const BlkU64 *>(ql + w * MP + base);
+                    if (w < QL_LDS_PLANES) qb = *reinterpret_cast<const BlkU64 *>(ql + w * MP + base);
                     else qb = *reinterpret_cast<const BlkU64 *>(Q + (size_t)w * MP + base);
 #pragma unroll
                     for (int k = 0; k < NR; ++k) tbits ^= ((uint32_t)__popcll(qb.v[k] & mkw) & 1u) << k;
@@ -335,7 +338,7 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                 if (pkey != 0xFFFFFFFFu) {
                     const int p = (int)pkey, K = npiv, kw = K >> 6;
                     const uint64_t kbit = 1ull << (K & 63);
-                    if ((K & 63) == 0 && kw >= 2) {                            // a new HBM plane comes into use: clear it
+                    if ((K & 63) == 0 && kw >= QL_LDS_PLANES) {                // a new HBM plane comes into use: clear it
                         BlkU64 zero;
 #pragma unroll
                         for (int k = 0; k < NR; ++k) zero.v[k] = 0ull;
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                     const uint32_t spp = (uint32_t)__builtin_amdgcn_readfirstlane((int)flags[p]) & QL_F_SP;
                     const uint32_t updm = tbits & ~mine;                       // rows the pivot row is added to
                     for (int w = 0; w <= kw; ++w) {
-                        if (w < 2) {
+                        if (w < QL_LDS_PLANES) {
                             uint64_t *qw = ql + w * MP;
                             uint64_t x = qw[p];
                             if (w == kw) x ^= kbit;
@@ -399,10 +402,9 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
             const BlkU8 fl = fl_blk;
 #pragma unroll
             for (int k = 0; k < NR; ++k)
-                if ((fl.v[k] & (QL_F_SP | QL_F_PIV)) == (QL_F_SP | QL_F_PIV)) { const uint32_t j = pcol[base + k]; atomicOr(&outw[j >> 5], 1u << (j & 31u)); }
+                if ((fl.v[k] & (QL_F_SP | QL_F_PIV)) == (QL_F_SP | QL_F_PIV)) { const uint32_t j = pcol[base + k]; atomicOr(&a.err_bits[shot * a.out_words + (j >> 5)], 1u << (j & 31u)); }
         }
         __syncthreads();
-        for (int w = lane; w < a.out_words; w += 64) a.err_bits[shot * a.out_words + w] = outw[w];
         if (lane == 0)
             a.status[shot] = (a.status[shot] & 0xFFFF) | QD_STATUS_OSD | (inconsistent ? QD_STATUS_INCONSISTENT : 0) | (min(npiv, 4095) << 20);
         __syncthreads();
@@ -432,7 +434,8 @@ static int lsd_nr(int m) { return m <= 512 ? 8 : m <= 1024 ? 16 : m <= 1536 ? 24
 static int lsd_lds(int nr, int n, int out_words)
 {
     const int fixed = nr == 8 ? QlLay<8>::o_added : nr == 16 ? QlLay<16>::o_added : nr == 24 ? QlLay<24>::o_added : QlLay<32>::o_added;
-    return fixed + ((((n + 31) / 32 + 3) & ~3) + ((out_words + 3) & ~3)) * 4;
+    (void)out_words;
+    return fixed + (((n + 31) / 32 + 3) & ~3) * 4;
 }
 
 int qd_lsd_lds_bytes(int m, int n, int out_words)
@@ -458,6 +461,7 @@ hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const Dec
     a.err_bits = d.err_bits; a.status = d.status;
     const int lds = lsd_lds(nr, gg.n, bg.out_words);
     a.next_slot = reinterpret_cast<int32_t *>(q_ws + (size_t)blocks_alloc * a.mw * 64 * nr);
+    a.pcol_ws = reinterpret_cast<uint16_t *>(q_ws + (size_t)blocks_alloc * a.mw * 64 * nr + 32);
 #ifdef QD_LSD_TIMING
     hipError_t e = hipMemsetAsync(a.next_slot, 0, sizeof(uint64_t) * 17, s);
 #else

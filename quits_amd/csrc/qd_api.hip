@@ -674,7 +674,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
             const int lds = qd_lsd_lds_bytes(g->m, g->n, g->bp.out_words);
             d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
             d->lsd_ws = nullptr;
-            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * ((size_t)d->lsd_blocks * ((g->m + 63) / 64) * qd_lsd_plane_rows(g->m) + 32)));   // + the work counter (+ debug timers)
+            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * ((size_t)d->lsd_blocks * ((g->m + 63) / 64) * qd_lsd_plane_rows(g->m) + 32 + ((size_t)d->lsd_blocks * qd_lsd_plane_rows(g->m) + 3) / 4)));   // + the work counter (+ debug timers) + pivot columns
         }
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
