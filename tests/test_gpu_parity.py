@@ -484,6 +484,30 @@ def test_config4_qlp_sliding_window_bit_exact(gpu, osd, order, shots, max_iter):
     assert pred.shape == (shots, lz.shape[0]) and np.array_equal(pred, ref.astype(np.int64))
 
 
+def test_config4_qlp_sliding_window_bplsd_bit_exact(gpu):
+    """configs[4]'s code and window plan through BP-LSD (sliding_window_bplsd_circuit_mem; 20 windows of 1350 x 18900: the LSD
+    kernel's 24-checks-per-lane instantiation, 77-wide rows = two ELL chunks per rescan) against the oracle's loop."""
+    from quits_amd.decoder import sliding_window_bplsd_circuit_mem
+    from quits_amd.decoder.base import spacetime, window_count
+    name, R = "qlp1020_cardinal_r20_p0.003", 20
+    circ, (H, L, pri) = _circuit_dem(name, 0.003, 0.001)
+    cd = helpers.code("qlp1020")
+    hz, lz = cd["hz"], cd["lz"]
+    nz = hz.shape[0]
+    shots = 12
+    det, obs, _ = orc.sample_dem(H, L, pri, seed=45, shot0=0, B=shots)
+    pred = sliding_window_bplsd_circuit_mem(det, circ, hz, lz, 3, 1, max_iter=30, lsd_order=0, bp_method="minimum_sum",
+                                            schedule="parallel", lsd_method="lsd_0")
+    ncr, _, _ = window_count(R, 3, 1)
+    checks, commits, priors, updates = spacetime(circ, hz, 3, 1, ncr)
+    wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None, "row0": k * nz}
+            for k in range(len(checks))]
+    prm = orc.make_params("minimum_sum", "parallel", 30, "lsd_0", 0, 1.0, orc.FORM_LDPC_F64)
+    ref, stats = orc.sliding_window_decode(wins, nz, det, prm, device_grid=True)
+    assert stats["osd_calls"] > shots, "LSD is not exercised"
+    assert np.array_equal(pred, ref.astype(np.int64))
+
+
 def test_all_detectors_circuit_decodes(gpu):
     """a circuit built with CircuitBuildOptions(get_all_detectors=True, noisy_zeroth_round=False,
     noisy_final_meas=True): X and Z detectors in one record.  The reference's window slicer assumes one detector type per

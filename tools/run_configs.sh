@@ -14,6 +14,7 @@ $B --code qlp1020 --window 3 1 --shots 8192 --no-cpu 2>/dev/null
 $B --code qlp1020 --window 3 1 --shots 8192 --p-override 0.001 --cpu-shots 24 2>/dev/null                                   # (CPU leg: 16 x 24 shots)
 $B --code qlp1020 --window 3 1 --shots 8192 --p-override 0.0005 --no-cpu 2>/dev/null
 $B --code qlp1020 --window 3 1 --shots 4096 --steps 1 --p-override 0.001 --osd-method osd_cs --osd-order 1 --cpu-shots 2 2>/dev/null     # configs[4]: OSD-CS leg (CPU leg: 16 x 2 shots)
+$B --code qlp1020 --window 3 1 --shots 4096 --steps 1 --p-override 0.001 --osd-method lsd_0 --no-cpu 2>/dev/null                       # configs[4] code with BP-LSD
 $B --osd-method osd_cs --osd-order 1 --shots 32768 --cpu-shots 100 2>/dev/null                                            # headline code with OSD-CS(1)
 $B --osd-method lsd_0 --cpu-shots 300 2>/dev/null                                                                         # headline code with BP-LSD (LSD-0)
 # the general (one message per edge) BP kernel at the headline code: the reference wrapper's other bp_method / schedule options
