@@ -284,7 +284,7 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
 #endif
 #define QD_OSD_KWR 6
 #ifndef QD_OSD_KWR0
-#define QD_OSD_KWR0 4
+#define QD_OSD_KWR0 2
 #endif
 #define QD_OSD_KPT 20     // monotone keys a thread keeps in registers while a tier is drawn (n <= 20 * T; else re-read)
 
@@ -1046,7 +1046,10 @@ __device__ QD_OSD_PANEL_INLINE int qd_osd_panel_wave0(const OsdLds &S, const uin
 }
 
 template <int T, int RPT, bool WFULL>
-__global__ void __launch_bounds__(T, (WFULL ? T / 256 : T / 128)) qd_osd0_reg_kernel(OsdRegArgs a)   // full-rank instantiation: one workgroup per CU, so twice the registers
+#ifndef QD_OSD0_WPS
+#define QD_OSD0_WPS (T == 512 ? 6 : T / 128)   // 512 threads: three workgroups per CU (85 registers)
+#endif
+__global__ void __launch_bounds__(T, (WFULL ? T / 256 : QD_OSD0_WPS)) qd_osd0_reg_kernel(OsdRegArgs a)   // full-rank instantiation: one workgroup per CU, so twice the registers
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x;

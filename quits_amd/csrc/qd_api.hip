@@ -446,7 +446,8 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             const int extra = sweep ? align16(bp.out_words * 4) + 256 : 0;
             const int f_budget = QD_LDS_BYTES / per_cu - 256 - small - sort_b - order_b - extra;
             kw = std::min(od.mw, std::max(0, f_budget / (m_pad * 8)));
-            if (kw < std::min(6, od.mw) || (m + od.f_threads - 1) / od.f_threads > 4) return 0;
+            const int min_planes = sweep ? 6 : 2;          // the Q mirror holds at least the planes the kernel keeps in registers (QD_OSD_KWR / QD_OSD_KWR0)
+            if (kw < std::min(min_planes, od.mw) || (m + od.f_threads - 1) / od.f_threads > 4) return 0;
             int o = carve(offs, kw * m_pad * 8, 0);
             o_sort = o; o += sort_b;
             o_order = o; o += order_b;
@@ -455,7 +456,10 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             return o <= QD_LDS_BYTES / per_cu ? o : 0;
         };
         od.f_off_hist = 0;
-        for (int per_cu = 2; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu)
+        // three workgroups per CU where the window allows it (two Q planes in LDS, the rest in the HBM spill): most of a shot is spent
+        // in single-wavefront phases, so the third workgroup is worth more than the planes (headline 10.8 -> 10.1 ms, p = 6e-3 164 -> 154 ms)
+        const int per_cu0 = std::getenv("QD_OSD_PER_CU") ? std::atoi(std::getenv("QD_OSD_PER_CU")) : 3;
+        for (int per_cu = per_cu0; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu)
             od.f_lds_bytes = lay(per_cu, false, od.f_off, od.f_off_sort, od.f_off_order, od.f_off_pivmask, od.f_off_npl, od.f_kw);
         od.w_lds_bytes = lay(1, true, od.w_off, od.w_off_sort, od.w_off_order, od.w_off_pivmask, od.w_off_npl, od.w_kw);
         // the column-form kernel (osd_kernels.hip, qd_osdw_col_kernel): 512 threads, 2 columns of 16 words each (m <= 1024, two
