@@ -84,7 +84,7 @@ __device__ __forceinline__ uint32_t ql_mono_key(float llr)
 #define QL_T(k) do {} while (0)
 #define QL_CNT(k, v) do {} while (0)
 #endif
-#define QL_NB 8            // rows per batch of the candidate scan: their loads are in flight together
+#define QL_NB 8            // rows per batch of the candidate scan: their loads are in flight together (16 measured 18 % slower: registers)
 
 template <int NR>
 __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
