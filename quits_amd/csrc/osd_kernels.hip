@@ -286,7 +286,10 @@ __device__ __forceinline__ void qd_osd_carve(unsigned char *smem, const int *off
 #ifndef QD_OSD_KWR0
 #define QD_OSD_KWR0 2
 #endif
-#define QD_OSD_KPT 20     // monotone keys a thread keeps in registers while a tier is drawn (n <= 20 * T; else re-read)
+#ifndef QD_OSD_KPT
+#define QD_OSD_KPT 1      // (20, i.e. every key of the headline window held in registers, was the round-1 choice: see qd_osd_draw_tier)
+#endif
+//      QD_OSD_KPT        // monotone keys a thread keeps in registers while a tier is drawn (windows with n <= KPT * T; else re-read)
 
 // Sum of v over the workgroup; one barrier; `buf` = 2 x 64 words alternating with `phase` (entries beyond the wave count must be zero).
 template <int T>
@@ -334,23 +337,25 @@ struct TierState { uint32_t lo_key, lo_idx; int sphase, exhausted, limit; };   /
 #ifndef QD_OSD_TIER_INLINE
 #define QD_OSD_TIER_INLINE __forceinline__
 #endif
-template <int T>
+// KPT = monotone keys a thread keeps in registers while the tier is drawn (used when n <= KPT * T; otherwise, and always with
+// KPT = 1 on windows of more than T faults, every radix level and the gather re-read the posteriors, which sit in L2).
+template <int T, int KPT = QD_OSD_KPT>
 __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const OsdRegArgs &a, const float *llr, uint64_t *sortbuf, uint16_t *order,
                                              uint32_t *red, uint32_t *sumbuf, TierState &ts)
 {
     const int tid = threadIdx.x;
     const int n = a.n;
-    const bool in_regs = n <= QD_OSD_KPT * T;
+    const bool in_regs = n <= KPT * T;
     uint32_t lo_key = ts.lo_key, lo_idx = ts.lo_idx;
     int sphase = ts.sphase;
     const uint32_t lim = (uint32_t)ts.limit;
     bool exhausted = false;
     int cnt = 0;
     {
-            uint32_t kreg[QD_OSD_KPT];
+            uint32_t kreg[KPT];
             if (in_regs) {
 #pragma unroll
-                for (int i = 0; i < QD_OSD_KPT; ++i) {
+                for (int i = 0; i < KPT; ++i) {
                     const int b = tid + i * T;
                     kreg[i] = (b < n) ? qd_mono_key(llr[b]) : 0xFFFFFFFFu;
                 }
@@ -390,7 +395,7 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const OsdRegArgs &a, const fl
                     };
                     if (in_regs) {
 #pragma unroll
-                        for (int i = 0; i < QD_OSD_KPT; ++i) tally(kreg[i]);
+                        for (int i = 0; i < KPT; ++i) tally(kreg[i]);
                     } else {
                         for (int b = tid; b < n; b += T) tally(qd_mono_key(llr[b]));
                     }
@@ -459,7 +464,7 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const OsdRegArgs &a, const fl
                 // buffer is irrelevant, it is sorted next)
                 uint32_t mask = 0u;
 #pragma unroll
-                for (int i = 0; i < QD_OSD_KPT; ++i) mask |= (kreg[i] >= t_lo && kreg[i] < t_hi) ? (1u << i) : 0u;
+                for (int i = 0; i < KPT; ++i) mask |= (kreg[i] >= t_lo && kreg[i] < t_hi) ? (1u << i) : 0u;
                 const uint32_t mine = (uint32_t)__popc(mask);
                 uint32_t incl = mine;
 #pragma unroll
@@ -471,7 +476,7 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const OsdRegArgs &a, const fl
                 for (int w = 0; w < (tid >> 6); ++w) at += buf[w];
                 sphase ^= 1;
 #pragma unroll
-                for (int i = 0; i < QD_OSD_KPT; ++i)
+                for (int i = 0; i < KPT; ++i)
                     if ((mask >> i) & 1u) sortbuf[at++] = ((uint64_t)kreg[i] << 32) | a.bit_orig[tid + i * T];
             } else
             for (int i = 0; i * T < n; ++i) {
@@ -1115,6 +1120,10 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : QD_OSD0_WPS)) qd_osd0_re
             // OSD-0 stops after ~100 columns at the usual operating points: a first tier of 256 costs a third of a full one
             TierState ts{lo_key, lo_idx, sphase, 0, (!want_full && ntier == 0) ? QD_OSD_TIER_FIRST : QD_OSD_TIER};
             ++ntier;
+            // The keys are re-read from the posteriors (L2) at every radix level instead of being held 20 per thread: those
+            // registers were what pushed the OSD-0 instantiation (three workgroups per CU, 85 registers) into scratch, 500 -> 116 B
+            // per lane.  Same-box A/B: headline OSD-0 10.2-11.5 -> 8.3-8.4 ms, p = 6e-3 152-154 -> 145-148 ms; OSD-CS(1) through
+            // qd_osdw_col_kernel 106.8 -> 98.8 ms per 32768-shot launch.  Same keys, same order.
             const int cnt = qd_osd_draw_tier<T>(a, llr, sortbuf, order, red, sumbuf, ts);
             lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
             if (ts.exhausted) break;
