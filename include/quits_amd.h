@@ -38,7 +38,9 @@ extern "C" {
 #define QD_OSD_0 1
 #define QD_OSD_E 2
 #define QD_OSD_CS 3
-#define QD_LSD_0 4            /* BP-LSD with lsd_order 0 (ldpc.bplsd_decoder.BpLsdDecoder, quits/decoder/bplsd.py:5): value of osd_method */
+#define QD_LSD_0 4            /* BP-LSD (ldpc.bplsd_decoder.BpLsdDecoder, quits/decoder/bplsd.py:5) as values of osd_method:       */
+#define QD_LSD_E 5            /*   lsd_method 'lsd_0' / 'lsd_e' / 'lsd_cs' (bplsd.py:10,54 forward lsd_method, lsd_order);        */
+#define QD_LSD_CS 6           /*   osd_order carries lsd_order (0: the three are the same decoder)                                */
 
 /* status word written per shot by qd_decode_batch */
 #define QD_STATUS_ITER_MASK 0x3FFF      /* BP iterations used (max_iter is capped at 16383)           */
@@ -65,7 +67,7 @@ typedef struct qd_params {
     int32_t bp_method;          /* QD_BP_*        ; MINIMUM_SUM + PARALLEL runs in the compressed LDS kernel,        */
     int32_t schedule;           /* QD_SCHEDULE_*  ; every other pair in the one-message-per-edge kernel (HBM)        */
     int32_t max_iter;           /* 0 -> number of faults n (ldpc convention)                     */
-    int32_t osd_method;         /* QD_OSD_* | QD_LSD_0 ; device path: OFF, 0, CS (order <= 64), E (order <= 15), LSD-0 */
+    int32_t osd_method;         /* QD_OSD_* | QD_LSD_* ; device path: OFF, 0, CS (order <= 64), E (order <= 15), LSD-0 / -CS / -E (same limits) */
     int32_t osd_order;
     int32_t reserved;           /* flag bits, QD_FLAG_*; 0 for the reference's behaviour                           */
     double ms_scaling_factor;   /* not exposed by the reference wrapper -> ldpc default 1.0; 0 = 1-2^-it */

@@ -17,7 +17,7 @@ _LIB = None
 BP_METHOD = {"product_sum": 0, "ps": 0, "prod_sum": 0, "minimum_sum": 1, "min_sum": 1, "ms": 1}
 SCHEDULE = {"parallel": 0, "p": 0, "serial": 1, "s": 1}
 OSD_METHOD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "osd_e": 2, "osde": 2, "exhaustive": 2,
-              "osd_cs": 3, "osdcs": 3, "combination_sweep": 3, "lsd_0": 4, "lsd0": 4}
+              "osd_cs": 3, "osdcs": 3, "combination_sweep": 3, "lsd_0": 4, "lsd0": 4, "lsd_e": 5, "lsde": 5, "lsd_cs": 6, "lsdcs": 6}
 FORM_LDPC_F64, FORM_COMPRESSED_F32, FORM_COMPRESSED_F64, FORM_LDPC_F32 = 0, 1, 2, 3
 
 
@@ -58,6 +58,7 @@ def lib():
         L.oq_gf2_rank.argtypes = [C.c_void_p]
         L.oq_osd0.argtypes = [C.c_void_p, u8p, f64p, C.c_int, u8p, i32p]
         L.oq_lsd0.argtypes = [C.c_void_p, u8p, f64p, u8p, i32p]
+        L.oq_lsd.argtypes = [C.c_void_p, u8p, f64p, C.c_int, C.c_int, C.c_int, u8p, i32p]
         L.oq_osd_w.argtypes = [C.c_void_p, u8p, f64p, C.c_int, C.c_int, u8p]
         L.oq_osd_w_fixed.argtypes = [C.c_void_p, u8p, f64p, C.c_int, C.c_int, u8p, i32p]
         L.oq_fixed_weight.restype = C.c_uint32
@@ -127,7 +128,7 @@ class Graph:
 
     def device_grid(self, max_iter: int):
         """Put the LLRs on the grid libquits_amd.so picks for this graph and max_iter (flooding min-sum, ms_scaling 1)."""
-        k, kc = grid_bits(self.priors, max_iter if max_iter > 0 else self.n)
+        k, kc = grid_bits(self.priors, device_max_iter(max_iter, self.n))
         return self.quantize_llr(k, kc)
 
     def bp(self, syndrome, params: Params):
@@ -155,6 +156,17 @@ class Graph:
         lib().oq_lsd0(self._h, s, np.ascontiguousarray(llr, dtype=np.float64), err, st)
         return err, {"pivots": int(st[0]), "added": int(st[1]), "inconsistent": bool(st[2]), "rounds": int(st[3])}
 
+    def lsd(self, syndrome, llr, lsd_method="lsd_cs", lsd_order=1, fixed=False):
+        """BP-LSD's post-processing of any order on given soft information (lsd_order 0 = lsd0).  fixed=True: integer candidate
+        costs (the HIP kernel's arithmetic)."""
+        s = np.ascontiguousarray(np.asarray(syndrome) % 2, dtype=np.uint8)
+        err = np.zeros(self.n, np.uint8)
+        st = np.zeros(8, np.int32)
+        lib().oq_lsd(self._h, s, np.ascontiguousarray(llr, dtype=np.float64), OSD_METHOD[lsd_method], int(lsd_order),
+                     int(bool(fixed)), err, st)
+        return err, {"pivots": int(st[0]), "added": int(st[1]), "inconsistent": bool(st[2]), "rounds": int(st[3]),
+                     "grown": int(st[4]), "swept": int(st[5]), "replaced": int(st[6])}
+
     def osd_w(self, syndrome, llr, osd_method="osd_cs", osd_order=1, fixed=False):
         """OSD-CS / OSD-E.  fixed=True: integer candidate costs (the HIP kernel's arithmetic); returns (err, stats)."""
         s = np.ascontiguousarray(np.asarray(syndrome) % 2, dtype=np.uint8)
@@ -178,6 +190,14 @@ class Graph:
         if rc:
             raise ValueError("oracle decode failed (unsupported parameter combination)")
         return (err, flags, grid) if return_grid else (err, flags)
+
+
+DEVICE_MAX_ITER = 16383      # libquits_amd.so keeps the iteration count in 14 status bits (QD_STATUS_ITER_MASK) and caps max_iter there
+
+
+def device_max_iter(max_iter: int, n: int) -> int:
+    """The iteration limit the device really runs for ldpc's `max_iter` (0 -> n) on a window of n faults."""
+    return min(int(max_iter) if int(max_iter) > 0 else int(n), DEVICE_MAX_ITER)
 
 
 def grid_bits(priors, max_iter: int):

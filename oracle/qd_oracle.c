@@ -41,6 +41,8 @@
 #define OQ_OSD_E 2
 #define OQ_OSD_CS 3
 #define OQ_LSD_0 4            /* BP-LSD, lsd_order 0 (ldpc.bplsd_decoder.BpLsdDecoder) */
+#define OQ_LSD_E 5            /* BP-LSD, lsd_method 'lsd_e',  osd_order = lsd_order */
+#define OQ_LSD_CS 6           /* BP-LSD, lsd_method 'lsd_cs', osd_order = lsd_order */
 #define OQ_FORM_LDPC_F64 0      /* per-edge messages, double, ldpc's update order              */
 #define OQ_FORM_COMPRESSED_F32 1 /* compressed min-sum state, float: bit-exact mirror of the HIP kernel */
 #define OQ_FORM_COMPRESSED_F64 2
@@ -137,13 +139,16 @@ void oq_graph_set_coarse_grid(oq_graph *g, int coarse_bits) { g->llr_coarse_bits
  * so the grid leaves room for 8 * max|llr0| * max_iter below 2^(23-k); the coarse grid is 16 times wider. */
 int oq_grid_bits_rule(double max_abs_llr0, int max_iter, int *coarse)
 {
+    if (max_iter > 16383) max_iter = 16383;      /* the device keeps the iteration count in 14 status bits (QD_STATUS_ITER_MASK) */
     double need = 8.0 * max_abs_llr0 * (double)(max_iter > 0 ? max_iter : 1);
     int e = 0;
     while (ldexp(1.0, e) < need && e < 40) e++;
-    int k = 23 - e;
-    if (k > 20) k = 20;
-    if (k < 2) k = 2;
-    if (coarse) *coarse = k - 4 < 0 ? 0 : k - 4;
+    int kr = 23 - e;
+    if (kr > 20) kr = 20;
+    if (kr < 2) kr = 2;
+    /* the fine grid is never coarser than 2^-10: with a large max_iter the rule's grid becomes the coarse (redo) grid */
+    int k = kr < 10 ? 10 : kr;
+    if (coarse) *coarse = kr >= 10 ? (kr - 4 < 0 ? 0 : kr - 4) : kr;
     return k;
 }
 
@@ -435,62 +440,201 @@ static int elim_add_column(const oq_graph *g, oq_elim *E, int col, uint8_t *t /*
     return 1;
 }
 
-int oq_lsd0(oq_graph *g, const uint8_t *synd, const double *llr, uint8_t *err, int32_t *stats)
+uint32_t oq_fixed_weight(double p);
+
+/* Higher-order LSD (lsd_method 'lsd_cs' / 'lsd_e' with lsd_order > 0; every BP-LSD call the reference itself makes passes
+ * lsd_order = 1: /root/reference/tests/test_decoders.py:136, doc/05_decoder_variants.ipynb cell 9).  Restated from the published
+ * algorithm (Hillmann et al. 2024, "higher-order reprocessing" applied to each cluster's own factorisation; ldpc lsd.hpp
+ * LsdDecoder::apply_lsdw), PARITY UNPINNED, with these choices where the paper / ldpc leave room:
+ *   1. growth stage: once every cluster is valid, each active cluster, in ascending id, whose number of non-pivot faults
+ *      ("dimension") is below lsd_order grows by further faults -- same growth rule, merges included -- until the dimension
+ *      reaches lsd_order or lsd_order faults have been added (ldpc: "the number of bits added is limited to be at most the
+ *      size of the lsd order");
+ *   2. sweep: per valid cluster, ascending id, OSD-CS / OSD-E of that order on the cluster's own faults: its non-pivot faults
+ *      sorted by (posterior LLR, index) ascending are the candidate positions (combination sweep: every single one, plus the
+ *      pairs among the first min(order, k_c); exhaustive: the 2^min(order, k_c) - 1 patterns on the first ones), the pivot
+ *      coefficients follow from the cluster's elimination, cost = sum of log(1 / p_j) over the cluster's flipped faults (the
+ *      cost osd.hpp uses), strict '<' keeps the earliest minimum, the LSD-0 solution first.
+ * Clusters own disjoint checks, so the shared elimination is block diagonal and each cluster's sweep only reads its block.
+ * `fixed` != 0: integer costs round(log(1/p) * 2^18), the device's arithmetic (exact sums). */
+typedef struct {
+    oq_graph *g;
+    const double *llr;
+    oq_elim E;
+    uint8_t *t, *added, *state, *ispiv;
+    int *owner, *nbits, *addlist;
+    int nadded, inconsistent;
+} oq_lsd_ctx;
+
+/* one growth step of cluster c; 0 if the cluster has no fault left to add (an invalid cluster is then retired: it can
+ * never become valid; a valid one, in the growth stage of the higher orders, just stays as it is) */
+static int lsd_grow(oq_lsd_ctx *x, int c, int retire)
+{
+    const oq_graph *g = x->g;
+    const int m = g->m;
+    int best = -1;
+    for (int i = 0; i < m; i++) {
+        if (x->owner[i] != c) continue;
+        for (int e = g->rp[i]; e < g->rp[i + 1]; e++) {
+            int j = g->ci[e];
+            if (x->added[j]) continue;
+            if (best < 0 || x->llr[j] < x->llr[best] || (x->llr[j] == x->llr[best] && j < best)) best = j;
+        }
+    }
+    if (best < 0) {
+        if (retire) { x->state[c] = 3; x->inconsistent = 1; }
+        return 0;
+    }
+    x->added[best] = 1; x->addlist[x->nadded++] = best; x->nbits[c]++;
+    for (int e = g->cp[best]; e < g->cp[best + 1]; e++) {
+        int i = g->ri[e], d = x->owner[i];
+        if (d == c) continue;
+        if (d < 0) { x->owner[i] = c; continue; }
+        for (int r = 0; r < m; r++) if (x->owner[r] == d) x->owner[r] = c;     /* absorb cluster d */
+        x->nbits[c] += x->nbits[d]; x->state[d] = 3;
+    }
+    x->ispiv[best] = (uint8_t)elim_add_column(g, &x->E, best, x->t);
+    int bad = 0;
+    for (int r = 0; r < m; r++) if (x->owner[r] == c && x->E.rowpiv[r] < 0 && x->E.sp[r]) { bad = 1; break; }
+    x->state[c] = bad ? 1 : 2;
+    return 1;
+}
+
+static int lsd_cluster_dimension(const oq_lsd_ctx *x, int c)
+{
+    int piv = 0;
+    for (int r = 0; r < x->g->m; r++) if (x->owner[r] == c && x->E.rowpiv[r] >= 0) piv++;
+    return x->nbits[c] - piv;
+}
+
+/* stats: pivots, faults added, inconsistent flag, growth rounds; [4..6] (if order > 0): faults added by the growth stage,
+ * clusters swept, clusters whose LSD-0 solution was replaced */
+int oq_lsd(oq_graph *g, const uint8_t *synd, const double *llr, int lsd_method, int lsd_order, int fixed, uint8_t *err,
+           int32_t *stats)
 {
     const int m = g->m, n = g->n;
-    oq_elim E;
-    elim_init(g, synd, &E);
-    uint8_t *t = (uint8_t *)malloc((size_t)m + 1);
-    uint8_t *added = (uint8_t *)calloc((size_t)n + 1, 1);
-    int *owner = (int *)malloc(sizeof(int) * (size_t)(m + 1));      /* check -> cluster id, -1 = free */
-    int *nbits = (int *)calloc((size_t)m + 1, sizeof(int));          /* per cluster id */
-    uint8_t *state = (uint8_t *)calloc((size_t)m + 1, 1);            /* per cluster id: 0 none, 1 active+invalid, 2 active+valid, 3 gone */
+    oq_lsd_ctx x;
+    x.g = g; x.llr = llr; x.nadded = 0; x.inconsistent = 0;
+    elim_init(g, synd, &x.E);
+    x.t = (uint8_t *)malloc((size_t)m + 1);
+    x.added = (uint8_t *)calloc((size_t)n + 1, 1);
+    x.ispiv = (uint8_t *)calloc((size_t)n + 1, 1);
+    x.owner = (int *)malloc(sizeof(int) * (size_t)(m + 1));      /* check -> cluster id, -1 = free */
+    x.nbits = (int *)calloc((size_t)m + 1, sizeof(int));          /* per cluster id */
+    x.state = (uint8_t *)calloc((size_t)m + 1, 1);                /* per cluster id: 0 none, 1 active+invalid, 2 active+valid, 3 gone */
+    x.addlist = (int *)malloc(sizeof(int) * (size_t)(n + 1));
     int *round = (int *)malloc(sizeof(int) * (size_t)(m + 1));
-    int nadded = 0, inconsistent = 0, rounds = 0;
-    for (int i = 0; i < m; i++) { owner[i] = (synd[i] & 1) ? i : -1; state[i] = (synd[i] & 1) ? 1 : 0; }
+    int rounds = 0, grown = 0, swept = 0, replaced = 0;
+    for (int i = 0; i < m; i++) { x.owner[i] = (synd[i] & 1) ? i : -1; x.state[i] = (synd[i] & 1) ? 1 : 0; }
     for (;;) {
         int nr = 0;
-        for (int c = 0; c < m; c++) if (state[c] == 1) round[nr++] = c;
+        for (int c = 0; c < m; c++) if (x.state[c] == 1) round[nr++] = c;
         if (!nr) break;
         rounds++;
         /* (size, id) ascending, sizes as they are at the start of the round: insertion sort, the lists are short */
         for (int a = 1; a < nr; a++) {
             int c = round[a], b = a - 1;
-            while (b >= 0 && (nbits[round[b]] > nbits[c])) { round[b + 1] = round[b]; b--; }
+            while (b >= 0 && (x.nbits[round[b]] > x.nbits[c])) { round[b + 1] = round[b]; b--; }
             round[b + 1] = c;
         }
-        for (int x = 0; x < nr; x++) {
-            const int c = round[x];
-            if (state[c] != 1) continue;
-            int best = -1;
-            for (int i = 0; i < m; i++) {
-                if (owner[i] != c) continue;
-                for (int e = g->rp[i]; e < g->rp[i + 1]; e++) {
-                    int j = g->ci[e];
-                    if (added[j]) continue;
-                    if (best < 0 || llr[j] < llr[best] || (llr[j] == llr[best] && j < best)) best = j;
-                }
+        for (int q = 0; q < nr; q++)
+            if (x.state[round[q]] == 1) lsd_grow(&x, round[q], 1);
+    }
+    const int order = (lsd_method == OQ_LSD_CS || lsd_method == OQ_LSD_E) ? lsd_order : 0;
+    if (order > 0) {
+        /* 1. growth stage */
+        for (int c = 0; c < m; c++) {
+            if (x.state[c] != 2) continue;
+            int cnt = 0;
+            while (x.state[c] == 2 && lsd_cluster_dimension(&x, c) < order && cnt < order) {
+                if (!lsd_grow(&x, c, 0)) break;
+                cnt++; grown++;
             }
-            if (best < 0) { state[c] = 3; inconsistent = 1; continue; }
-            added[best] = 1; nadded++; nbits[c]++;
-            for (int e = g->cp[best]; e < g->cp[best + 1]; e++) {
-                int i = g->ri[e], d = owner[i];
-                if (d == c) continue;
-                if (d < 0) { owner[i] = c; continue; }
-                for (int r = 0; r < m; r++) if (owner[r] == d) owner[r] = c;     /* absorb cluster d */
-                nbits[c] += nbits[d]; state[d] = 3;
-            }
-            elim_add_column(g, &E, best, t);
-            int bad = 0;
-            for (int r = 0; r < m; r++) if (owner[r] == c && E.rowpiv[r] < 0 && E.sp[r]) { bad = 1; break; }
-            state[c] = bad ? 1 : 2;
         }
     }
     memset(err, 0, (size_t)n);
-    for (int k = 0; k < E.npiv; k++) err[E.pcol[k]] = E.sp[E.prow[k]];
-    if (stats) { stats[0] = E.npiv; stats[1] = nadded; stats[2] = inconsistent; stats[3] = rounds; }
-    elim_free(&E); free(t); free(added); free(owner); free(nbits); free(state); free(round);
+    for (int k = 0; k < x.E.npiv; k++) err[x.E.pcol[k]] = x.E.sp[x.E.prow[k]];
+    if (order > 0) {
+        /* 2. sweep, cluster by cluster */
+        double *wd = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+        for (int j = 0; j < n; j++) wd[j] = fixed ? (double)oq_fixed_weight(g->prior[j]) : log(1.0 / g->prior[j]);
+        oq_sortrec *np = (oq_sortrec *)malloc(sizeof(oq_sortrec) * (size_t)(x.nadded > 0 ? x.nadded : 1));
+        int *cpk = (int *)malloc(sizeof(int) * (size_t)(m + 1));         /* the cluster's pivots (orders) */
+        uint8_t *flip = (uint8_t *)malloc((size_t)m + 1);                /* per pivot order of the cluster: coefficient flipped by the candidate */
+        uint8_t *bestflip = (uint8_t *)malloc((size_t)m + 1);
+        for (int c = 0; c < m; c++) {
+            if (x.state[c] != 2) continue;
+            int kk = 0, npk = 0;
+            for (int a = 0; a < x.nadded; a++) {
+                int j = x.addlist[a];
+                if (x.owner[g->ri[g->cp[j]]] != c || x.ispiv[j]) continue;   /* all checks of an added fault are in its cluster */
+                np[kk].key = llr[j]; np[kk].idx = j; kk++;
+            }
+            if (!kk) continue;
+            swept++;
+            qsort(np, (size_t)kk, sizeof(oq_sortrec), cmp_sortrec);
+            for (int k = 0; k < x.E.npiv; k++) if (x.owner[x.E.prow[k]] == c) cpk[npk++] = k;
+            double base = 0;
+            for (int q = 0; q < npk; q++) if (x.E.sp[x.E.prow[cpk[q]]]) base += wd[x.E.pcol[cpk[q]]];
+            int w = order > kk ? kk : order;
+            long ncand = lsd_method == OQ_LSD_E ? (1L << w) - 1 : (long)kk + (long)w * (w - 1) / 2;
+            double best = base;
+            int bsel[64], bnsel = 0;
+            for (long ic = 0; ic < ncand; ic++) {
+                int sel[64], nsel = 0;
+                if (lsd_method == OQ_LSD_E) {
+                    long pat = ic + 1;
+                    for (int b = 0; b < w; b++) if ((pat >> b) & 1) sel[nsel++] = b;
+                } else if (ic < kk) {
+                    sel[nsel++] = (int)ic;
+                } else {
+                    long q = ic - kk; int a = 0;
+                    while (q >= w - 1 - a) { q -= w - 1 - a; a++; }
+                    sel[0] = a; sel[1] = a + 1 + (int)q; nsel = 2;
+                }
+                memset(flip, 0, (size_t)npk + 1);
+                double wgt = 0;
+                for (int s = 0; s < nsel; s++) {
+                    int col = np[sel[s]].idx;
+                    wgt += wd[col];
+                    int nmask = 0, maskk[OQ_MAX_COL_DEG];
+                    memset(x.t, 0, (size_t)m);
+                    for (int e = g->cp[col]; e < g->cp[col + 1]; e++) {
+                        int r = g->ri[e];
+                        x.t[r] ^= 1;
+                        if (x.E.rowpiv[r] >= 0) maskk[nmask++] = x.E.rowpiv[r];
+                    }
+                    for (int q = 0; q < npk; q++) {
+                        int r = x.E.prow[cpk[q]];
+                        const uint64_t *Q = x.E.Q + (size_t)r * x.E.mw;
+                        int b = x.t[r];
+                        for (int z = 0; z < nmask; z++) b ^= (int)((Q[maskk[z] >> 6] >> (maskk[z] & 63)) & 1);
+                        flip[q] ^= (uint8_t)b;
+                    }
+                }
+                for (int q = 0; q < npk; q++)
+                    if (x.E.sp[x.E.prow[cpk[q]]] ^ flip[q]) wgt += wd[x.E.pcol[cpk[q]]];
+                if (wgt < best) { best = wgt; bnsel = nsel; memcpy(bsel, sel, sizeof(int) * (size_t)nsel); memcpy(bestflip, flip, (size_t)npk); }
+            }
+            if (bnsel) {
+                replaced++;
+                for (int q = 0; q < npk; q++) if (bestflip[q]) err[x.E.pcol[cpk[q]]] ^= 1;
+                for (int s = 0; s < bnsel; s++) err[np[bsel[s]].idx] = 1;
+            }
+        }
+        free(wd); free(np); free(cpk); free(flip); free(bestflip);
+    }
+    if (stats) {
+        stats[0] = x.E.npiv; stats[1] = x.nadded; stats[2] = x.inconsistent; stats[3] = rounds;
+        if (order > 0) { stats[4] = grown; stats[5] = swept; stats[6] = replaced; }
+    }
+    elim_free(&x.E); free(x.t); free(x.added); free(x.ispiv); free(x.owner); free(x.nbits); free(x.state); free(x.addlist); free(round);
     return 0;
+}
+
+int oq_lsd0(oq_graph *g, const uint8_t *synd, const double *llr, uint8_t *err, int32_t *stats)
+{
+    return oq_lsd(g, synd, llr, OQ_LSD_0, 0, 0, err, stats);
 }
 
 /* Candidate cost.  ldpc sums log(1/p_j) in double (osd.hpp).  `fixed` != 0 switches to the integer weights the HIP
@@ -619,7 +763,12 @@ int oq_bposd_decode(oq_graph *g, const oq_params *prm, const uint8_t *synd, uint
         oq_graph_quantize_llr(g, fine);
     }
     if (!conv && prm->osd_method != OQ_OSD_OFF) {
-        if (prm->osd_method == OQ_LSD_0) oq_lsd0(g, synd, llr, err, st);
+        const int dev_costs = prm->form == OQ_FORM_COMPRESSED_F32 || prm->form == OQ_FORM_LDPC_F32 || g->llr_frac_bits >= 0;
+        if (prm->osd_method == OQ_LSD_0 || prm->osd_method == OQ_LSD_E || prm->osd_method == OQ_LSD_CS) {
+            int32_t st7[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            oq_lsd(g, synd, llr, prm->osd_method, prm->osd_order, dev_costs, err, st7);
+            st[0] = st7[0]; st[2] = st7[2];
+        }
         else if (prm->osd_method == OQ_OSD_0 || prm->osd_order == 0) oq_osd0(g, synd, llr, 1, err, st);
         else osd_w_impl(g, synd, llr, prm->osd_method, prm->osd_order,
                         prm->form == OQ_FORM_COMPRESSED_F32 || prm->form == OQ_FORM_LDPC_F32 || g->llr_frac_bits >= 0

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("QUITS_AMD_LIB", os.path.join(_HERE, "lib", "libquits_
 QD_BP = {"product_sum": 0, "ps": 0, "prod_sum": 0, "minimum_sum": 1, "min_sum": 1, "ms": 1, 0: 0, 1: 1}
 QD_SCHEDULE = {"parallel": 0, "p": 0, "serial": 1, "s": 1, 0: 0, 1: 1}
 QD_OSD = {"osd_off": 0, "off": 0, "osd_0": 1, "osd0": 1, "osd_e": 2, "osde": 2, "exhaustive": 2,
-          "osd_cs": 3, "osdcs": 3, "combination_sweep": 3, "lsd_0": 4, 0: 0, 1: 1, 2: 2, 3: 3, 4: 4}
+          "osd_cs": 3, "osdcs": 3, "combination_sweep": 3, "lsd_0": 4, "lsd_e": 5, "lsd_cs": 6, 0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 6}
 
 STATUS_ITER_MASK = 0x3FFF
 STATUS_COARSE_GRID = 1 << 14

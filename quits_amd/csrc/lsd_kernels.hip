@@ -41,6 +41,14 @@ struct LsdArgs {
     uint64_t *q_ws;                // [blocks][mw][64 * NR] Q planes (planes 0 and 1 unused: they live in LDS)
     int32_t *next_slot;            // work counter, zero at launch
     uint16_t *pcol_ws;             // [blocks][64 * NR] pivot row -> its fault
+    // higher-order LSD (lsd_method 'lsd_cs' / 'lsd_e' with lsd_order > 0): 0 = LSD-0, 1 = combination sweep, 2 = exhaustive
+    int lsd_w, order;
+    const uint32_t *wfix;          // [n] integer candidate costs round(log(1/p) * 2^18) (as for OSD-CS / OSD-E)
+    const uint32_t *slot_of;       // [n] fault -> its posterior column in llr_ws
+    uint16_t *npl_ws;              // [blocks][npl_cap] the added faults that did not become pivot columns, in order of addition
+    int npl_cap;
+    uint32_t *tv_ws;               // [blocks][QL_TV_WORDS] images of the first 64 sorted non-pivot faults of the cluster at hand
+                                   //                       ([i][lane] = bit k: row base + k), then their fault indices
     uint32_t *err_bits;
     int32_t *status;
 };
@@ -84,7 +92,16 @@ __device__ __forceinline__ uint32_t ql_mono_key(float llr)
 #define QL_T(k) do {} while (0)
 #define QL_CNT(k, v) do {} while (0)
 #endif
+#define QL_TV_MAX 64       // candidate positions whose images are kept (pairs of 'lsd_cs' among the first min(order, 64); 'lsd_e': 15)
+#define QL_TV_WORDS (QL_TV_MAX * 64 + QL_TV_MAX)
 #define QL_NB 8            // rows per batch of the candidate scan: their loads are in flight together (16 measured 18 % slower: registers)
+
+__device__ __forceinline__ long long ql_wave_sum_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
 template <int NR>
 __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
@@ -113,6 +130,8 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
     const int m = a.m;
     const int nfail = *a.fail_count;
     uint64_t *Q = a.q_ws + (size_t)blockIdx.x * (size_t)a.mw * MP;            // planes >= 2 (rare): HBM, per resident slot
+    uint16_t *npl = a.npl_ws + (size_t)blockIdx.x * a.npl_cap;
+    uint32_t *tv = a.tv_ws + (size_t)blockIdx.x * QL_TV_WORDS;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     BlkU16 &own_blk = *reinterpret_cast<BlkU16 *>(owner + base);
     BlkU8 &fl_blk = *reinterpret_cast<BlkU8 *>(flags + base);
@@ -212,23 +231,58 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
         scan_list(rl, nseed);                                                  // seeds: the candidate of every unsatisfied check
         QL_T(1); QL_CNT(12, 1);
 
-        int npiv = 0, inconsistent = 0, nrl = nseed;
+        int npiv = 0, inconsistent = 0, nrl = nseed, nnp = 0;
+        int mode = 0, pc = -1, pcnt = 0;                                       // mode 1: growth stage of the higher orders (below)
         for (;;) {
-            // ---- this round: the clusters still invalid, by (size now, id); they all were in the previous round's list
-            int out = 0;
-            for (int b0 = 0; b0 < nrl; b0 += 64) {
-                const int idx = b0 + lane;
-                const int c = idx < nrl ? (int)(rl[idx] & 0xFFFFu) : 0;
-                const bool inv = idx < nrl && cstate[c] == 1;
-                const uint32_t v = ((uint32_t)cnbits[c] << 16) | (uint32_t)c;
-                const unsigned long long bi = __ballot(inv);
-                if (inv) rl[out + __popcll(bi & lt_mask)] = v;                 // out <= b0: never ahead of the reads
-                out += __popcll(bi);
+            if (mode == 0) {
+                // ---- this round: the clusters still invalid, by (size now, id); they all were in the previous round's list
+                int out = 0;
+                for (int b0 = 0; b0 < nrl; b0 += 64) {
+                    const int idx = b0 + lane;
+                    const int c = idx < nrl ? (int)(rl[idx] & 0xFFFFu) : 0;
+                    const bool inv = idx < nrl && cstate[c] == 1;
+                    const uint32_t v = ((uint32_t)cnbits[c] << 16) | (uint32_t)c;
+                    const unsigned long long bi = __ballot(inv);
+                    if (inv) rl[out + __popcll(bi & lt_mask)] = v;             // out <= b0: never ahead of the reads
+                    out += __popcll(bi);
+                }
+                nrl = out;
+                __syncthreads();
+                QL_T(2); QL_CNT(13, 1);
+                if (nrl == 0) {
+                    if (a.lsd_w == 0) break;
+                    mode = 1;
+                }
             }
-            nrl = out;
-            __syncthreads();
-            QL_T(2); QL_CNT(13, 1);
-            if (nrl == 0) break;
+            if (mode == 1) {
+                // ---- higher-order LSD, growth stage (oracle oq_lsd, step 1): every cluster is valid now; in ascending id, a
+                // cluster with fewer than `order` non-pivot faults takes up to `order` further faults, by the same growth step
+                // (merges included).  One step per trip of this loop: the "round" is that one cluster.
+                int c1 = -1;
+                for (;;) {
+                    if (pc >= 0 && pcnt < a.order && __builtin_amdgcn_readfirstlane((int)cstate[pc]) == 2) {
+                        const BlkU16 own = own_blk;
+                        const BlkU8 fl = fl_blk;
+                        int pv = 0;
+#pragma unroll
+                        for (int k = 0; k < NR; ++k) pv += (own.v[k] == (uint16_t)pc && (fl.v[k] & QL_F_PIV)) ? 1 : 0;
+                        const int dim = __builtin_amdgcn_readfirstlane((int)cnbits[pc]) - (int)qd_wave_add((uint32_t)pv);
+                        if (dim < a.order) { c1 = pc; break; }
+                    }
+                    const BlkU8 cs = *reinterpret_cast<const BlkU8 *>(cstate + base);
+                    uint32_t cm = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) if (cs.v[k] == 2 && base + k > pc) cm = min(cm, (uint32_t)(base + k));
+                    cm = qd_wave_umin(cm);
+                    if (cm == 0xFFFFFFFFu) break;
+                    pc = (int)cm; pcnt = 0;
+                }
+                if (c1 < 0) break;
+                pcnt++;
+                if (lane == 0) rl[0] = (uint32_t)c1;
+                nrl = 1;
+                __syncthreads();
+            }
             long long last = -1;
             for (;;) {
                 uint32_t kk = 0xFFFFFFFFu;
@@ -238,7 +292,7 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                 last = (long long)kk;
                 const int c = (int)(kk & 0xFFFFu);
                 QL_T(3);
-                if (__builtin_amdgcn_readfirstlane((int)cstate[c]) != 1) continue;   // became valid or was absorbed earlier in the round
+                if (mode == 0 && __builtin_amdgcn_readfirstlane((int)cstate[c]) != 1) continue;   // became valid or was absorbed earlier in the round
                 QL_CNT(14, 1);
                 // ---- the fault that joins: lowest (LLR, index) among the cached candidates of the cluster's checks
                 int j;
@@ -250,6 +304,7 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                     for (int k = 0; k < NR; ++k) if (own.v[k] == (uint16_t)c) kmin = min(kmin, bk.v[k]);
                     const uint32_t K = qd_wave_umin(kmin);
                     if (K == 0xFFFFFFFFu) {                                    // nothing left to add: the syndrome is outside the column space
+                        if (mode == 1) { pcnt = a.order; continue; }           // (growth stage: the cluster is valid and simply complete)
                         if (lane == 0) cstate[c] = 3;
                         inconsistent = 1;
                         __syncthreads();
@@ -375,6 +430,9 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                     pivb |= mine;
                     if (lane == 0) { rowpiv[p] = (int16_t)K; pcol[p] = (uint16_t)j; }
                     npiv = K + 1;
+                } else if (a.lsd_w) {                                          // dependent on the cluster's pivot columns: a candidate position of the sweep
+                    if (lane == 0) npl[nnp] = (uint16_t)j;
+                    nnp++;
                 }
                 // ---- flags back (image cleared); valid once no unpivoted check of the cluster carries syndrome
 #pragma unroll
@@ -397,6 +455,144 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
             }
             QL_T(3);
             __syncthreads();
+        }
+        if (a.lsd_w && nnp > 0) {
+            // ---- higher-order LSD, sweep (oracle oq_lsd, step 2): per valid cluster, ascending id, OSD-CS / OSD-E on the cluster's
+            // own factorisation.  Candidate positions: its non-pivot faults by (posterior LLR, index); flipping a set of them
+            // flips the pivot coefficients on the rows of t = XOR of their images; cost change = sum of their weights + the
+            // weights of the pivot columns switched on - those switched off, in integers (exact); strict '<', earliest wins.
+            __syncthreads();
+            const int kwmax = (npiv + 63) / 64 - 1;
+            auto image = [&](int j) -> uint32_t {                              // t = T * column j on this lane's rows
+                const int c0 = a.cp[j], deg = a.cp[j + 1] - c0;
+                const int myrow = lane < deg ? a.ri[c0 + lane] : -1;
+                const int mypk = lane < deg ? (int)rowpiv[myrow] : -1;
+                const unsigned long long bpk = __ballot(mypk >= 0);
+                uint32_t tb = 0;
+                for (int x = 0; x < deg; ++x) {
+                    const int r = __builtin_amdgcn_readlane(myrow, x) - base;
+                    if ((unsigned)r < (unsigned)NR) tb |= 1u << r;
+                }
+                for (int w = 0; w <= kwmax; ++w) {
+                    uint64_t mkw = 0ull;
+                    for (unsigned long long bb = bpk; bb; bb &= bb - 1ull) {
+                        const int pk = __builtin_amdgcn_readlane(mypk, (int)__builtin_ctzll(bb));
+                        if ((pk >> 6) == w) mkw |= 1ull << (pk & 63);
+                    }
+                    if (mkw == 0ull) continue;
+                    BlkU64 qb;
+                    if (w < QL_LDS_PLANES) qb = *reinterpret_cast<const BlkU64 *>(ql + w * MP + base);
+                    else qb = *reinterpret_cast<const BlkU64 *>(Q + (size_t)w * MP + base);
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) tb ^= ((uint32_t)__popcll(qb.v[k] & mkw) & 1u) << k;
+                }
+                return tb;
+            };
+            int sc = -1;
+            for (;;) {
+                const BlkU8 cs = *reinterpret_cast<const BlkU8 *>(cstate + base);
+                uint32_t cm = 0xFFFFFFFFu;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) if (cs.v[k] == 2 && base + k > sc) cm = min(cm, (uint32_t)(base + k));
+                cm = qd_wave_umin(cm);
+                if (cm == 0xFFFFFFFFu) break;
+                sc = (int)cm;
+                // the cluster's candidate positions
+                int kk = 0;
+                for (int i0 = 0; i0 < nnp; i0 += 64) {
+                    const int i = i0 + lane;
+                    bool mem = false;
+                    if (i < nnp) mem = owner[a.ri[a.cp[npl[i]]]] == (uint16_t)sc;     // all checks of an added fault are in its cluster
+                    kk += __popcll(__ballot(mem));
+                }
+                if (kk == 0) continue;
+                const BlkU16 own = own_blk;
+                BlkU8 fl = fl_blk;
+                uint32_t memb = 0, pivb = 0, spb = 0;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const uint32_t f = fl.v[k];
+                    if (own.v[k] == (uint16_t)sc) memb |= 1u << k;
+                    pivb |= ((f >> 2) & 1u) << k; spb |= (f & 1u) << k;
+                }
+                const uint32_t mp = memb & pivb;
+                uint32_t wv[NR];                                               // cost of the pivot column of each of the lane's pivot rows
+#pragma unroll
+                for (int k = 0; k < NR; ++k) wv[k] = ((mp >> k) & 1u) ? a.wfix[pcol[base + k]] : 0u;
+                auto delta_of = [&](uint32_t tb) -> long long {
+                    long long d = 0;
+                    const uint32_t on = tb & mp & ~spb, off = tb & mp & spb;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) d += ((on >> k) & 1u) ? (long long)wv[k] : (((off >> k) & 1u) ? -(long long)wv[k] : 0ll);
+                    return ql_wave_sum_i64(d);
+                };
+                const int wmax = a.lsd_w == 1 ? QL_TV_MAX : 15;
+                const int w = min(min(a.order, kk), wmax);
+                const int nsingle = a.lsd_w == 1 ? kk : w;
+                long long best = 0;
+                uint32_t btb = 0;
+                int bja = -1, bjb = -1;
+                unsigned bpat = 0;
+                unsigned long long lastkey = 0ull;
+                for (int i = 0; i < nsingle; ++i) {
+                    unsigned long long kmin = QL_NOKEY64;
+                    for (int i0 = 0; i0 < nnp; i0 += 64) {
+                        const int x = i0 + lane;
+                        if (x < nnp) {
+                            const uint32_t jj = npl[x];
+                            if (owner[a.ri[a.cp[jj]]] == (uint16_t)sc) {
+                                const unsigned long long key = ((unsigned long long)ql_mono_key(llr[a.slot_of[jj]]) << 16) | jj;
+                                if ((i == 0 || key > lastkey) && key < kmin) kmin = key;
+                            }
+                        }
+                    }
+                    const uint32_t hi = (uint32_t)(kmin >> 16), mh = qd_wave_umin(hi);
+                    const uint32_t ml = qd_wave_umin((hi == mh && kmin != QL_NOKEY64) ? (uint32_t)(kmin & 0xFFFFu) : 0xFFFFu);
+                    lastkey = ((unsigned long long)mh << 16) | ml;
+                    const int j = (int)ml;
+                    const uint32_t tb = image(j) & memb;
+                    if (i < w) { tv[i * 64 + lane] = tb; if (lane == 0) tv[QL_TV_MAX * 64 + i] = (uint32_t)j; }
+                    if (a.lsd_w == 1) {
+                        const long long d = delta_of(tb) + (long long)a.wfix[j];
+                        if (d < best) { best = d; btb = tb; bja = j; bjb = -1; }
+                    }
+                }
+                __syncthreads();
+                if (a.lsd_w == 1) {
+                    for (int x = 0; x < w; ++x)
+                        for (int y = x + 1; y < w; ++y) {
+                            const uint32_t tb = tv[x * 64 + lane] ^ tv[y * 64 + lane];
+                            const int ja = (int)tv[QL_TV_MAX * 64 + x], jb = (int)tv[QL_TV_MAX * 64 + y];
+                            const long long d = delta_of(tb) + (long long)a.wfix[ja] + (long long)a.wfix[jb];
+                            if (d < best) { best = d; btb = tb; bja = ja; bjb = jb; }
+                        }
+                } else {
+                    for (unsigned pat = 1; pat < (1u << w); ++pat) {
+                        uint32_t tb = 0;
+                        long long ws = 0;
+                        for (int b = 0; b < w; ++b)
+                            if ((pat >> b) & 1u) { tb ^= tv[b * 64 + lane]; ws += (long long)a.wfix[tv[QL_TV_MAX * 64 + b]]; }
+                        const long long d = delta_of(tb) + ws;
+                        if (d < best) { best = d; btb = tb; bpat = pat; }
+                    }
+                }
+                if (best < 0) {
+                    spb ^= btb & mp;
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) fl.v[k] = (uint8_t)((fl.v[k] & ~QL_F_SP) | ((spb >> k) & 1u));
+                    fl_blk = fl;
+                    if (lane == 0) {
+                        uint32_t *eb = a.err_bits + shot * a.out_words;
+                        if (a.lsd_w == 1) {
+                            atomicOr(&eb[bja >> 5], 1u << (bja & 31));
+                            if (bjb >= 0) atomicOr(&eb[bjb >> 5], 1u << (bjb & 31));
+                        } else
+                            for (int b = 0; b < w; ++b)
+                                if ((bpat >> b) & 1u) { const uint32_t jj = tv[QL_TV_MAX * 64 + b]; atomicOr(&eb[jj >> 5], 1u << (jj & 31u)); }
+                    }
+                }
+                __syncthreads();
+            }
         }
         {                                                                      // err[pivot column] = transformed syndrome at the pivot row
             const BlkU8 fl = fl_blk;
@@ -447,7 +643,18 @@ int qd_lsd_lds_bytes(int m, int n, int out_words)
 // rows of one Q plane in the HBM workspace
 int qd_lsd_plane_rows(int m) { return 64 * lsd_nr(m); }
 
-hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks, hipStream_t s)
+// bytes of the per-slot workspace behind the Q planes: work counter (+ debug timers), pivot columns, and for the higher orders
+// the non-pivot list and the image scratch
+size_t qd_lsd_ws_bytes(int m, int n, int blocks, int lsd_w)
+{
+    const size_t rows = (size_t)qd_lsd_plane_rows(m);
+    size_t b = sizeof(uint64_t) * ((size_t)blocks * ((m + 63) / 64) * rows + 32 + ((size_t)blocks * rows + 3) / 4);
+    if (lsd_w) b += ((size_t)blocks * ((n + 3) & ~3) * sizeof(uint16_t) + 15) / 16 * 16 + (size_t)blocks * QL_TV_WORDS * sizeof(uint32_t) + 64;
+    return b;
+}
+
+hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks,
+                          int lsd_w, int lsd_order, const uint32_t *wfix, hipStream_t s)
 {
     LsdArgs a{};
     const int nr = lsd_nr(gg.m);
@@ -462,6 +669,13 @@ hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const Dec
     const int lds = lsd_lds(nr, gg.n, bg.out_words);
     a.next_slot = reinterpret_cast<int32_t *>(q_ws + (size_t)blocks_alloc * a.mw * 64 * nr);
     a.pcol_ws = reinterpret_cast<uint16_t *>(q_ws + (size_t)blocks_alloc * a.mw * 64 * nr + 32);
+    a.lsd_w = lsd_order > 0 ? lsd_w : 0; a.order = lsd_order; a.wfix = wfix; a.slot_of = bg.bit_slot_of;
+    a.npl_cap = (gg.n + 3) & ~3;
+    {
+        unsigned char *tail = reinterpret_cast<unsigned char *>(q_ws + (size_t)blocks_alloc * a.mw * 64 * nr + 32 + ((size_t)blocks_alloc * 64 * nr + 3) / 4);
+        a.npl_ws = reinterpret_cast<uint16_t *>(tail);
+        a.tv_ws = reinterpret_cast<uint32_t *>(tail + ((size_t)blocks_alloc * a.npl_cap * sizeof(uint16_t) + 15) / 16 * 16);
+    }
 #ifdef QD_LSD_TIMING
     hipError_t e = hipMemsetAsync(a.next_slot, 0, sizeof(uint64_t) * 17, s);
 #else

@@ -16,7 +16,9 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
                                 int schedule, int64_t shot0, int nshots, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s);
-hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks, hipStream_t s);
+hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks,
+                          int lsd_w, int lsd_order, const uint32_t *wfix, hipStream_t s);
+size_t qd_lsd_ws_bytes(int m, int n, int blocks, int lsd_w);
 int qd_lsd_lds_bytes(int m, int n, int out_words);
 int qd_lsd_plane_rows(int m);
 hipError_t qd_launch_stage_llr(const float *llr_in, int n, int n_pad, const uint32_t *bit_orig, int64_t B, float *llr_ws,
@@ -94,11 +96,12 @@ struct qd_decoder {
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
     int lsd = 0;                // 1: BP-LSD post-processing (lsd_kernels.hip) instead of OSD
     int lsd_blocks = 0;
+    int lsd_w = 0;              // higher-order LSD: 0 = LSD-0, 1 = combination sweep, 2 = exhaustive (order = prm.osd_order)
     uint64_t *lsd_ws = nullptr; // [lsd_blocks][mw][m_pad] Q planes, then the work counter
     int64_t gen_ws_limit = 0;   // bytes; 0 = default
     GenWs gws{};
     // ---- LLR grid (flooding min-sum, ms_scaling 1): decoder-owned prior arrays on the fine and the coarse grid
-    int grid_k = -1, grid_kc = -1;
+    int grid_k = -1, grid_kc = -1, grid_floor = 0;   // grid_floor: the fine grid is the 2^-10 floor, not the rule's: any number of shots may need the redo pass
     BpGraphDev bp_fine{}, bp_coarse{};         // copies of g->bp with their own bit_rec
     const float *llr0_q = nullptr;             // fault-order LLRs for the one-message-per-edge kernel (fine grid)
     int32_t *redo_list = nullptr;
@@ -116,6 +119,7 @@ struct qd_spmat {
     DevAllocs mem;
 };
 
+#define QD_GRID_MIN_BITS 10
 static inline int align16(int x) { return (x + 15) & ~15; }
 static inline int pad64(int x) { return (x + 63) & ~63; }
 
@@ -542,9 +546,12 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     if (p->bp_method != QD_BP_MINIMUM_SUM && p->bp_method != QD_BP_PRODUCT_SUM) return fail(QD_EINVAL, "unknown bp_method %d", p->bp_method);
     if (p->schedule != QD_SCHEDULE_PARALLEL && p->schedule != QD_SCHEDULE_SERIAL) return fail(QD_EINVAL, "unknown schedule %d", p->schedule);
     if (p->reserved & ~(QD_FLAG_EDGE_MESSAGES | QD_FLAG_RAW_LLR)) return fail(QD_EINVAL, "unknown flag bits 0x%x", p->reserved);
-    const bool lsd = p->osd_method == QD_LSD_0;
-    if (lsd && p->osd_order != 0)
-        return fail(QD_EUNSUPPORTED, "BP-LSD: lsd_order %d > 0 is not implemented on the device path (LSD-0 only)", p->osd_order);
+    const bool lsd = p->osd_method == QD_LSD_0 || p->osd_method == QD_LSD_E || p->osd_method == QD_LSD_CS;
+    if (lsd && p->osd_order < 0) return fail(QD_EINVAL, "negative lsd_order");
+    if (p->osd_method == QD_LSD_CS && p->osd_order > 64)
+        return fail(QD_EUNSUPPORTED, "lsd_cs: lsd_order %d > 64 is not implemented on the device path", p->osd_order);
+    if (p->osd_method == QD_LSD_E && p->osd_order > 15)
+        return fail(QD_EUNSUPPORTED, "lsd_e: lsd_order %d > 15 is not implemented on the device path", p->osd_order);
     if (lsd && qd_lsd_lds_bytes(g->m, g->n, g->bp.out_words) > QD_LDS_BYTES)
         return fail(QD_ECAPACITY, "window %d x %d does not fit the LSD kernel's LDS layout", g->m, g->n);
     const bool osd0 = lsd || p->osd_method == QD_OSD_0 || ((p->osd_method == QD_OSD_CS || p->osd_method == QD_OSD_E) && p->osd_order == 0);
@@ -563,6 +570,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     if (p->max_iter < 0 || p->ms_scaling_factor < 0) return fail(QD_EINVAL, "negative max_iter / ms_scaling_factor");
     qd_decoder *d = new qd_decoder();
     d->g = g; d->prm = *p; d->lsd = lsd ? 1 : 0;
+    d->lsd_w = (lsd && p->osd_order > 0) ? (p->osd_method == QD_LSD_CS ? 1 : (p->osd_method == QD_LSD_E ? 2 : 0)) : 0;
     d->general = (p->bp_method != QD_BP_MINIMUM_SUM || p->schedule != QD_SCHEDULE_PARALLEL || (p->reserved & QD_FLAG_EDGE_MESSAGES)) ? 1 : 0;
     d->osd_w = osd0 || p->osd_method == QD_OSD_OFF ? 0 : (p->osd_method == QD_OSD_CS ? 1 : 2);
     if (d->osd_w) host_rank(const_cast<qd_graph *>(g));     // the sweep needs the complete factorisation: rank pivots
@@ -577,10 +585,16 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
         const double need = 8.0 * mx * (double)std::max(1, d->prm.max_iter);
         int e = 0;
         while (std::ldexp(1.0, e) < need && e < 40) ++e;
-        d->grid_k = std::min(20, std::max(2, 23 - e));
-        d->grid_kc = std::max(0, d->grid_k - 4);
+        // fine grid: never coarser than 2^-10, whatever max_iter (a large max_iter -- ldpc's max_iter = 0 means n -- would otherwise
+        // put every shot on a grid of 1/4 or 1/8 although most shots converge long before their magnitudes get anywhere near the
+        // bound); the shots that do outgrow it are certified on the grid the rule gives, by the redo pass
+        const int kr = std::min(20, std::max(2, 23 - e));
+        d->grid_k = std::max(kr, QD_GRID_MIN_BITS);
+        d->grid_kc = kr >= QD_GRID_MIN_BITS ? std::max(0, kr - 4) : kr;
+        d->grid_floor = kr < QD_GRID_MIN_BITS ? 1 : 0;
         if (hipSetDevice(g->device) != hipSuccess) { delete d; return fail(QD_EHIP, "hipSetDevice(%d) failed", g->device); }
-        auto on_grid = [&](double l, int k) { return (float)std::ldexp(std::nearbyint(std::ldexp(l, k)), -k); };
+        // (+ 0.0f: a prior that rounds to zero from below must be +0, not -0 -- the kernel's sign test reads the bit pattern)
+        auto on_grid = [&](double l, int k) { return (float)std::ldexp(std::nearbyint(std::ldexp(l, k)), -k) + 0.0f; };
         int rc = 0;
         for (int pass = 0; pass < 2; ++pass) {
             const int k = pass == 0 ? d->grid_k : d->grid_kc;
@@ -658,7 +672,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
     HIP_TRY(hipMalloc((void **)&d->fail_count, 256));
     HIP_TRY(hipMemset(d->fail_count, 0, 256));
     if (d->grid_k >= 0 && !d->general) {
-        d->redo_cap = (int)std::min<int64_t>(max_batch, 4096);
+        d->redo_cap = (int)(d->grid_floor ? max_batch : std::min<int64_t>(max_batch, 4096));
         HIP_TRY(hipMalloc((void **)&d->redo_list, sizeof(int32_t) * (size_t)d->redo_cap));
     }
     if (osd) {
@@ -678,7 +692,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
             const int lds = qd_lsd_lds_bytes(g->m, g->n, g->bp.out_words);
             d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
             d->lsd_ws = nullptr;
-            HIP_TRY(hipMalloc((void **)&d->lsd_ws, sizeof(uint64_t) * ((size_t)d->lsd_blocks * ((g->m + 63) / 64) * qd_lsd_plane_rows(g->m) + 32 + ((size_t)d->lsd_blocks * qd_lsd_plane_rows(g->m) + 3) / 4)));   // + the work counter (+ debug timers) + pivot columns
+            HIP_TRY(hipMalloc((void **)&d->lsd_ws, qd_lsd_ws_bytes(g->m, g->n, d->lsd_blocks, d->lsd_w)));   // Q planes + work counter (+ debug timers) + pivot columns (+ sweep scratch)
         }
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
@@ -824,7 +838,8 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         hipEvent_t t0 = nullptr;
         if (int rc = span(1, t0)) return rc;
         if (d->lsd)
-            HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), s));
+            HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), d->lsd_w,
+                                   d->prm.osd_order, d->g->osd.wfix, s));
         else
             HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                    (int)std::min<int64_t>(B, d->osd_blocks), s));
@@ -878,7 +893,8 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     HIP_TRY(qd_launch_stage_llr(d_llr, d->g->n, d->g->bp.n_pad, d->g->bp.bit_orig, B, d->llr_ws, d->fail_list, d->fail_count,
                                 d_status, s));
     if (lsd_only)
-        HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), s));
+        HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), d->lsd_w,
+                                   d->prm.osd_order, d->g->osd.wfix, s));
     else
         HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                (int)std::min<int64_t>(B, d->osd_blocks), s));

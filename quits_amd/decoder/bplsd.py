@@ -8,9 +8,15 @@ below: BP on the MI355X exactly as for BP-OSD (csrc/bp_kernels.hip / bp_general.
 of the shots BP could not finish (csrc/lsd_kernels.hip: clusters grown from the unsatisfied checks, one fault per step in
 order of posterior LLR, on-the-fly GF(2) elimination), one wavefront per shot.
 
-Device path coverage: `lsd_order = 0` (the reference wrapper's default; with order 0 the methods 'lsd_0', 'lsd_cs' and
-'lsd_e' are the same decoder) and ldpc's default `bits_per_step = 1`.  A higher order or another step size raises
+Device path coverage: `lsd_method` in {'lsd_0', 'lsd_cs', 'lsd_e'} with `lsd_order` <= 64 ('lsd_cs') / <= 15 ('lsd_e') -- every
+BP-LSD call the reference itself makes passes `lsd_order=1` (/root/reference/tests/test_decoders.py:136,
+doc/05_decoder_variants.ipynb cell 9) -- and ldpc's default `bits_per_step = 1`.  A larger order or another step size raises
 NotImplementedError -- never a silent change of algorithm; there is no CPU fallback.
+
+This is LSD as published (Hillmann et al. 2024) with the open choices fixed as oracle/qd_oracle.c (oq_lsd) states them
+(cluster order, tie breaks, which cluster absorbs, candidate costs log(1/p)): an LSD variant that is bit-exact against this
+repo's oracle, not against ldpc's implementation (whose source is not available here); the anchor to ldpc is statistical
+(tests/test_published_anchor.py: the BP-LSD failure rate published in doc/05_decoder_variants.ipynb).
 """
 from __future__ import annotations
 
@@ -21,13 +27,21 @@ _LSD_METHODS = ("lsd_0", "lsd0", "lsd_e", "lsde", "lsd_cs", "lsdcs", 0, 1, 2)
 
 
 def lsd_to_device_method(lsd_method, lsd_order, bits_per_step=1):
-    if (lsd_method.lower() if isinstance(lsd_method, str) else lsd_method) not in _LSD_METHODS:
+    """(osd_method, osd_order) of the device decoder for BpLsdDecoder's (lsd_method, lsd_order)."""
+    key = lsd_method.lower() if isinstance(lsd_method, str) else lsd_method
+    if key not in _LSD_METHODS:
         raise ValueError("lsd_method must be one of 'lsd_0', 'lsd_e', 'lsd_cs'")
-    if int(lsd_order) != 0:
-        raise NotImplementedError("BP-LSD on the device path implements lsd_order = 0 (LSD-0) only; got lsd_order = %r" % (lsd_order,))
+    order = int(lsd_order)
+    if order < 0:
+        raise ValueError("lsd_order must be non-negative")
     if int(bits_per_step) != 1:
         raise NotImplementedError("BP-LSD on the device path grows clusters one fault per step (ldpc's default bits_per_step = 1)")
-    return "lsd_0"
+    if order == 0 or key in ("lsd_0", "lsd0", 0):          # with order 0 the three methods are the same decoder
+        return "lsd_0", 0
+    cs = key in ("lsd_cs", "lsdcs", 2)
+    if order > (64 if cs else 15):
+        raise NotImplementedError("BP-LSD on the device path implements lsd_order <= %d for %r; got lsd_order = %d" % (64 if cs else 15, lsd_method, order))
+    return ("lsd_cs" if cs else "lsd_e"), order
 
 
 class BpLsdDecoder(BpOsdDecoder):
@@ -38,10 +52,11 @@ class BpLsdDecoder(BpOsdDecoder):
                  ms_scaling_factor=1.0, schedule="parallel", omp_thread_count=1, random_schedule_seed=0,
                  serial_schedule_order=None, bits_per_step=1, lsd_order=0, lsd_method="lsd_0", input_vector_type="syndrome",
                  channel_probs=None, **kwargs):
+        method, order = lsd_to_device_method(lsd_method, lsd_order, bits_per_step)
         super().__init__(pcm, error_rate=error_rate, error_channel=error_channel, max_iter=max_iter, bp_method=bp_method,
                          ms_scaling_factor=ms_scaling_factor, schedule=schedule, omp_thread_count=omp_thread_count,
                          random_schedule_seed=random_schedule_seed, serial_schedule_order=serial_schedule_order,
-                         osd_method=lsd_to_device_method(lsd_method, lsd_order, bits_per_step), osd_order=0,
+                         osd_method=method, osd_order=order,
                          input_vector_type=input_vector_type, channel_probs=channel_probs, **kwargs)
 
 

@@ -149,49 +149,66 @@ class DeviceWindowPlan:
         return pred
 
 
-def _kwargs_for_device(d):
-    allowed = ("bp_method", "schedule", "max_iter", "osd_method", "osd_order", "ms_scaling_factor")
+def _kwargs_for_device(d, cls):
+    """Keyword arguments of plug-in class `cls` -> BatchDecoder options.  The post-processor follows the CLASS, as it does in
+    ldpc: a BpLsdDecoder runs LSD whether or not the dict names `lsd_method` / `lsd_order` (ldpc's defaults 'lsd_0', 0), and
+    each class refuses the other's keywords with TypeError, as the real classes do -- never a silent change of algorithm."""
+    from .bplsd import BpLsdDecoder, lsd_to_device_method
+    common = ("bp_method", "schedule", "max_iter", "ms_scaling_factor")
+    rates = ("error_rate", "channel_probs", "error_channel")
     d = dict(d)
-    if "lsd_method" in d or "lsd_order" in d:        # BpLsdDecoder's options (reference bplsd.py:38-49,74-83)
-        from .bplsd import lsd_to_device_method
-        d["osd_method"] = lsd_to_device_method(d.pop("lsd_method", "lsd_0"), d.pop("lsd_order", 0), d.pop("bits_per_step", 1))
-        d["osd_order"] = 0
-    extra = [k for k in d if k not in allowed + ("error_rate", "channel_probs", "error_channel")]
+    is_lsd = isinstance(cls, type) and issubclass(cls, BpLsdDecoder)
+    own = ("lsd_method", "lsd_order", "bits_per_step") if is_lsd else ("osd_method", "osd_order")
+    extra = [k for k in d if k not in common + rates + own]
     if extra:
-        raise TypeError("unsupported decoder option(s) for the device path: %s" % ", ".join(sorted(extra)))
-    return {k: d[k] for k in d if k in allowed}
+        raise TypeError("%s() got unexpected keyword argument(s): %s" % (cls.__name__, ", ".join(sorted(extra))))
+    out = {k: d[k] for k in d if k in common}
+    if is_lsd:
+        out["osd_method"], out["osd_order"] = lsd_to_device_method(d.get("lsd_method", "lsd_0"), d.get("lsd_order", 0),
+                                                                   d.get("bits_per_step", 1))
+    else:
+        out.update({k: d[k] for k in d if k in own})
+    return out
 
 
-def build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2):
+def build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2, decoder1=None, decoder2=None):
+    from .bposd import BpOsdDecoder
     nz = hz.shape[0]
     num_cor_rounds, _, _ = window_count(num_rounds, W, F)
     checks, commits, priors, updates = spacetime(circuit, hz, W, F, num_cor_rounds)
     row0 = [F * k * nz for k in range(num_cor_rounds)] + [F * num_cor_rounds * nz]
     return DeviceWindowPlan(checks, commits, priors, updates, row0, nz, commits[0].shape[0],
-                            _kwargs_for_device(dict1), _kwargs_for_device(dict2))
+                            _kwargs_for_device(dict1, decoder1 or BpOsdDecoder), _kwargs_for_device(dict2, decoder2 or BpOsdDecoder))
 
 
-def build_phenom_plan(hz, lz, W, F, num_rounds, dict1, dict2):
+def phenom_window_set(hz, lz, W, F, num_rounds, rate_mid, rate_last):
+    """The phenomenological variant's windows in spacetime()'s format (checks, commits, priors, updates): the analytic window
+    matrices of reference sliding_window.py:56-68 with the slicing of :86,:88,:96,:99 written as matrices
+    (commit = lz @ sum of the first F data blocks, by linearity; hand-off = measurement block F-1 of the decoded vector)."""
     hz = np.asarray(hz) % 2
     lz = np.asarray(lz) % 2
     nz, nq = hz.shape
     num_cor_rounds, W_last, _ = window_count(num_rounds, W, F)
     h_mid, h_last = phenom_window_matrices(hz, W, F, W_last)
-    # commit = lz @ (sum of the first F data blocks)   (reference :86,:99, by linearity)
     commit_mid = csr_matrix(np.concatenate([np.tile(lz, (1, F)), np.zeros((lz.shape[0], h_mid.shape[1] - F * nq), int)], axis=1))
     commit_last = csr_matrix(np.concatenate([np.tile(lz, (1, W_last)), np.zeros((lz.shape[0], h_last.shape[1] - W_last * nq), int)], axis=1))
-    # hand-off = measurement block F-1 of the decoded vector (reference :88)
     sel = np.zeros((nz, h_mid.shape[1]), dtype=int)
     sel[np.arange(nz), W * nq + (F - 1) * nz + np.arange(nz)] = 1
     checks = [h_mid] * num_cor_rounds + [h_last]
     commits = [commit_mid] * num_cor_rounds + [commit_last]
     updates = [csr_matrix(sel)] * num_cor_rounds
-    p1 = float(dict1["error_rate"])
-    p2 = float(dict2["error_rate"])
-    priors = [np.full(h_mid.shape[1], p1)] * num_cor_rounds + [np.full(h_last.shape[1], p2)]
+    priors = [np.full(h_mid.shape[1], float(rate_mid))] * num_cor_rounds + [np.full(h_last.shape[1], float(rate_last))]
+    return checks, commits, priors, updates
+
+
+def build_phenom_plan(hz, lz, W, F, num_rounds, dict1, dict2, decoder1=None, decoder2=None):
+    from .bposd import BpOsdDecoder
+    nz = np.asarray(hz).shape[0]
+    num_cor_rounds, _, _ = window_count(num_rounds, W, F)
+    checks, commits, priors, updates = phenom_window_set(hz, lz, W, F, num_rounds, dict1["error_rate"], dict2["error_rate"])
     row0 = [F * k * nz for k in range(num_cor_rounds)] + [F * num_cor_rounds * nz]
-    return DeviceWindowPlan(checks, commits, priors, updates, row0, nz, lz.shape[0],
-                            _kwargs_for_device(dict1), _kwargs_for_device(dict2))
+    return DeviceWindowPlan(checks, commits, priors, updates, row0, nz, np.asarray(lz).shape[0],
+                            _kwargs_for_device(dict1, decoder1 or BpOsdDecoder), _kwargs_for_device(dict2, decoder2 or BpOsdDecoder))
 
 
 def sliding_window_phenom_mem(zcheck_samples, hz, lz, W, F, decoder1, decoder2, dict1: dict, dict2: dict,
@@ -210,7 +227,7 @@ def sliding_window_phenom_mem(zcheck_samples, hz, lz, W, F, decoder1, decoder2, 
         warnings.warn("Window size larger than the syndrome extraction rounds: Doing whole history correction")
 
     if _is_device_decoder(decoder1) and _is_device_decoder(decoder2) and function_name1 == function_name2 == "decode":
-        plan = build_phenom_plan(hz, lz, W, F, num_rounds, dict1, dict2)
+        plan = build_phenom_plan(hz, lz, W, F, num_rounds, dict1, dict2, decoder1, decoder2)
         pred = plan.decode(_to_device_samples(zcheck_samples))
         return pred.cpu().numpy().astype(np.int64)
 
@@ -256,7 +273,7 @@ def sliding_window_circuit_mem(zcheck_samples, circuit, hz, lz, W, F, decoder1, 
         warnings.warn("Window size larger than the syndrome extraction rounds: Doing whole history correction")
 
     if _is_device_decoder(decoder1) and _is_device_decoder(decoder2) and function_name1 == function_name2 == "decode":
-        plan = build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2)
+        plan = build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2, decoder1, decoder2)
         pred = plan.decode(_to_device_samples(zcheck_samples))
         return pred.cpu().numpy().astype(np.int64)
 

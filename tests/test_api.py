@@ -75,8 +75,9 @@ def test_package_surface_mirrors_reference():
 
 
 def test_bplsd_options_outside_the_device_path_fail_loudly():
-    """lsd_order > 0 / bits_per_step != 1 are legal for ldpc and not implemented on the device: NotImplementedError, raised
-    before anything touches the GPU; a missing error rate is the reference's ValueError (bplsd.py:35-36)."""
+    """bits_per_step != 1 and orders beyond the kernels' limits are legal for ldpc and not implemented on the device:
+    NotImplementedError, raised before anything touches the GPU; a missing error rate is the reference's ValueError
+    (bplsd.py:35-36).  lsd_order = 1 -- what the reference's own calls pass -- maps onto the device decoder."""
     import helpers
     from quits_amd.decoder import sliding_window_bplsd_circuit_mem, sliding_window_bplsd_phenom_mem
     from quits_amd.decoder.bplsd import lsd_to_device_method
@@ -84,14 +85,38 @@ def test_bplsd_options_outside_the_device_path_fail_loudly():
     cd = helpers.code("bb72")
     det = np.zeros((4, 36 * 8), np.uint8)
     with pytest.raises(NotImplementedError, match="lsd_order"):
-        sliding_window_bplsd_circuit_mem(det, Circuit(helpers.circuit_text("bb72_custom_r6_p0.003")), cd["hz"], cd["lz"], 3, 1, lsd_order=1)
+        sliding_window_bplsd_circuit_mem(det, Circuit(helpers.circuit_text("bb72_custom_r6_p0.003")), cd["hz"], cd["lz"], 3, 1, lsd_order=65)
+    with pytest.raises(NotImplementedError, match="lsd_order"):
+        lsd_to_device_method("lsd_e", 16)
     with pytest.raises(ValueError, match="eff_error_rate_per_fault"):
         sliding_window_bplsd_phenom_mem(det, cd["hz"], cd["lz"], 3, 1)
-    assert lsd_to_device_method("lsd_cs", 0) == lsd_to_device_method("lsd_e", 0) == lsd_to_device_method("lsd_0", 0) == "lsd_0"
+    assert lsd_to_device_method("lsd_cs", 0) == lsd_to_device_method("lsd_e", 0) == lsd_to_device_method("lsd_0", 0) == ("lsd_0", 0)
+    assert lsd_to_device_method("lsd_cs", 1) == ("lsd_cs", 1) and lsd_to_device_method("LSD_E", 7) == ("lsd_e", 7)
+    assert lsd_to_device_method("lsd_0", 3) == ("lsd_0", 0)
     with pytest.raises(NotImplementedError):
         lsd_to_device_method("lsd_0", 0, bits_per_step=2)
     with pytest.raises(ValueError):
         lsd_to_device_method("osd_cs", 0)
+
+
+def test_device_options_follow_the_decoder_class():
+    """the post-processor is chosen by the plug-in CLASS, not by which keys the dict happens to hold."""
+    from quits_amd.decoder import BpLsdDecoder, BpOsdDecoder
+    from quits_amd.decoder.sliding_window import _kwargs_for_device
+    base = {"bp_method": "product_sum", "max_iter": 3, "schedule": "serial", "channel_probs": None}
+    kw = _kwargs_for_device(base, BpLsdDecoder)                      # no lsd_* keys: still LSD (ldpc's defaults lsd_0 / order 0)
+    assert kw["osd_method"] == "lsd_0" and kw["osd_order"] == 0
+    kw = _kwargs_for_device(dict(base, osd_method="osd_cs", osd_order=2), BpOsdDecoder)
+    assert kw["osd_method"] == "osd_cs" and kw["osd_order"] == 2
+    assert "osd_method" not in _kwargs_for_device(base, BpOsdDecoder)            # BatchDecoder's default then applies
+    with pytest.raises(TypeError, match="lsd_order"):
+        _kwargs_for_device(dict(base, lsd_order=0), BpOsdDecoder)
+    with pytest.raises(TypeError, match="osd_method"):
+        _kwargs_for_device(dict(base, osd_method="osd_0"), BpLsdDecoder)
+
+    class MyLsd(BpLsdDecoder):
+        pass
+    assert _kwargs_for_device(base, MyLsd)["osd_method"] == "lsd_0"
 
 
 def test_dict_helpers():

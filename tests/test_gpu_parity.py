@@ -20,11 +20,11 @@ def _oracle(H, pri, max_iter, osd="osd_0", alpha=1.0, order=0):
     return g, orc.make_params("minimum_sum", "parallel", max_iter, osd, order, alpha, form)
 
 
-def _gpu_decode(H, pri, synd, max_iter, osd="osd_0", alpha=1.0):
+def _gpu_decode(H, pri, synd, max_iter, osd="osd_0", alpha=1.0, order=0):
     import torch
     from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
     g = WindowGraph(H, pri)
-    d = BatchDecoder(g, max_iter=max_iter, osd_method=osd, ms_scaling_factor=alpha)
+    d = BatchDecoder(g, max_iter=max_iter, osd_method=osd, osd_order=order, ms_scaling_factor=alpha)
     det = torch.from_numpy(np.ascontiguousarray(synd)).cuda()
     bits, status = d.decode(det)
     err = unpack_bits(bits, g.n).cpu().numpy()
@@ -68,6 +68,33 @@ def test_bp_bit_exact(gpu, name, shots, max_iter, alpha):
     assert np.array_equal(err, ref), "hard decisions differ"
     assert status[0] & (1 << 19) and not err[0].any()
     assert 0 < conv.mean() < 1 or shots < 50
+
+
+def test_large_max_iter_keeps_a_fine_llr_grid(gpu):
+    """ldpc's max_iter = 0 (-> n iterations): the fine grid stays at 2^-10 and only the shots whose exactness bound trips are
+    decoded again on the rule's grid (the grid used to follow max_iter down to 2^-3 for every shot).  Device ==
+    oracle bit for bit including which shots took the redo pass; and the predictions stay close to the exact-LLR double
+    form (ldpc's arithmetic) -- every shot that converges within the fine grid's range is decoded from LLRs within 5e-4 of ldpc's."""
+    name = "bb72_custom_r6_p0.003"
+    H, L, pri = helpers.dem_matrices(name)
+    shots = 400
+    synd, obs, _ = orc.sample_dem(H, L, pri, seed=41, shot0=0, B=shots)
+    err, status, dec = _gpu_decode(H, pri, synd, 0, osd="osd_0")
+    info = dec.info()
+    assert (info["llr_grid_bits"], info["llr_coarse_bits"]) == orc.grid_bits(pri, H.shape[1]) and info["llr_grid_bits"] == 10
+    g, prm = _oracle(H, pri, 0, "osd_0")
+    ref, flags, grid = g.decode_batch(synd, prm, return_grid=True)
+    assert np.array_equal((status >> 14) & 1, (grid[:, 0] != g.grid[0]).astype(int)), "coarse-grid flags differ"
+    assert 0 < ((status >> 14) & 1).sum() < shots // 2, "the redo pass should run for the few shots BP cannot finish, not for all"
+    assert not (status & (1 << 15)).any()
+    assert np.array_equal(status & 0x3FFF, flags[:, 1]) and np.array_equal(err, ref)
+    exact, fl_exact = orc.Graph(H, pri).decode_batch(synd, orc.make_params("minimum_sum", "parallel", 0, "osd_0", 0, 1.0, orc.FORM_LDPC_F64))
+    Ld = np.asarray(L.todense(), dtype=np.int64)
+    f_dev = ((err.astype(np.int64) @ Ld.T) % 2 != obs).any(axis=1)
+    f_ex = ((exact.astype(np.int64) @ Ld.T) % 2 != obs).any(axis=1)
+    conv_both = (flags[:, 0] == 1) & (fl_exact[:, 0] == 1)
+    assert (err[conv_both] != exact[conv_both]).any(axis=1).mean() < 0.02      # converged shots: same correction but for rare ties
+    assert abs(int(f_dev.sum()) - int(f_ex.sum())) <= 3 * np.sqrt(max(f_ex.sum(), 1)) + 2, (f_dev.sum(), f_ex.sum())
 
 
 @pytest.mark.parametrize("name,shots,max_iter", [
@@ -591,6 +618,96 @@ def test_bplsd_bit_exact(gpu, name, shots, max_iter):
     assert bad.size == 0, "LSD output differs on shots %s" % bad[:10]
     Hd = np.asarray(H.todense(), dtype=np.int64)
     assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+
+
+@pytest.mark.parametrize("name,shots,max_iter,method,order", [
+    ("bb72_custom_r6_p0.003", 1500, 8, "lsd_cs", 1),          # the order every BP-LSD call of the reference uses
+    ("bb72_custom_r6_p0.003", 600, 6, "lsd_cs", 5),
+    ("bb72_custom_r6_p0.003", 600, 6, "lsd_e", 4),
+    ("hgp225_cardinal_r3_p0.01", 150, 10, "lsd_cs", 2),
+    ("bb144_custom_r12_p0.003", 400, 30, "lsd_cs", 1),
+    ("bb144_custom_r12_p0.003", 200, 20, "lsd_e", 6),
+])
+def test_bplsd_higher_order_bit_exact(gpu, name, shots, max_iter, method, order):
+    """lsd_order > 0 (reference bplsd.py:10,54 forward lsd_method / lsd_order; its own calls pass lsd_order = 1:
+    /root/reference/tests/test_decoders.py:136): growth stage + per-cluster sweep on the device against the oracle's oq_lsd,
+    bit for bit, and the sweep really replaces LSD-0 solutions."""
+    H, L, pri = helpers.dem_matrices(name)
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=14, shot0=0, B=shots)
+    err, status, dec = _gpu_decode(H, pri, synd, max_iter, osd=method, order=order)
+    g, prm = _oracle(H, pri, max_iter, method, order=order)
+    ref, flags = g.decode_batch(synd, prm)
+    used = (status >> 17) & 1
+    assert np.array_equal(used, 1 - flags[:, 0]) and used.sum() > 10
+    assert np.array_equal((status >> 20) & 0xFFF, np.minimum(flags[:, 2], 4095)), "pivot counts differ"
+    bad = np.flatnonzero((err != ref).any(axis=1))
+    assert bad.size == 0, "LSD-w output differs on shots %s" % bad[:10]
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+    err0, _, _ = _gpu_decode(H, pri, synd, max_iter, osd="lsd_0")
+    assert (err != err0).any(axis=1).sum() > 3, "the higher order never changed a solution: test does not exercise the sweep"
+
+
+def test_bplsd_higher_order_crafted_soft_information(gpu):
+    """LSD-w alone on soft information that forces ties, big merged clusters with many non-pivot faults (more candidate
+    positions than the 64 whose images are kept; exhaustive patterns on the first 10), and inconsistent syndromes."""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    m, n = H.shape
+    rng = np.random.default_rng(18)
+    B = 20
+    synd, _, _ = orc.sample_dem(H, L, pri, seed=6, shot0=0, B=B)
+    synd[B - 3:] = (rng.random((3, m)) < 0.2).astype(np.uint8)            # mostly inconsistent (rank 1002 < 1008)
+    llr = rng.normal(size=(B, n)).astype(np.float32)
+    llr[:5] = 2.5
+    llr[5:10] = rng.choice(np.array([-1.0, 0.25, 3.0], np.float32), size=(5, n))
+    wg = WindowGraph(H, pri)
+    g = orc.Graph(H, pri)
+    for method, order in (("lsd_cs", 1), ("lsd_cs", 12), ("lsd_cs", 64), ("lsd_e", 10)):
+        dec = BatchDecoder(wg, max_iter=1, osd_method=method, osd_order=order)
+        bits, status = dec.osd0(torch.from_numpy(synd).cuda(), torch.from_numpy(llr).cuda())
+        err, status = unpack_bits(bits, n).cpu().numpy(), status.cpu().numpy()
+        swept = 0
+        for b in range(B):
+            ref, st = g.lsd(synd[b], llr[b].astype(np.float64), method, order, fixed=True)
+            assert np.array_equal(err[b], ref), (method, order, b, st)
+            assert ((status[b] >> 20) & 0xFFF) == min(st["pivots"], 4095) and bool(status[b] & (1 << 18)) == st["inconsistent"], (b, st)
+            swept += st["replaced"]
+        assert swept > 0, (method, order)
+
+
+def test_reference_decoder_tests_bposd_and_bplsd_phenom(gpu):
+    """/root/reference/tests/test_decoders.py:88-159 on the device: BPC code (lift 15, factor 3), cardinal circuit seed 1,
+    p = 5e-4, 10 rounds, W = 5, F = 3, eff_error_rate_per_fault = p (depth + 3), max_iter = 10, osd_order = 1 / lsd_order = 1,
+    wrapper defaults otherwise -- with the reference's own acceptance thresholds, on 20 000 shots instead of 50, and bit for
+    bit against the oracle on the first 96."""
+    from quits_amd.decoder import sliding_window_bplsd_phenom_mem, sliding_window_bposd_phenom_mem
+    from quits_amd.decoder.base import detector_error_model_to_matrix
+    from quits_amd.decoder.device import DemSampler
+    from quits_amd.decoder.sliding_window import phenom_window_set
+    from quits_amd.dem import Circuit
+    name = "bpc_cardinal_r10_p0.0005"
+    meta = helpers.circuit_index()[name]
+    cd = helpers.code("bpc_15_3")
+    hz, lz = cd["hz"], cd["lz"]
+    nz = hz.shape[0]
+    R, W, F, p = 10, 5, 3, 5e-4
+    eff = p * (meta["depth"] + 3)
+    H, L, pri = detector_error_model_to_matrix(Circuit(helpers.circuit_text(name)).detector_error_model())
+    det, obs = DemSampler(H, L, pri).sample(20000, seed=1)
+    obs = obs.cpu().numpy()
+    for fn, kw, lim_pl, lim_lfr, method in ((sliding_window_bposd_phenom_mem, dict(max_iter=10, osd_order=1), 0.25, 0.08, "osd_cs"),
+                                            (sliding_window_bplsd_phenom_mem, dict(max_iter=10, lsd_order=1), 0.3, 0.1, "lsd_cs")):
+        pred = fn(det, hz, lz, W, F, eff_error_rate_per_fault=eff, tqdm_on=False, **kw)
+        pL = np.mean((obs - pred).any(axis=1))                       # the reference's formulas (test_decoders.py:68-69)
+        lfr = 1 - (1 - pL) ** (1 / R)
+        assert pL <= lim_pl and lfr <= lim_lfr, (fn.__name__, pL, lfr)
+        a, b, pp, d = phenom_window_set(hz, lz, W, F, R, eff, eff)
+        wins = [{"H": a[k], "L": b[k], "priors": pp[k], "U": d[k] if k < len(d) else None, "row0": F * k * nz} for k in range(len(a))]
+        ref, stats = orc.sliding_window_decode(wins, nz, det[:96].cpu().numpy(),
+                                               orc.make_params("product_sum", "serial", 10, method, 1, 1.0, orc.FORM_LDPC_F32))
+        assert np.array_equal(pred[:96], ref.astype(np.int64)), fn.__name__
 
 
 def test_bplsd_crafted_soft_information_and_inconsistent(gpu):

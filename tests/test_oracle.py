@@ -242,6 +242,11 @@ def test_grid_bound_sends_a_shot_to_the_coarse_grid():
     e32, fl32, gr32 = g.decode_batch(synd, orc.make_params("minimum_sum", "parallel", 40, "osd_0", 0, 1.0, orc.FORM_COMPRESSED_F32), return_grid=True)
     assert np.array_equal(e32, e) and np.array_equal(gr32, gr)
     assert orc.grid_bits(np.array([0.003]), 50) == (11, 7) and orc.grid_bits(np.array([0.5 - 1e-9]), 1)[0] == 20
+    # a large max_iter (ldpc: max_iter = 0 -> n) no longer drags every shot onto a grid of 1/8: the fine grid stops at 2^-10 and
+    # the rule's grid becomes the redo grid; the device's 14-bit iteration field caps the rule's max_iter
+    assert orc.grid_bits(np.array([0.003]), 9504) == (10, 4) and orc.grid_bits(np.array([0.003]), 200) == (10, 9)
+    assert orc.grid_bits(np.array([0.003]), 10 ** 6) == orc.grid_bits(np.array([0.003]), 16383)
+    assert orc.device_max_iter(0, 18900) == 16383 and orc.device_max_iter(0, 2592) == 2592 and orc.device_max_iter(7, 100) == 7
 
 
 def test_lsd0_invariants():
@@ -277,3 +282,69 @@ def test_lsd0_invariants():
     bad = (rng.random(H2.shape[0]) < 0.4).astype(np.uint8)
     e3, st3 = g2.lsd0(bad, rng.normal(size=H2.shape[1]))
     assert st3["inconsistent"]
+
+
+def _cost_fixed(err, pri):
+    w = np.array([orc.lib().oq_fixed_weight(float(p)) for p in pri], dtype=np.int64)
+    return int((err.astype(np.int64) * w).sum())
+
+
+@pytest.mark.parametrize("method", ["lsd_cs", "lsd_e"])
+def test_higher_order_lsd_invariants(method):
+    """oq_lsd with lsd_order > 0 (what every BP-LSD call of the reference asks for: tests/test_decoders.py:136): order 0 is
+    LSD-0; every output reproduces its syndrome; the growth stage leaves the LSD-0 solution alone, so with integer costs a
+    higher order never costs more than LSD-0, and raising the order of 'lsd_e' on the same clusters never costs more; an order
+    beyond every cluster's dimension changes nothing further."""
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    synd, obs, _ = orc.sample_dem(H, L, pri, seed=31, shot0=0, B=160)
+    g = orc.Graph(H, pri)
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    prm = orc.make_params("product_sum", "parallel", 3, "osd_off", 0, 1.0, orc.FORM_LDPC_F64)
+    better = grown = 0
+    for b in range(160):
+        conv, dec, llr, it = g.bp(synd[b], prm)
+        if conv:
+            continue
+        e0, st0 = g.lsd0(synd[b], llr)
+        ez, stz = g.lsd(synd[b], llr, method, 0, fixed=True)
+        assert np.array_equal(e0, ez) and stz["grown"] == 0 and stz["swept"] == 0
+        c0 = _cost_fixed(e0, pri)
+        prev = c0
+        for order in (1, 2, 5):
+            e, st = g.lsd(synd[b], llr, method, order, fixed=True)
+            assert np.array_equal((e.astype(np.int64) @ Hd.T) % 2, synd[b]), (b, order)
+            c = _cost_fixed(e, pri)
+            assert c <= c0, (b, order, c, c0)
+            assert st["added"] >= st0["added"] and st["grown"] == st["added"] - st0["added"]
+            assert st["replaced"] <= st["swept"]
+            better += c < c0
+            grown += st["grown"]
+            prev = c
+        ed, std = g.lsd(synd[b], llr, method, 5, fixed=False)          # ldpc's double costs: same winner unless two costs tie to 1e-5
+        assert np.array_equal((ed.astype(np.int64) @ Hd.T) % 2, synd[b])
+    assert better > 5 and grown > 20, (better, grown)
+
+
+def test_higher_order_lsd_small_case_by_brute_force():
+    """One cluster, hand-checkable: repetition-code chain H (4 checks x 6 faults incl. two parallel faults on check 1-2).
+    Syndrome on checks 1, 2.  LSD-0 takes the lowest-LLR fault; with order 1 the cheaper parallel fault must win when costs say so."""
+    from scipy.sparse import csc_matrix
+    H = csc_matrix(np.array([[1, 1, 0, 0, 0, 0],
+                             [0, 1, 1, 1, 0, 0],
+                             [0, 0, 1, 1, 1, 0],
+                             [0, 0, 0, 0, 1, 1]], dtype=np.uint8))
+    pri = np.array([0.01, 0.01, 0.001, 0.2, 0.01, 0.01])          # fault 3 is cheap (log 1/p small), fault 2 expensive
+    g = orc.Graph(H, pri)
+    s = np.array([0, 1, 1, 0], np.uint8)
+    llr = np.array([3.0, 3.0, 0.5, 1.0, 3.0, 3.0])                # posteriors prefer fault 2
+    e0, st0 = g.lsd0(s, llr)
+    assert e0.tolist() == [0, 0, 1, 0, 0, 0] and st0["added"] == 1
+    e1, st1 = g.lsd(s, llr, "lsd_cs", 1)
+    # growth stage: dimension 0 < 1 -> one more fault joins (lowest LLR touching checks 1, 2: fault 3), it is dependent on fault 2
+    # (same column) -> non-pivot; sweep: flip fault 3 => fault 2 off; cost log(1/0.2) < log(1/0.001)
+    assert st1["grown"] == 1 and st1["swept"] == 1 and st1["replaced"] == 1
+    assert e1.tolist() == [0, 0, 0, 1, 0, 0]
+    # with the costs the other way round the LSD-0 solution stays
+    g2 = orc.Graph(H, np.array([0.01, 0.01, 0.2, 0.001, 0.01, 0.01]))
+    e2, st2 = g2.lsd(s, llr, "lsd_cs", 1)
+    assert e2.tolist() == [0, 0, 1, 0, 0, 0] and st2["replaced"] == 0

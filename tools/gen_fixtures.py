@@ -119,6 +119,58 @@ def gen_codes(with_qlp=False):
 
 
 # ----------------------------------------------------------------------------------------------------------
+def gen_anchor_circuits():
+    """Circuits of the reference's EXECUTED notebook cells, whose printed outputs are the only results of the real
+    ldpc + Stim pipeline available to this repo (doc/06A_end_to_end_demo_hgp.ipynb cell 5, doc/06B_end_to_end_demo_bb.ipynb
+    cell 5, doc/04_decoding_sliding_window.ipynb cells 5-9, doc/05_decoder_variants.ipynb cells 8-9,
+    doc/00_getting_started.ipynb cell 8).  One fixture per circuit at p = 1e-3; the other rates of a sweep differ only by the
+    printed '%.10f' literal (tests/helpers.py: circuit_text_at_p)."""
+    import_reference()
+    from quits.noise import ErrorModel
+    from quits.qldpc_code import BbCode, HgpCode
+    from quits.qldpc_code.circuit_construction.circuit_build_options import CircuitBuildOptions
+
+    meta = {}
+    h = np.loadtxt(os.path.join(REF, "parity_check_matrices", "n=12_dv=3_dc=4_dist=6.txt"), dtype=int)
+    hgp = HgpCode(h, h)
+    p = 1e-3
+    c = hgp.build_circuit(error_model=ErrorModel(p, p, p, p), num_rounds=15, basis="Z",
+                          circuit_build_options=CircuitBuildOptions(), seed=1)      # 06A cell 5 / 04 cell 5: default strategy
+    assert hgp.depth == 8, hgp.depth                                               # "# layer of entangling gates:  8" (04 cell 5 output)
+    _save_text("hgp225_cardinal_r15_p0.001", c)
+    meta["hgp225_cardinal_r15_p0.001"] = dict(code="hgp225", rounds=15, p=p, strategy="default(cardinal)", seed=1, depth=8)
+    bb = BbCode(l=15, m=3, A_x_pows=[9], A_y_pows=[1, 2], B_x_pows=[2, 7], B_y_pows=[0])
+    c = bb.build_circuit(error_model=ErrorModel(p, p, p, p), num_rounds=15, basis="Z",
+                         circuit_build_options=CircuitBuildOptions())              # 06B cell 5: default strategy
+    old = _load_text("bb90_custom_r15_p0.001")
+    assert str(c) == old, "06B's default-strategy circuit differs from the committed custom-strategy fixture"
+    # 00_getting_started cell 4/8: 3 x 3 cyclic repetition matrix -> HGP [[18,2,3]], zxcoloration, R = 3
+    H = np.zeros((3, 3), dtype=int)
+    for i in range(3):
+        H[i, i] = 1
+        H[i, (i + 1) % 3] = 1
+    small = HgpCode(H, H)
+    _save_code("hgp_rep3", small)
+    c = small.build_circuit(strategy="zxcoloration", error_model=ErrorModel(idle_error=1e-3, sqgate_error=1e-3,
+                                                                            tqgate_error=1e-3, spam_error=1e-3),
+                            num_rounds=3, basis="Z")
+    assert small.depth == 8, small.depth                                           # "HGP zxcoloration depth: 8" (00 cell 4 output)
+    _save_text("hgprep3_zxcoloration_r3_p0.001", c)
+    meta["hgprep3_zxcoloration_r3_p0.001"] = dict(code="hgp_rep3", rounds=3, p=1e-3, strategy="zxcoloration", depth=8)
+    # the reference's own decoder tests (tests/test_decoders.py:9-31,88-159): BPC code, cardinal seed 1, R = 10, p = 5e-4
+    from quits.qldpc_code import BpcCode
+    bpc = BpcCode([0, 1, 5], [0, 8, 13], 15, 3)
+    c = bpc.build_circuit(strategy="cardinal", error_model=ErrorModel(5e-4, 5e-4, 5e-4, 5e-4), num_rounds=10, basis="Z", seed=1)
+    _save_code("bpc_15_3", bpc)
+    _save_text("bpc_cardinal_r10_p0.0005", c)
+    meta["bpc_cardinal_r10_p0.0005"] = dict(code="bpc_15_3", rounds=10, p=5e-4, strategy="cardinal", seed=1, depth=int(bpc.depth))
+    mpath = os.path.join(GOLD, "circuits", "index.json")
+    idx = json.load(open(mpath))
+    idx.update(meta)
+    json.dump(idx, open(mpath, "w"), indent=1, sort_keys=True)
+    print("anchor circuits written:", sorted(meta), "hgp_rep3 hz", small.hz.shape, "lz", small.lz.shape)
+
+
 def _load_text(name):
     with gzip.open(os.path.join(GOLD, "circuits", name + ".stim.gz"), "rb") as f:
         return f.read().decode()
@@ -358,6 +410,8 @@ if __name__ == "__main__":
         gen_codes(with_qlp=False)
     if what == "qlp":
         gen_codes(with_qlp=True)
+    if what in ("all", "anchor"):
+        gen_anchor_circuits()
     if what in ("all", "dem"):
         gen_dem_merge()
     if what in ("all", "windows"):
