@@ -46,7 +46,8 @@
 #define OQ_FORM_LDPC_F64 0      /* per-edge messages, double, ldpc's update order              */
 #define OQ_FORM_COMPRESSED_F32 1 /* compressed min-sum state, float: bit-exact mirror of the HIP kernel */
 #define OQ_FORM_COMPRESSED_F64 2
-#define OQ_FORM_LDPC_F32 3       /* per-edge messages, float: bit-exact mirror of the general HIP kernel (bp_general.hip) */
+#define OQ_FORM_LDPC_F32 3       /* per-edge messages, float: bit-exact mirror of the general HIP kernel (bp_general.hip); the serial
+                                 * product-sum product is taken as prefix * suffix there (bp_core.inc, bp_serial_ps_presuf) */
 #define OQ_MAX_COL_DEG 64
 
 typedef struct {
@@ -186,6 +187,7 @@ void oq_graph_destroy(oq_graph *g)
 
 #define REAL float
 #define SFX _f32
+#define OQ_SERIAL_PRESUF
 #define REAL_MAX FLT_MAX
 #define REAL_ABS fabsf
 #define REAL_TANH_HALF(x) qd_tanh_half(x)
@@ -221,6 +223,7 @@ int oq_bp_decode(const oq_graph *g, const oq_params *prm_in, const uint8_t *synd
     if (use_f32) {
         float *l = (float *)malloc(sizeof(float) * (size_t)g->n);
         if (compressed) conv = bp_minsum_compressed_f32(g, &prm, synd, dec, l, iters);
+        else if (prm.schedule == OQ_SERIAL && prm.bp_method == OQ_PRODUCT_SUM) conv = bp_serial_ps_presuf_f32(g, &prm, synd, dec, l, iters);
         else if (prm.schedule == OQ_SERIAL) conv = bp_serial_edge_f32(g, &prm, synd, dec, l, iters);
         else conv = bp_parallel_edge_f32(g, &prm, synd, dec, l, iters);
         for (int j = 0; j < g->n; j++) llr_out[j] = (double)l[j];

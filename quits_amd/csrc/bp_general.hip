@@ -16,30 +16,27 @@
 // take every G-th row / column, with a barrier between the passes -- G times the loads in flight for the same memory.
 // Serial schedule: faults that share no check commute; they are grouped into dependency levels on the host and the G = 4
 // wavefronts of a workgroup take the faults of a level in parallel, one barrier per level (3.4 faults per level at the
-// headline: 2795 levels for 9504 faults).
+// headline: 2795 levels for 9504 faults).  bp.hpp recomputes, for every edge (i, j) it visits, the product (minimum) over the
+// OTHER edges of row i: row weight loads per edge, 14 dependent memory round trips per fault.  Here a row keeps a running PREFIX
+// over the entries the sweep has already refreshed (natural fault order = ascending position in every row) and, per edge, the
+// SUFFIX over the entries still to come, computed once at the start of the sweep: one load of each per edge, one round trip per
+// fault.  Minimum and sign parity are associative, so min-sum returns bp.hpp's numbers exactly; the product-sum product becomes
+// (prefix, left to right) x (suffix, right to left) -- the order bp.hpp itself uses in its flooding schedule -- instead of one
+// left-to-right chain: the float mirror (oracle/bp_core.inc, bp_serial_ps_presuf) follows, the double-precision reference
+// form keeps bp.hpp's chain.
 //
 // The adjacency arrays are separate __restrict__ kernel arguments on purpose: only then can the compiler prove that the
 // kernel's stores do not clobber them and read them with scalar loads (as members of the by-value graph struct they came
 // in through vector loads + readfirstlane, one dependent VMEM round trip each).
 //
 // tanh(x/2) and log((1+c)/(1-c)) are the fixed-operation-order float functions of qd_math.h (shared with the CPU mirror).
-// The serial product-sum schedule keeps tanh(b2c/2) of every edge beside the message (bp.hpp re-evaluates it once per
+// The serial product-sum schedule keeps tanh(b2c/2) of every edge INSTEAD of the message (bp.hpp re-evaluates it once per
 // use, row weight times per sweep; a pure function of an unchanged argument, so the cached value is the same number).
 #include "qd_internal.h"
 #include "qd_math.h"
 #include "../../include/quits_amd.h"
 
-#ifndef QD_GEN_KG
-#define QD_GEN_KG 1           // (6 measured 5-10 % slower: the scans are not what the serial schedule waits for)
-#endif
-//      QD_GEN_KG:          // checks of one fault whose rows the serial schedule scans together
 #define QD_GEN_MLP 8          // loads of one row issued together (the arithmetic that follows keeps bp.hpp's order)
-
-#ifdef QD_GEN_TIMING   // serial-schedule phase timers: 0 adjacency, 1 row scans, 2 log / posterior, 3 backward sweep
-#define QD_GT(slot) { const unsigned long long now_ = clock64(); gacc_[slot] += now_ - gtick_; gtick_ = now_; }
-#else
-#define QD_GT(slot)
-#endif
 
 // per-lane OR across the G wavefronts of the workgroup (every wavefront gets the result)
 template <int G>
@@ -55,7 +52,8 @@ __device__ __forceinline__ uint32_t qd_lanes_or(uint32_t v, uint32_t (*red)[64],
     return r;
 }
 
-template <int METHOD, int SCHED, int G>
+// D: bound on the column weight the instantiation unrolls for (4, 8 or QD_MAX_COL_DEG; registers: five arrays of D in the serial schedule)
+template <int METHOD, int SCHED, int G, int D>
 __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                             const int32_t *__restrict__ cp, const int32_t *__restrict__ ri,
                                                             const int32_t *__restrict__ c2r, const float *__restrict__ llr0,
@@ -74,11 +72,12 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
     // wavefronts; it measured 30 % slower in the flooding schedule.)
     const size_t S = (size_t)w.S;
     const int lsc = active ? ls : 0;
-    float *__restrict__ b2c = w.b2c + lsc;                           // [nnz][S], CSR edge order
+    float *__restrict__ b2c = w.b2c ? w.b2c + lsc : nullptr;         // [nnz][S], CSR edge order (not for serial product-sum)
     float *__restrict__ c2b = w.c2b + lsc;
     float *__restrict__ th = w.th ? w.th + lsc : nullptr;            // product-sum only
     float *__restrict__ llr = w.llr + lsc;                           // [n][S]
     uint8_t *__restrict__ syn = w.syn + lsc;                         // [m][S]
+    float *__restrict__ rpre = w.pre ? w.pre + lsc : nullptr;        // [m][S] serial schedule: running prefix of each row
     const float BIG = 3.402823466e+38f;
 
     // ---- window syndrome (sliding_window.py:168-169)
@@ -110,16 +109,13 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
             const float l0 = llr0[j];
             for (int e = cp[j]; e < cp[j + 1]; ++e) {
                 const size_t ce = (size_t)c2r[e] * S;
-                b2c[ce] = l0;
                 if (METHOD == QD_BP_PRODUCT_SUM && SCHED == QD_SCHEDULE_SERIAL) th[ce] = qd_tanh_half(l0);
+                else b2c[ce] = l0;
             }
         }
     if (G > 1) __syncthreads();
 
     int iters = 0, converged = 0;
-#ifdef QD_GEN_TIMING
-    unsigned long long gacc_[4] = {0, 0, 0, 0}, gtick_ = clock64();
-#endif
     for (int it = 1; it <= a.max_iter; ++it) {
         if (G > 1) { if (!__syncthreads_or(active ? 1 : 0)) break; }
         else if (!active) break;
@@ -229,103 +225,112 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
             if (G > 1) __syncthreads();
             for (int j = wv; active && j < g.n; j += G) {
                 const int c0 = cp[j], deg = cp[j + 1] - c0;
-                float cv[QD_MAX_COL_DEG], pre[QD_MAX_COL_DEG];
+                float cv[D], pre[D];
 #pragma unroll
-                for (int k = 0; k < QD_MAX_COL_DEG; ++k)
+                for (int k = 0; k < D; ++k)
                     if (k < deg) cv[k] = c2b[(size_t)c2r[c0 + k] * S];
                 float temp = llr0[j];
 #pragma unroll
-                for (int k = 0; k < QD_MAX_COL_DEG; ++k)
+                for (int k = 0; k < D; ++k)
                     if (k < deg) { pre[k] = temp; temp += cv[k]; }
                 llr[(size_t)j * S] = temp;
                 temp = 0.f;
 #pragma unroll
-                for (int k = QD_MAX_COL_DEG - 1; k >= 0; --k)
+                for (int k = D - 1; k >= 0; --k)
                     if (k < deg) { b2c[(size_t)c2r[c0 + k] * S] = pre[k] + temp; temp += cv[k]; }
             }
             if (G > 1) __syncthreads();
         } else {
-            // ---- serial schedule: each fault refreshes its incoming messages first.  Faults are taken level by level (see
-            // GenGraphDev): inside a level they share no check, so the G wavefronts take one each; across levels every pair of
-            // faults with a common check keeps its natural order -- the result is that of the natural-order sweep of bp.hpp.
+            // ---- serial schedule (see the header).  msg = tanh(b2c / 2) (product-sum) or b2c (min-sum), per CSR edge; suf = the
+            // suffix over the row entries behind an edge; pre = the row's running prefix.  Min-sum packs the parity of the
+            // "<= 0" signs into the sign bit of the (non-negative) running minimum.
+            float *__restrict__ msg = METHOD == QD_BP_PRODUCT_SUM ? th : b2c;
+            float *__restrict__ suf = c2b;
+            for (int i = wv; active && i < g.m; i += G) {
+                const int r0 = rp[i], r1 = rp[i + 1];
+                float sm = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
+                uint32_t par = 0u;
+                int e = r1 - 1;
+                for (; e - (QD_GEN_MLP - 1) >= r0; e -= QD_GEN_MLP) {
+                    float v[QD_GEN_MLP];
+#pragma unroll
+                    for (int k = 0; k < QD_GEN_MLP; ++k) v[k] = msg[(size_t)(e - k) * S];
+#pragma unroll
+                    for (int k = 0; k < QD_GEN_MLP; ++k) {
+                        if (METHOD == QD_BP_PRODUCT_SUM) { suf[(size_t)(e - k) * S] = sm; sm = v[k] * sm; }
+                        else {
+                            suf[(size_t)(e - k) * S] = __uint_as_float(__float_as_uint(sm) | (par << 31));
+                            const float av = fabsf(v[k]);
+                            if (av < sm) sm = av;
+                            par ^= (v[k] <= 0.f) ? 1u : 0u;
+                        }
+                    }
+                }
+                for (; e >= r0; --e) {
+                    const float v = msg[(size_t)e * S];
+                    if (METHOD == QD_BP_PRODUCT_SUM) { suf[(size_t)e * S] = sm; sm = v * sm; }
+                    else {
+                        suf[(size_t)e * S] = __uint_as_float(__float_as_uint(sm) | (par << 31));
+                        const float av = fabsf(v);
+                        if (av < sm) sm = av;
+                        par ^= (v <= 0.f) ? 1u : 0u;
+                    }
+                }
+                rpre[(size_t)i * S] = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
+            }
+            if (G > 1) __syncthreads();
+            // Faults are taken level by level (see GenGraphDev): inside a level they share no check, so the G wavefronts take one
+            // each; across levels every pair of faults with a common check keeps its natural order -- the result is that of the
+            // natural-order sweep of bp.hpp.
             for (int lev = 0; lev < g.nlev; ++lev) {
             const int x1 = lvl_ptr[lev + 1];
             for (int x = lvl_ptr[lev] + wv; active && x < x1; x += G) {
                 const int j = lvl_bits[x];
-                const int c0 = cp[j], c1 = cp[j + 1];
+                const int c0 = cp[j], deg = cp[j + 1] - c0;
                 float lj = llr0[j];
-                float cv[QD_MAX_COL_DEG], pre[QD_MAX_COL_DEG];
-                const int deg = c1 - c0;
-                QD_GT(3)
-                // The incoming messages of the fault's checks do not depend on one another, only the running posterior
-                // does: the rows of up to QD_GEN_KG checks are scanned together (QD_GEN_KG x QD_GEN_MLP loads in flight),
-                // each check's own product / minimum still in bp.hpp's order.
+                float P[D], X[D], cv[D], pr[D];
+                uint32_t sy[D];
 #pragma unroll
-                for (int k0 = 0; k0 < QD_MAX_COL_DEG; k0 += QD_GEN_KG) {
-                    if (k0 >= deg) break;
-                    int r0[QD_GEN_KG], r1[QD_GEN_KG], own[QD_GEN_KG], sg[QD_GEN_KG];
-                    float t[QD_GEN_KG];
-                    int maxlen = 0;
-#pragma unroll
-                    for (int k = 0; k < QD_GEN_KG; ++k) {
-                        r0[k] = 0; r1[k] = 0; own[k] = -1; sg[k] = 0;
-                        t[k] = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
-                        if (k0 + k < QD_MAX_COL_DEG && k0 + k < deg) {
-                            const int e = c0 + k0 + k;
-                            const int i = ri[e];
-                            own[k] = c2r[e];
-                            r0[k] = rp[i]; r1[k] = rp[i + 1];
-                            sg[k] = (int)syn[(size_t)i * S];
-                            maxlen = max(maxlen, r1[k] - r0[k]);
-                        }
+                for (int k = 0; k < D; ++k)
+                    if (k < deg) {
+                        const int i = ri[c0 + k];
+                        P[k] = rpre[(size_t)i * S];
+                        X[k] = suf[(size_t)c2r[c0 + k] * S];
+                        sy[k] = syn[(size_t)i * S];
                     }
-                    QD_GT(0)
-                    const float *__restrict__ src = METHOD == QD_BP_PRODUCT_SUM ? th : b2c;
-                    for (int off = 0; off < maxlen; off += QD_GEN_MLP) {
-                        float v[QD_GEN_KG][QD_GEN_MLP];
 #pragma unroll
-                        for (int k = 0; k < QD_GEN_KG; ++k)
-#pragma unroll
-                            for (int q = 0; q < QD_GEN_MLP; ++q)
-                                if (r0[k] + off + q < r1[k]) v[k][q] = src[(size_t)(r0[k] + off + q) * S];
-#pragma unroll
-                        for (int k = 0; k < QD_GEN_KG; ++k)
-#pragma unroll
-                            for (int q = 0; q < QD_GEN_MLP; ++q) {
-                                const int f = r0[k] + off + q;
-                                if (f < r1[k] && f != own[k]) {
-                                    if (METHOD == QD_BP_PRODUCT_SUM) t[k] = t[k] * v[k][q];
-                                    else {
-                                        const float av = fabsf(v[k][q]);
-                                        if (av < t[k]) t[k] = av;
-                                        if (v[k][q] <= 0.f) sg[k] += 1;
-                                    }
-                                }
-                            }
-                    }
-                    QD_GT(1)
-#pragma unroll
-                    for (int k = 0; k < QD_GEN_KG; ++k)
-                        if (k0 + k < QD_MAX_COL_DEG && k0 + k < deg) {
-                            float c;
-                            if (METHOD == QD_BP_PRODUCT_SUM) c = ((sg[k] & 1) ? -1.0f : 1.0f) * qd_log_ratio(t[k]);
-                            else c = alpha * ((sg[k] % 2 == 0) ? 1.0f : -1.0f) * t[k];
-                            cv[k0 + k] = c;              // (bp.hpp stores c2b and b2c here; nothing reads them before the
-                            pre[k0 + k] = lj;            //  backward sweep below, which writes the final b2c)
-                            lj += c;
+                for (int k = 0; k < D; ++k)
+                    if (k < deg) {
+                        float c;
+                        if (METHOD == QD_BP_PRODUCT_SUM) c = (sy[k] ? -1.0f : 1.0f) * qd_log_ratio(P[k] * X[k]);
+                        else {
+                            const float a1 = fabsf(P[k]), a2 = fabsf(X[k]);
+                            const uint32_t sg = (sy[k] ^ (__float_as_uint(P[k]) >> 31) ^ (__float_as_uint(X[k]) >> 31)) & 1u;
+                            c = alpha * (sg ? -1.0f : 1.0f) * (a2 < a1 ? a2 : a1);
                         }
-                }
-                QD_GT(2)
+                        cv[k] = c;
+                        pr[k] = lj;
+                        lj += c;
+                    }
                 llr[(size_t)j * S] = lj;
                 float temp = 0.f;
 #pragma unroll
-                for (int k = QD_MAX_COL_DEG - 1; k >= 0; --k)
-                    if (k < c1 - c0) {               // b2c = prefix (kept in registers) + suffix; c2b likewise
+                for (int k = D - 1; k >= 0; --k)
+                    if (k < deg) {               // b2c = prefix (kept in registers) + suffix
+                        const int i = ri[c0 + k];
                         const size_t ce = (size_t)c2r[c0 + k] * S;
-                        const float v = pre[k] + temp;
-                        b2c[ce] = v;
-                        if (METHOD == QD_BP_PRODUCT_SUM) th[ce] = qd_tanh_half(v);
+                        const float v = pr[k] + temp;
                         temp += cv[k];
+                        if (METHOD == QD_BP_PRODUCT_SUM) {
+                            const float nt = qd_tanh_half(v);
+                            msg[ce] = nt;
+                            rpre[(size_t)i * S] = P[k] * nt;
+                        } else {
+                            msg[ce] = v;
+                            const float a1 = fabsf(P[k]), av = fabsf(v);
+                            const uint32_t np = (__float_as_uint(P[k]) >> 31) ^ ((v <= 0.f) ? 1u : 0u);
+                            rpre[(size_t)i * S] = __uint_as_float(__float_as_uint(av < a1 ? av : a1) | (np << 31));
+                        }
                     }
             }
             if (G > 1) __syncthreads();
@@ -362,9 +367,6 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
         for (int j = 32 * x; j < j1; ++j) word |= ((llr[(size_t)j * S] <= 0.f) ? 1u : 0u) << (j & 31);
         out[x] = word;
     }
-#ifdef QD_GEN_TIMING
-    if (lane == 0 && wv == 0) { for (int i = 0; i < 4; ++i) atomicAdd(&a.dbg[i], gacc_[i]); atomicAdd(&a.dbg[4], (unsigned long long)iters); }
-#endif
     if (wv != 0) return;
     a.status[shot] = iters | (converged << 16);
     if (!converged && a.want_llr) {
@@ -398,27 +400,38 @@ __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__rest
     }
 }
 
+#ifndef QD_GEN_GS
 #define QD_GEN_GS 4           // wavefronts per 64 shots in the serial schedule (faults of one dependency level in parallel)
+#endif
 #define QD_GEN_G 8            // wavefronts per 64 shots in the flooding schedule
 
-template <int METHOD, int SCHED, int G>
-static hipError_t launch_k(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
+template <int METHOD, int SCHED, int G, int D>
+static hipError_t launch_kd(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
 {
-    hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G>), dim3((unsigned)((nshots + 63) / 64)), dim3(64 * G), 0, s, g, g.rp, g.ci,
+    hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D>), dim3((unsigned)((nshots + 63) / 64)), dim3(64 * G), 0, s, g, g.rp, g.ci,
                        g.cp, g.ri, g.c2r, g.llr0, g.lvl_ptr, g.lvl_bits, a, w, shot0, nshots);
     return hipGetLastError();
+}
+
+template <int METHOD, int SCHED, int G>
+static hipError_t launch_k(const GenGraphDev &g, int max_cdeg, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
+{
+    if (max_cdeg <= 4) return launch_kd<METHOD, SCHED, G, 4>(g, a, w, shot0, nshots, s);
+    if (max_cdeg <= 8) return launch_kd<METHOD, SCHED, G, 8>(g, a, w, shot0, nshots, s);
+    return launch_kd<METHOD, SCHED, G, QD_MAX_COL_DEG>(g, a, w, shot0, nshots, s);
 }
 
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
                                 int schedule, int64_t shot0, int nshots, hipStream_t s)
 {
     hipError_t e;
+    const int cd = bg.max_cdeg;
     if (bp_method == QD_BP_PRODUCT_SUM)
-        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, a, w, shot0, nshots, s);
+        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, cd, a, w, shot0, nshots, s)
+                                             : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, cd, a, w, shot0, nshots, s);
     else
-        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, a, w, shot0, nshots, s);
+        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, cd, a, w, shot0, nshots, s)
+                                             : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, cd, a, w, shot0, nshots, s);
     if (e != hipSuccess || !a.want_llr) return e;
     hipLaunchKernelGGL(qd_publish_llr_kernel, dim3((unsigned)((g.n + 63) / 64), (unsigned)((nshots + 63) / 64)), dim3(256), 0, s,
                        w.llr, w.slot, w.S, nshots, g.n, bg.n_pad, bg.bit_orig, a.llr_ws);

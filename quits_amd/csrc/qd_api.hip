@@ -635,6 +635,7 @@ static void free_ws(qd_decoder *d)
     if (d->gws.b2c) (void)hipFree(d->gws.b2c);
     if (d->gws.c2b) (void)hipFree(d->gws.c2b);
     if (d->gws.th) (void)hipFree(d->gws.th);
+    if (d->gws.pre) (void)hipFree(d->gws.pre);
     if (d->gws.llr) (void)hipFree(d->gws.llr);
     if (d->gws.syn) (void)hipFree(d->gws.syn);
     if (d->gws.slot) (void)hipFree(d->gws.slot);
@@ -711,8 +712,10 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
     }
     if (d->general) {
         // [index][shot] message planes for a chunk of S shots; a batch larger than S is decoded chunk by chunk
-        const bool ps = d->prm.bp_method == QD_BP_PRODUCT_SUM;
-        const size_t per_shot = ((size_t)g->nnz * (ps ? 3 : 2) + g->n) * sizeof(float) + g->m + sizeof(int32_t);
+        const bool ps = d->prm.bp_method == QD_BP_PRODUCT_SUM, serial = d->prm.schedule == QD_SCHEDULE_SERIAL;
+        // edge planes: flooding b2c + c2b (+ th for product-sum); serial: messages (th or b2c) + suffixes (the c2b plane), and a row plane
+        const int planes = serial ? 2 : (ps ? 3 : 2);
+        const size_t per_shot = ((size_t)g->nnz * planes + g->n + (serial ? g->m : 0)) * sizeof(float) + g->m + sizeof(int32_t);
         // Default budget 48 GB of the 288: the kernel is latency-bound (one wavefront per 64 shots), so a launch costs about
         // the same for 8 K or 64 K shots and chunks should be as large as memory allows -- and of equal size.
         double budget_gb = 48.0;
@@ -724,9 +727,10 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         S = std::max<int64_t>(256, (((max_batch + nchunks - 1) / nchunks) + 255) & ~(int64_t)255);
         GenWs &w = d->gws;
         w.S = S;
-        HIP_TRY(hipMalloc((void **)&w.b2c, sizeof(float) * (size_t)g->nnz * S));
+        if (!(ps && serial)) HIP_TRY(hipMalloc((void **)&w.b2c, sizeof(float) * (size_t)g->nnz * S));
         HIP_TRY(hipMalloc((void **)&w.c2b, sizeof(float) * (size_t)g->nnz * S));
         if (ps) HIP_TRY(hipMalloc((void **)&w.th, sizeof(float) * (size_t)g->nnz * S));
+        if (serial) HIP_TRY(hipMalloc((void **)&w.pre, sizeof(float) * (size_t)g->m * S));
         HIP_TRY(hipMalloc((void **)&w.llr, sizeof(float) * (size_t)g->n * S));
         HIP_TRY(hipMalloc((void **)&w.syn, (size_t)g->m * S));
         HIP_TRY(hipMalloc((void **)&w.slot, sizeof(int32_t) * (size_t)S));

@@ -57,7 +57,8 @@ struct GenGraphDev {
 };
 // ... and its per-chunk workspace, [index][shot] with S shots per row
 struct GenWs {
-    float *b2c, *c2b, *th, *llr;    // [nnz][S] x 3 (th: product-sum only), [n][S]
+    float *b2c, *c2b, *th, *llr;    // [nnz][S] x 3 (th: product-sum only; b2c: not for serial product-sum, which keeps tanh(b2c/2) alone), [n][S]
+    float *pre;                     // [m][S]  serial schedule: running prefix of each row (product / minimum + sign parity)
     uint8_t *syn;                   // [m][S]
     int32_t *slot;                  // [S]  fail-list slot of a shot BP could not finish, else -1
     int64_t S;
