@@ -29,7 +29,7 @@ class Params(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("qd_oracle.c", "bp_core.inc")]
+    srcs = [os.path.join(_HERE, f) for f in ("qd_oracle.c", "bp_core.inc", "oq_math.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so

@@ -30,7 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
-#include "qd_math.h"   /* quits_amd/csrc: the float tanh(x/2) and log((1+c)/(1-c)) shared with the HIP kernel (see its header) */
+#include "oq_math.h"   /* the oracle's own float tanh(x/2) and log((1+c)/(1-c)): same arithmetic as quits_amd/csrc/qd_math.h, no shared code */
 
 #define OQ_PRODUCT_SUM 0
 #define OQ_MINIMUM_SUM 1
@@ -85,10 +85,10 @@ double oq_max_abs_llr(int reset) { double v = g_max_abs_llr; if (reset) g_max_ab
 static double g_max_s = 0.0;
 #define OQ_TRACK_S(x) do { if ((double)(x) > g_max_s) g_max_s = (double)(x); } while (0)
 
-/* the shared float functions, exposed so that tests can compare them with libm in double */
+/* the oracle's float functions, exposed so that tests can compare them with libm in double and with the product's */
 void oq_math_f32(int kind, const float *x, float *y, int64_t count)
 {
-    for (int64_t i = 0; i < count; i++) y[i] = kind == 0 ? qd_tanh_half(x[i]) : qd_log_ratio(x[i]);
+    for (int64_t i = 0; i < count; i++) y[i] = kind == 0 ? oq_tanh_half_f32(x[i]) : oq_log_ratio_f32(x[i]);
 }
 
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -190,8 +190,8 @@ void oq_graph_destroy(oq_graph *g)
 #define OQ_SERIAL_PRESUF
 #define REAL_MAX FLT_MAX
 #define REAL_ABS fabsf
-#define REAL_TANH_HALF(x) qd_tanh_half(x)
-#define REAL_LOG_RATIO(c) qd_log_ratio(c)
+#define REAL_TANH_HALF(x) oq_tanh_half_f32(x)
+#define REAL_LOG_RATIO(c) oq_log_ratio_f32(c)
 #include "bp_core.inc"
 #undef REAL
 #undef SFX

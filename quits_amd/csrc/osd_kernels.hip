@@ -322,7 +322,7 @@ struct OsdRegArgs {
     int64_t det_stride, det_offset, upd_stride;
     const float *llr_ws;
     const int32_t *fail_list, *fail_count;
-    const int32_t *slot_list, *slot_count;      // when set: only these fail-list slots (the shots osd_wave.hip handed over)
+    const int32_t *slot_list, *slot_count;      // when set: only these fail-list slots (a subset handed over by an earlier pass)
     uint64_t *q_spill_fast;
     uint64_t *mt_ws;
     uint32_t *err_bits;
@@ -1761,8 +1761,6 @@ __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphD
     }
 }
 
-hipError_t qd_launch_osd0_wave(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &d, int blocks, hipStream_t s);
-int qd_osd_wave_lds_bytes(int m, int m_pad, int max_cdeg, int out_words);
 
 template <int TF, int RPT>
 static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s, bool handed_over)
@@ -1816,20 +1814,7 @@ hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const Deco
                           int blocks_full, hipStream_t s)
 {
     if (g.f_lds_bytes > 0) {
-        // OSD-0, opt-in (QD_OSD_WAVE=1): the one-wavefront-per-shot kernel of osd_wave.hip takes every shot first and hands over
-        // the ones that need more than the head of the column order or more than 128 pivots.  Same bits, measured SLOWER at
-        // the headline (wave kernel 8.3 ms + 21 % of the shots handed over 6.1 ms vs 10.0 ms for this kernel alone: a single
-        // wavefront pays ~1.5 us of dependent LDS round trips per column, and 33 KB of LDS per shot allow only five per CU),
-        // so it is off by default; tests/test_gpu_parity.py::test_osd_wave_path_bit_exact keeps it honest.
-        bool ho = false;
-        const int wlds = qd_osd_wave_lds_bytes(g.m, g.m_pad, g.max_cdeg, bg.out_words);
-        const bool wave_on = std::getenv("QD_OSD_WAVE") && std::atoi(std::getenv("QD_OSD_WAVE")) == 1;
-        if (a.osd_w == 0 && wlds > 0 && wlds <= QD_LDS_BYTES && a.hard_list && wave_on) {
-            const int per_cu = std::max(1, std::min(8, QD_LDS_BYTES / wlds));
-            hipError_t e = qd_launch_osd0_wave(g, bg, a, 256 * per_cu, s);
-            if (e != hipSuccess) return e;
-            ho = true;
-        }
+        const bool ho = false;
         const int rpt = (g.m + g.f_threads - 1) / g.f_threads;
         if (g.f_threads == 256) {
             switch (rpt) {

@@ -70,3 +70,45 @@ def same_sparse(a, b):
     a = csc_matrix(a); a.sort_indices()
     b = csc_matrix(b); b.sort_indices()
     return a.shape == b.shape and np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+
+
+# ---- the CPU oracle over several processes (the oracle is single-threaded C; the larger parity tests slice the shots) ----------
+def _oracle_procs():
+    return max(1, min(32, len(os.sched_getaffinity(0))))
+
+
+def _sw_worker(args):
+    import oracle as orc
+    wins, nz, det, prm, device_grid = args
+    return orc.sliding_window_decode(wins, nz, det, orc.make_params(*prm), device_grid=device_grid)
+
+
+def oracle_sliding_window_parallel(wins, nz, det, prm, device_grid=False):
+    """orc.sliding_window_decode over shot slices in a fork pool; prm = the argument tuple of orc.make_params.
+    Returns (predictions, summed stats)."""
+    import multiprocessing as mp
+    n = _oracle_procs()
+    parts = [p for p in np.array_split(np.ascontiguousarray(det), min(n, max(1, len(det) // 2))) if len(p)]
+    with mp.get_context("fork").Pool(min(n, len(parts))) as pool:
+        res = pool.map(_sw_worker, [(wins, nz, p, prm, device_grid) for p in parts])
+    stats = {k: sum(r[1][k] for r in res) for k in res[0][1]}
+    return np.concatenate([r[0] for r in res], axis=0), stats
+
+
+def _batch_worker(args):
+    import oracle as orc
+    H, pri, synd, prm, max_iter_grid = args
+    g = orc.Graph(H, pri)
+    if max_iter_grid is not None:
+        g.device_grid(max_iter_grid)
+    return g.decode_batch(synd, orc.make_params(*prm))
+
+
+def oracle_decode_batch_parallel(H, pri, synd, prm, device_grid_max_iter=None):
+    """Graph.decode_batch over shot slices in a fork pool (device_grid_max_iter: put the LLRs on the device's grid for that max_iter)."""
+    import multiprocessing as mp
+    n = _oracle_procs()
+    parts = [p for p in np.array_split(np.ascontiguousarray(synd), min(n * 4, max(1, len(synd) // 8))) if len(p)]
+    with mp.get_context("fork").Pool(min(n, len(parts))) as pool:
+        res = pool.map(_batch_worker, [(H, pri, p, prm, device_grid_max_iter) for p in parts])
+    return np.concatenate([r[0] for r in res], axis=0), np.concatenate([r[1] for r in res], axis=0)

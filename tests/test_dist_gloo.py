@@ -100,6 +100,21 @@ def test_bench_rank_plumbing_two_processes():
         assert nogpu.returncode != 0 and "needs a GPU" in (nogpu.stderr + nogpu.stdout)
 
 
+def test_p_sweep_two_processes_six_points():
+    """tools/p_sweep.py (BASELINE configs[3]) as it would be launched on N GPUs, on gloo: six p-points, the same shard of the
+    global shot range for every point, one (errors, shots) all-reduce and one elapsed-time MAX per point."""
+    import json
+    script = os.path.join(ROOT, "tools", "p_sweep.py")
+    out = _torchrun(2, [script, "--gpus", "2", "--shots", "1000001", "--dry-run-backend", "gloo"], 29651)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert [ln["p"] for ln in lines] == [0.001, 0.002, 0.003, 0.004, 0.005, 0.006]
+    for ip, ln in enumerate(lines):
+        assert ln["shots"] == 1000001 and ln["errors"] == 3 * (ip + 1) and ln["tmax"] == 2.0 and ln["n_gpus"] == 2
+    bad = _torchrun(2, [script, "--gpus", "8", "--dry-run-backend", "gloo"], 29653)
+    assert bad.returncode != 0 and "--gpus 8 but WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
 def test_master_port_comes_from_the_launcher():
     from quits_amd import parallel
     env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")

@@ -486,7 +486,7 @@ def test_config3_p_sweep_points_bit_exact(gpu, p, shots):
     assert (conv > 0.9) if p == 0.001 else (conv < 0.05), conv
 
 
-@pytest.mark.parametrize("osd,order,shots,max_iter", [("osd_0", 0, 32, 30), ("osd_cs", 1, 8, 30)])
+@pytest.mark.parametrize("osd,order,shots,max_iter", [("osd_0", 0, 128, 30), ("osd_cs", 1, 64, 30)])
 def test_config4_qlp_sliding_window_bit_exact(gpu, osd, order, shots, max_iter):
     """configs[4]: QLP [[1020,136]], cardinal circuit, R = 20, sliding window W = 3 F = 1 (20 windows of 1350 x 18900: 77-wide
     checks -> separate sign words, 22-word OSD rows, the 128-register BP instantiation), OSD-0 and OSD-CS order 1, at
@@ -506,15 +506,17 @@ def test_config4_qlp_sliding_window_bit_exact(gpu, osd, order, shots, max_iter):
     assert len(checks) == 20 and checks[1].shape == (1350, 18900)
     wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None, "row0": k * nz}
             for k in range(len(checks))]
-    prm = orc.make_params("minimum_sum", "parallel", max_iter, osd, order, 1.0, orc.FORM_LDPC_F64)
-    ref, stats = orc.sliding_window_decode(wins, nz, det, prm, device_grid=True)
+    ref, stats = helpers.oracle_sliding_window_parallel(wins, nz, det, ("minimum_sum", "parallel", max_iter, osd, order, 1.0, orc.FORM_LDPC_F64),
+                                                        device_grid=True)
     assert stats["osd_calls"] > shots, "OSD is not exercised"
     assert pred.shape == (shots, lz.shape[0]) and np.array_equal(pred, ref.astype(np.int64))
 
 
-def test_config4_qlp_sliding_window_bplsd_bit_exact(gpu):
+@pytest.mark.parametrize("method,order,shots", [("lsd_0", 0, 64), ("lsd_cs", 1, 32)])
+def test_config4_qlp_sliding_window_bplsd_bit_exact(gpu, method, order, shots):
     """configs[4]'s code and window plan through BP-LSD (sliding_window_bplsd_circuit_mem; 20 windows of 1350 x 18900: the LSD
-    kernel's 24-checks-per-lane instantiation, 77-wide rows = two ELL chunks per rescan) against the oracle's loop."""
+    kernel's 24-checks-per-lane instantiation, 77-wide rows = two ELL chunks per rescan), LSD-0 and the order the reference's
+    own BP-LSD calls use, against the oracle's loop."""
     from quits_amd.decoder import sliding_window_bplsd_circuit_mem
     from quits_amd.decoder.base import spacetime, window_count
     name, R = "qlp1020_cardinal_r20_p0.003", 20
@@ -522,18 +524,35 @@ def test_config4_qlp_sliding_window_bplsd_bit_exact(gpu):
     cd = helpers.code("qlp1020")
     hz, lz = cd["hz"], cd["lz"]
     nz = hz.shape[0]
-    shots = 12
     det, obs, _ = orc.sample_dem(H, L, pri, seed=45, shot0=0, B=shots)
-    pred = sliding_window_bplsd_circuit_mem(det, circ, hz, lz, 3, 1, max_iter=30, lsd_order=0, bp_method="minimum_sum",
-                                            schedule="parallel", lsd_method="lsd_0")
+    pred = sliding_window_bplsd_circuit_mem(det, circ, hz, lz, 3, 1, max_iter=30, lsd_order=order, bp_method="minimum_sum",
+                                            schedule="parallel", lsd_method=method)
     ncr, _, _ = window_count(R, 3, 1)
     checks, commits, priors, updates = spacetime(circ, hz, 3, 1, ncr)
     wins = [{"H": checks[k], "L": commits[k], "priors": priors[k], "U": updates[k] if k < ncr else None, "row0": k * nz}
             for k in range(len(checks))]
-    prm = orc.make_params("minimum_sum", "parallel", 30, "lsd_0", 0, 1.0, orc.FORM_LDPC_F64)
-    ref, stats = orc.sliding_window_decode(wins, nz, det, prm, device_grid=True)
+    ref, stats = helpers.oracle_sliding_window_parallel(wins, nz, det, ("minimum_sum", "parallel", 30, method, order, 1.0, orc.FORM_LDPC_F64),
+                                                        device_grid=True)
     assert stats["osd_calls"] > shots, "LSD is not exercised"
     assert np.array_equal(pred, ref.astype(np.int64))
+
+
+@pytest.mark.parametrize("osd,order", [("lsd_0", 0), ("lsd_cs", 1), ("osd_cs", 1), ("osd_e", 6)])
+def test_headline_window_2048_shots_other_postprocessors(gpu, osd, order):
+    """The post-processors other than OSD-0 (whose 200 000-shot golden lives in tests/golden/ler) at the headline window on
+    2048 shots: every correction, convergence flag and iteration count against the oracle (tools/scale_parity.py at 16 384)."""
+    from quits_amd.decoder.device import DemSampler
+    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    shots = 2048
+    det, obs = DemSampler(H, L, pri).sample(shots, seed=9)
+    synd = det.cpu().numpy()
+    err, st, dec = _gpu_decode(H, pri, synd, 50, osd=osd, order=order)
+    ref, flags = helpers.oracle_decode_batch_parallel(H, pri, synd, ("minimum_sum", "parallel", 50, osd, order, 1.0, orc.FORM_LDPC_F64),
+                                                      device_grid_max_iter=50)
+    assert np.array_equal((st >> 16) & 1, flags[:, 0]) and np.array_equal(st & 0x3FFF, flags[:, 1])
+    assert ((st >> 17) & 1).sum() > 400
+    bad = np.flatnonzero((err != ref).any(axis=1))
+    assert bad.size == 0, bad[:10]
 
 
 def test_all_detectors_circuit_decodes(gpu):
@@ -839,18 +858,3 @@ def test_osdw_row_form_and_column_form_agree(gpu, monkeypatch):
         for b in range(shots):
             ref, st = g.osd_w(synd[b], llr[b].astype(np.float64), "osd_cs", 3, fixed=True)
             assert np.array_equal(out[0][0][b], ref), (m, b, st)
-
-
-def test_osd_wave_path_bit_exact(gpu, monkeypatch):
-    """The opt-in one-wavefront-per-shot OSD-0 kernel (csrc/osd_wave.hip, QD_OSD_WAVE=1; shots it cannot finish go to the
-    workgroup-per-shot kernel): same corrections, pivot counts and flags as the default path and as the oracle."""
-    H, L, pri = helpers.dem_matrices("bb144_custom_r12_p0.003")
-    synd, _, _ = orc.sample_dem(H, L, pri, seed=77, shot0=0, B=600)
-    err0, st0, _ = _gpu_decode(H, pri, synd, 30, osd="osd_0")
-    monkeypatch.setenv("QD_OSD_WAVE", "1")
-    err1, st1, _ = _gpu_decode(H, pri, synd, 30, osd="osd_0")
-    assert np.array_equal(err0, err1) and np.array_equal(st0, st1)
-    g, prm = _oracle(H, pri, 30, "osd_0")
-    ref, flags = g.decode_batch(synd, prm)
-    assert np.array_equal(err1, ref) and np.array_equal((st1 >> 20) & 0xFFF, np.minimum(flags[:, 2], 4095))
-    assert ((st1 >> 17) & 1).sum() > 100

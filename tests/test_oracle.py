@@ -1,4 +1,6 @@
 """The CPU oracle (oracle/qd_oracle.c) against the reference's golden vectors and its own invariants."""
+import os
+
 import numpy as np
 import pytest
 from scipy.sparse import csc_matrix, csr_matrix
@@ -168,9 +170,36 @@ def test_oracle_plugin_surface():
         orc.OracleBpOsdDecoder(csc_matrix(H))
 
 
+def test_oracle_float_functions_equal_the_products_bit_for_bit(tmp_path):
+    """oracle/oq_math.h (the checker's own tanh(x/2) / log((1+c)/(1-c))) and quits_amd/csrc/qd_math.h (the product's, here
+    compiled for the host) share no code and must return the same bits: 400 000 inputs incl. every branch boundary."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "qd_math_host.c"
+    src.write_text('#include "qd_math.h"\n#include <stdint.h>\n'
+                   'void f(int kind, const float *x, float *y, int64_t n) { for (int64_t i = 0; i < n; i++) y[i] = kind == 0 ? qd_tanh_half(x[i]) : qd_log_ratio(x[i]); }\n')
+    so = tmp_path / "qd_math_host.so"
+    subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-std=c11",
+                           "-I", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quits_amd", "csrc"),
+                           "-o", str(so), str(src), "-lm"])
+    lib = ctypes.CDLL(str(so))
+    f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    lib.f.argtypes = [ctypes.c_int, f32p, f32p, ctypes.c_int64]
+    rng = np.random.default_rng(11)
+    edge = np.float32([0.0, -0.0, 0.5, -0.5, 0.49999997, 0.50000006, 40.0, 40.000004, 1e4, -1e4, 1e-30, 0.171875, 0.17187501, -0.171875,
+                       0.99999994, -0.99999994, 1.4142135, np.inf, -np.inf])
+    x = np.concatenate([rng.uniform(-45, 45, 150000), rng.uniform(-1, 1, 150000), rng.normal(0, 1e-3, 50000),
+                        rng.uniform(-1, 1, 50000) * 10.0 ** rng.uniform(-30, 0, 50000), edge]).astype(np.float32)
+    for kind, name in ((0, "tanh_half"), (1, "log_ratio")):
+        xs = x if kind == 0 else np.clip(x, -0.99999994, 0.99999994).astype(np.float32)
+        y = np.empty_like(xs)
+        lib.f(kind, xs, y, xs.size)
+        assert np.array_equal(y.view(np.uint32), orc.math_f32(name, xs).view(np.uint32)), name
+
+
 def test_float_elementary_functions_against_libm():
-    """tanh(x/2) and log((1+c)/(1-c)) as the float product-sum forms evaluate them (quits_amd/csrc/qd_math.h, shared by
-    the HIP kernel and the oracle's float form) against libm in double: a few ulp, monotone clamp at +-(1 - 2^-24)."""
+    """tanh(x/2) and log((1+c)/(1-c)) as the float product-sum forms evaluate them (the oracle's oq_math.h; bit-identical to
+    the product's qd_math.h by the test above) against libm in double: a few ulp, monotone clamp at +-(1 - 2^-24)."""
     rng = np.random.default_rng(7)
     x = np.concatenate([rng.uniform(-40, 40, 100000), rng.uniform(-1, 1, 100000), rng.normal(0, 1e-3, 20000),
                         [0.0, -0.0, 0.5, -0.5, 0.49999997, 17.0, 19.0, 35.0, 50.0, 1e4, 1e-30]]).astype(np.float32)

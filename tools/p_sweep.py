@@ -22,11 +22,26 @@ def main():
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--points", type=float, nargs="*", default=[0.001, 0.002, 0.003, 0.004, 0.005, 0.006])
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--dry-run-backend", default=None, help=argparse.SUPPRESS)   # tests: the per-point sharding + collectives on CPU (gloo), no decoding
     args = ap.parse_args()
     from quits_amd import parallel
     rank, world, local_rank = parallel.env_rank_world()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if args.dry_run_backend:
+        # the N > 1 path without a GPU: join the group, then per point the barrier, the (errors, shots) SUM and the elapsed-time MAX
+        dist = parallel.init_distributed(args.dry_run_backend)
+        lo, hi = parallel.shard_range(args.shots, rank, world)
+        for ip, p in enumerate(args.points):
+            if dist is not None:
+                dist.barrier()
+            n_err, n_shots = parallel.reduce_counts(dist, (rank + 1) * (ip + 1), hi - lo)
+            tmax = parallel.reduce_max(dist, float(rank + 1))
+            if rank == 0:
+                print(json.dumps({"dry_run": True, "p": p, "n_gpus": world, "errors": n_err, "shots": n_shots, "tmax": tmax}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("p_sweep.py needs a GPU; the decoder has no CPU fallback")
     torch.cuda.set_device(local_rank)
