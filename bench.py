@@ -282,12 +282,25 @@ def main():
 
     if general:
         achieved = (algo_bytes / bp_s / 1e9) if bp_s > 0 else 0.0
+        # what the kernel itself moves per shot-iteration (csrc/bp_general.hip), in units of E edges, n faults, m detectors:
+        #   serial:   suffix pass 8E (+4m), level pass 9E in + 8E out + 4n, convergence test 4E + m
+        #   flooding: check pass 20E (min-sum) / 24E (product-sum: tanh plane), bit pass 8E + 4n, convergence test 4E + m
+        ps = args.bp_method == "product_sum"
+        def k_iter(rec):
+            E_, n_, m_ = rec["nnz"], rec["n"], rec["m"]
+            return (29 * E_ + 4 * n_ + 5 * m_) if args.schedule == "serial" else ((36 if ps else 32) * E_ + 4 * n_ + m_)
+        kern_bytes = sum(int((s_t & 0x3FFF).to(torch.int64).sum().item()) * k_iter(per_dec[id(plan.windows[k]["dec"])]) for (k, s_t) in stats)
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": traffic, "kernel": "qd_bp_edge_kernel", "avg_launch_ms": prof["bp_ms"] / nlaunch,
                     "algorithmic_bytes_per_launch": algo_bytes / nlaunch,
+                    "kernel_model": {"bytes_per_launch": kern_bytes / nlaunch, "GBps": kern_bytes / bp_s / 1e9 if bp_s > 0 else 0.0,
+                                     "frac": kern_bytes / bp_s / 1e9 / HBM_PEAK_GBS if bp_s > 0 else 0.0,
+                                     "note": "bytes the kernel's own loads and stores add up to per shot-iteration (29E+4n+5m serial, "
+                                             "32E/36E+4n+m flooding), cache hits included: an upper bound on its HBM traffic"},
                     "note": "one message per edge in HBM: algorithmic bytes = sum over shots of BP iterations x (4E+2n)*4 B (SURVEY.md "
-                            "8d); the kernel really moves a multiple of this (ldpc's forward/backward sweeps; the serial schedule "
-                            "re-reads a row per edge), see DESIGN.md"}
+                            "8d).  The serial schedule keeps a running prefix per row and a suffix per edge (one load of each per "
+                            "edge instead of bp.hpp's row rescan); it is bound by the latency of one dependency level (a few faults "
+                            "per level, one barrier each), not by bandwidth, see DESIGN.md"}
     else:
         # The LDS kernel's messages never leave the CU, so HBM cannot bound it ("report ... LDS bytes as the bound").
         # What bounds it is vector-ALU issue: wave-instructions per edge from the compiler's assembly

@@ -1708,7 +1708,8 @@ __global__ void __launch_bounds__(T, WPS) qd_osdw_col_kernel(OsdRegArgs a)
         }
         __syncthreads();
         QD_TICK(2)
-        if (NWD <= 16) qd_osd_sweep_t<T, 16, true>(a, smem, llr, nullptr, mt, npiv, nnp);
+        if (NWD <= 8) qd_osd_sweep_t<T, 8, true>(a, smem, llr, nullptr, mt, npiv, nnp);
+        else if (NWD <= 16) qd_osd_sweep_t<T, 16, true>(a, smem, llr, nullptr, mt, npiv, nnp);
         else qd_osd_sweep_t<T, 32, true>(a, smem, llr, nullptr, mt, npiv, nnp);
         for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = S.outw[w];
         if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
@@ -1762,19 +1763,31 @@ __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphD
 }
 
 
+#ifndef QD_COLK2_T
+#define QD_COLK2_T 512        // threads / wavefronts-per-SIMD budget of the m <= 1024 instantiation (1024 columns in all)
+#define QD_COLK2_WPS 4
+#endif
+#ifndef QD_COLK1_T
+#define QD_COLK1_T 256        // threads of the small-window instantiation of the column kernel (512 columns in all): a shot of a
+                              // 360-check window is ~1700 barriers, so fewer wavefronts per barrier and six shots per CU beat 512 threads and
+                              // three (W=5 F=3 windows of the [[144,12,12]] code, OSD-CS(1): 42.8 -> 25.5 ms per launch)
+#endif
 template <int TF, int RPT>
 static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s, bool handed_over)
 {
     const bool wl = a.osd_w != 0;                              // higher-order OSD uses the one-workgroup-per-CU layout
     auto k = wl ? qd_osd0_reg_kernel<TF, RPT, true> : qd_osd0_reg_kernel<TF, RPT, false>;
-    // higher-order OSD: elimination by column (qd_osdw_col_kernel) when the host laid it out (c_* layout)
+    // higher-order OSD: elimination by column (qd_osdw_col_kernel, always 512 threads) when the host laid it out (c_* layout).
+    // c_cpt names the instantiation: 1 = one column of 8 words per thread (m <= 512: the sliding windows the reference really
+    // runs, W = 3..5 rounds of a [[144,12,12]] or smaller code), 2 = two of 16 (m <= 1024), 3 = three of 22 (m <= 1408)
     int colk = 0;
-    if constexpr (TF == 512) {
+    {
         const bool row_form = std::getenv("QD_OSDW_ROWS") && std::atoi(std::getenv("QD_OSDW_ROWS")) == 1;   // the round-1 kernel, for A/B runs
         if (wl && a.mt_ws && !row_form && g.c_lds_bytes > 0) colk = g.c_cpt;
     }
     const int lds = colk ? g.c_lds_bytes : wl ? g.w_lds_bytes : g.f_lds_bytes;
-    hipError_t e = hipFuncSetAttribute(colk == 2 ? (const void *)qd_osdw_col_kernel<512, 2, 16, 4> : colk == 3 ? (const void *)qd_osdw_col_kernel<512, 3, 22, 2> : (const void *)k,
+    hipError_t e = hipFuncSetAttribute(colk == 1 ? (const void *)qd_osdw_col_kernel<QD_COLK1_T, 512 / QD_COLK1_T, 8, 6> : colk == 2 ? (const void *)qd_osdw_col_kernel<QD_COLK2_T, 1024 / QD_COLK2_T, 16, QD_COLK2_WPS>
+                                       : colk == 3 ? (const void *)qd_osdw_col_kernel<512, 3, 22, 2> : (const void *)k,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     OsdRegArgs r{};
@@ -1793,7 +1806,8 @@ static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const D
         for (int i = 0; i < 10; ++i) r.off[i] = g.c_off[i];
         r.off_sort = g.c_off_sort; r.off_order = g.c_off_order; r.off_pivmask = g.c_off_pivmask; r.off_npl = g.c_off_npl;
     }
-    if (colk == 2) hipLaunchKernelGGL((qd_osdw_col_kernel<512, 2, 16, 4>), dim3((unsigned)blocks), dim3(512), lds, s, r);
+    if (colk == 1) hipLaunchKernelGGL((qd_osdw_col_kernel<QD_COLK1_T, 512 / QD_COLK1_T, 8, 6>), dim3((unsigned)blocks), dim3(QD_COLK1_T), lds, s, r);
+    else if (colk == 2) hipLaunchKernelGGL((qd_osdw_col_kernel<QD_COLK2_T, 1024 / QD_COLK2_T, 16, QD_COLK2_WPS>), dim3((unsigned)blocks), dim3(QD_COLK2_T), lds, s, r);
     else if (colk == 3) hipLaunchKernelGGL((qd_osdw_col_kernel<512, 3, 22, 2>), dim3((unsigned)blocks), dim3(512), lds, s, r);
     else hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TF), lds, s, r);
     return hipGetLastError();

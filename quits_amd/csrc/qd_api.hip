@@ -470,8 +470,9 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         // workgroups per CU by registers) or 3 of 22 (m <= 1408, one per CU); the Q region holds 64 pending columns, one word
         // per pivot and a few vectors
         od.c_lds_bytes = 0; od.c_cpt = 0; od.c_per_cu = 0;
-        if (od.w_lds_bytes > 0 && od.f_threads == 512 && m <= 1408) {
-            const int cpt = m <= 1024 ? 2 : 3, nwd = m <= 1024 ? 16 : 22;
+        if (od.w_lds_bytes > 0 && m <= 1408) {
+            const int var = m <= 512 ? 1 : (m <= 1024 ? 2 : 3);            // instantiation (osd_kernels.hip, launch_reg)
+            const int cpt = var, nwd = var == 1 ? 8 : (var == 2 ? 16 : 22);
             const int need = (64 * nwd + 512 * cpt + 2 * nwd) * 8 + 512;
             int o = carve(od.c_off, need, 0);
             od.c_off_sort = o; o += sort_b;
@@ -479,8 +480,8 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             od.c_off_pivmask = o; o += align16(bp.out_words * 4);
             od.c_off_npl = o; o += 256;
             if (o <= QD_LDS_BYTES) {
-                od.c_lds_bytes = o; od.c_cpt = cpt;
-                od.c_per_cu = std::max(1, std::min(cpt == 2 ? 2 : 1, QD_LDS_BYTES / o));
+                od.c_lds_bytes = o; od.c_cpt = var;
+                od.c_per_cu = std::max(1, std::min(var == 1 ? (std::getenv("QD_COLK1_PER_CU") ? std::atoi(std::getenv("QD_COLK1_PER_CU")) : 6) : (var == 2 ? (std::getenv("QD_COLK2_PER_CU") ? std::atoi(std::getenv("QD_COLK2_PER_CU")) : 2) : 1), QD_LDS_BYTES / o));   // the instantiations' register budgets
             }
         }
     }
