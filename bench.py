@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--bp-method", default="minimum_sum", choices=["minimum_sum", "product_sum"])
     ap.add_argument("--schedule", default="parallel", choices=["parallel", "serial"],
                     help="anything but minimum_sum + parallel runs in the one-message-per-edge kernel (bp_general.hip)")
-    ap.add_argument("--osd-method", default="osd_0", choices=["osd_0", "osd_cs", "osd_e", "osd_off", "lsd_0"], help="lsd_0: BP-LSD (lsd_order 0) instead of BP-OSD")
+    ap.add_argument("--osd-method", default="osd_0", choices=["osd_0", "osd_cs", "osd_e", "osd_off", "lsd_0", "lsd_cs", "lsd_e"],
+                    help="lsd_*: BP-LSD instead of BP-OSD (--osd-order carries lsd_order)")
     ap.add_argument("--osd-order", type=int, default=0)
     ap.add_argument("--p-override", type=float, default=None, help="physical error rate for the non-headline codes")
     ap.add_argument("--code", default="bb144", choices=["bb144", "bb72", "hgp225", "qlp1020"],

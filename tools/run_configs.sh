@@ -17,8 +17,12 @@ $B --code qlp1020 --window 3 1 --shots 4096 --steps 1 --p-override 0.001 --osd-m
 $B --code qlp1020 --window 3 1 --shots 4096 --steps 1 --p-override 0.001 --osd-method lsd_0 --no-cpu 2>/dev/null                       # configs[4] code with BP-LSD
 $B --osd-method osd_cs --osd-order 1 --shots 32768 --cpu-shots 100 2>/dev/null                                            # headline code with OSD-CS(1)
 $B --osd-method lsd_0 --cpu-shots 300 2>/dev/null                                                                         # headline code with BP-LSD (LSD-0)
+$B --osd-method lsd_cs --osd-order 1 --cpu-shots 300 2>/dev/null                                                          # ... and with lsd_order 1, what the reference's own BP-LSD calls pass
 # the general (one message per edge) BP kernel at the headline code: the reference wrapper's other bp_method / schedule options
 $B --bp-method product_sum --schedule serial --max-iter 10 --cpu-shots 100 2>/dev/null
 $B --bp-method product_sum --schedule parallel --cpu-shots 100 2>/dev/null
 $B --bp-method minimum_sum --schedule serial --max-iter 10 --cpu-shots 100 2>/dev/null
 $B --bp-method product_sum --schedule serial --max-iter 10 --osd-method osd_cs --osd-order 1 --shots 16384 --cpu-shots 30 2>/dev/null   # the docs' decoder settings
+$B --bp-method product_sum --schedule serial --max-iter 10 --osd-method osd_cs --osd-order 1 --window 5 3 --cpu-shots 100 2>/dev/null  # ... on the docs' windows (W=5 F=3)
+$B --bp-method product_sum --schedule serial --max-iter 10 --osd-method osd_cs --osd-order 1 --window 3 1 --cpu-shots 100 2>/dev/null
+$B --bp-method product_sum --schedule serial --max-iter 10 --osd-method lsd_cs --osd-order 1 --window 5 3 --no-cpu 2>/dev/null
