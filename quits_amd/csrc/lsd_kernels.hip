@@ -46,6 +46,8 @@ struct LsdArgs {
     const uint32_t *wfix;          // [n] integer candidate costs round(log(1/p) * 2^18) (as for OSD-CS / OSD-E)
     const uint32_t *slot_of;       // [n] fault -> its posterior column in llr_ws
     uint16_t *npl_ws;              // [blocks][npl_cap] the added faults that did not become pivot columns, in order of addition
+    uint16_t *nown_ws;             // [blocks][npl_cap] ... the cluster each belongs to at sweep time
+    uint32_t *nkey_ws;             // [blocks][npl_cap] ... and its sort key (monotone image of the posterior LLR)
     int npl_cap;
     uint32_t *tv_ws;               // [blocks][QL_TV_WORDS] images of the first 64 sorted non-pivot faults of the cluster at hand
                                    //                       ([i][lane] = bit k: row base + k), then their fault indices
@@ -131,6 +133,8 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
     const int nfail = *a.fail_count;
     uint64_t *Q = a.q_ws + (size_t)blockIdx.x * (size_t)a.mw * MP;            // planes >= 2 (rare): HBM, per resident slot
     uint16_t *npl = a.npl_ws + (size_t)blockIdx.x * a.npl_cap;
+    uint16_t *nown = a.nown_ws + (size_t)blockIdx.x * a.npl_cap;
+    uint32_t *nkey = a.nkey_ws + (size_t)blockIdx.x * a.npl_cap;
     uint32_t *tv = a.tv_ws + (size_t)blockIdx.x * QL_TV_WORDS;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     BlkU16 &own_blk = *reinterpret_cast<BlkU16 *>(owner + base);
@@ -488,6 +492,13 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                 }
                 return tb;
             };
+            // owner and sort key of every candidate position, once per shot (ownership is final here)
+            for (int x = lane; x < nnp; x += 64) {
+                const uint32_t jj = npl[x];
+                nown[x] = owner[a.ri[a.cp[jj]]];                               // all checks of an added fault are in its cluster
+                nkey[x] = ql_mono_key(llr[a.slot_of[jj]]);
+            }
+            __syncthreads();
             int sc = -1;
             for (;;) {
                 const BlkU8 cs = *reinterpret_cast<const BlkU8 *>(cstate + base);
@@ -497,14 +508,8 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                 cm = qd_wave_umin(cm);
                 if (cm == 0xFFFFFFFFu) break;
                 sc = (int)cm;
-                // the cluster's candidate positions
                 int kk = 0;
-                for (int i0 = 0; i0 < nnp; i0 += 64) {
-                    const int i = i0 + lane;
-                    bool mem = false;
-                    if (i < nnp) mem = owner[a.ri[a.cp[npl[i]]]] == (uint16_t)sc;     // all checks of an added fault are in its cluster
-                    kk += __popcll(__ballot(mem));
-                }
+                for (int i0 = 0; i0 < nnp; i0 += 64) kk += __popcll(__ballot(i0 + lane < nnp && nown[i0 + lane] == (uint16_t)sc));
                 if (kk == 0) continue;
                 const BlkU16 own = own_blk;
                 BlkU8 fl = fl_blk;
@@ -528,43 +533,55 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                 };
                 const int wmax = a.lsd_w == 1 ? QL_TV_MAX : 15;
                 const int w = min(min(a.order, kk), wmax);
-                const int nsingle = a.lsd_w == 1 ? kk : w;
+                // best so far: (cost change, class, key) -- class -1 = the LSD-0 solution (cost change 0), 0 = one position, 1 = a pair /
+                // pattern.  The oracle walks OSD-0, the single positions in sorted order, then the pairs, keeping the first strict
+                // minimum: among single positions that is the lexicographic minimum of (cost change, sort key), so they can be
+                // taken in list order; only the first w positions -- the ones pairs and patterns are built from -- have to be found in order.
                 long long best = 0;
+                int bcls = -1;
+                unsigned long long bkey = 0ull;
                 uint32_t btb = 0;
                 int bja = -1, bjb = -1;
                 unsigned bpat = 0;
+                const int nsorted = (a.lsd_w == 2 || w >= 2) ? w : 0;
                 unsigned long long lastkey = 0ull;
-                for (int i = 0; i < nsingle; ++i) {
+                for (int i = 0; i < nsorted; ++i) {
                     unsigned long long kmin = QL_NOKEY64;
                     for (int i0 = 0; i0 < nnp; i0 += 64) {
                         const int x = i0 + lane;
-                        if (x < nnp) {
-                            const uint32_t jj = npl[x];
-                            if (owner[a.ri[a.cp[jj]]] == (uint16_t)sc) {
-                                const unsigned long long key = ((unsigned long long)ql_mono_key(llr[a.slot_of[jj]]) << 16) | jj;
-                                if ((i == 0 || key > lastkey) && key < kmin) kmin = key;
-                            }
+                        if (x < nnp && nown[x] == (uint16_t)sc) {
+                            const unsigned long long key = ((unsigned long long)nkey[x] << 16) | npl[x];
+                            if ((i == 0 || key > lastkey) && key < kmin) kmin = key;
                         }
                     }
                     const uint32_t hi = (uint32_t)(kmin >> 16), mh = qd_wave_umin(hi);
                     const uint32_t ml = qd_wave_umin((hi == mh && kmin != QL_NOKEY64) ? (uint32_t)(kmin & 0xFFFFu) : 0xFFFFu);
                     lastkey = ((unsigned long long)mh << 16) | ml;
-                    const int j = (int)ml;
-                    const uint32_t tb = image(j) & memb;
-                    if (i < w) { tv[i * 64 + lane] = tb; if (lane == 0) tv[QL_TV_MAX * 64 + i] = (uint32_t)j; }
-                    if (a.lsd_w == 1) {
-                        const long long d = delta_of(tb) + (long long)a.wfix[j];
-                        if (d < best) { best = d; btb = tb; bja = j; bjb = -1; }
-                    }
+                    const uint32_t tb = image((int)ml) & memb;
+                    tv[i * 64 + lane] = tb;
+                    if (lane == 0) tv[QL_TV_MAX * 64 + i] = ml;
                 }
                 __syncthreads();
                 if (a.lsd_w == 1) {
-                    for (int x = 0; x < w; ++x)
-                        for (int y = x + 1; y < w; ++y) {
+                    for (int i0 = 0; i0 < nnp; i0 += 64) {
+                        const int x = i0 + lane;
+                        const bool mem = x < nnp && nown[x] == (uint16_t)sc;
+                        const uint32_t myj = mem ? (uint32_t)npl[x] : 0u, myk = mem ? nkey[x] : 0u;
+                        for (unsigned long long bm = __ballot(mem); bm; bm &= bm - 1ull) {
+                            const int src = (int)__builtin_ctzll(bm);
+                            const int j = __builtin_amdgcn_readlane((int)myj, src);
+                            const unsigned long long key = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)myk, src) << 16) | (uint32_t)j;
+                            const uint32_t tb = image(j) & memb;
+                            const long long d = delta_of(tb) + (long long)a.wfix[j];
+                            if (d < best || (d == best && bcls == 0 && key < bkey)) { best = d; bcls = 0; bkey = key; btb = tb; bja = j; bjb = -1; }
+                        }
+                    }
+                    for (int x = 0; x < nsorted; ++x)
+                        for (int y = x + 1; y < nsorted; ++y) {
                             const uint32_t tb = tv[x * 64 + lane] ^ tv[y * 64 + lane];
                             const int ja = (int)tv[QL_TV_MAX * 64 + x], jb = (int)tv[QL_TV_MAX * 64 + y];
                             const long long d = delta_of(tb) + (long long)a.wfix[ja] + (long long)a.wfix[jb];
-                            if (d < best) { best = d; btb = tb; bja = ja; bjb = jb; }
+                            if (d < best) { best = d; bcls = 1; btb = tb; bja = ja; bjb = jb; }
                         }
                 } else {
                     for (unsigned pat = 1; pat < (1u << w); ++pat) {
@@ -573,7 +590,7 @@ __global__ void __launch_bounds__(64) qd_lsd0_kernel(LsdArgs a)
                         for (int b = 0; b < w; ++b)
                             if ((pat >> b) & 1u) { tb ^= tv[b * 64 + lane]; ws += (long long)a.wfix[tv[QL_TV_MAX * 64 + b]]; }
                         const long long d = delta_of(tb) + ws;
-                        if (d < best) { best = d; btb = tb; bpat = pat; }
+                        if (d < best) { best = d; bcls = 1; btb = tb; bpat = pat; }
                     }
                 }
                 if (best < 0) {
@@ -649,7 +666,8 @@ size_t qd_lsd_ws_bytes(int m, int n, int blocks, int lsd_w)
 {
     const size_t rows = (size_t)qd_lsd_plane_rows(m);
     size_t b = sizeof(uint64_t) * ((size_t)blocks * ((m + 63) / 64) * rows + 32 + ((size_t)blocks * rows + 3) / 4);
-    if (lsd_w) b += ((size_t)blocks * ((n + 3) & ~3) * sizeof(uint16_t) + 15) / 16 * 16 + (size_t)blocks * QL_TV_WORDS * sizeof(uint32_t) + 64;
+    if (lsd_w) b += ((size_t)blocks * ((n + 3) & ~3) * sizeof(uint16_t) + 15) / 16 * 16 * 2 + (size_t)blocks * ((n + 3) & ~3) * sizeof(uint32_t)
+                    + (size_t)blocks * QL_TV_WORDS * sizeof(uint32_t) + 64;
     return b;
 }
 
@@ -673,8 +691,11 @@ hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const Dec
     a.npl_cap = (gg.n + 3) & ~3;
     {
         unsigned char *tail = reinterpret_cast<unsigned char *>(q_ws + (size_t)blocks_alloc * a.mw * 64 * nr + 32 + ((size_t)blocks_alloc * 64 * nr + 3) / 4);
+        const size_t l16 = ((size_t)blocks_alloc * a.npl_cap * sizeof(uint16_t) + 15) / 16 * 16;
         a.npl_ws = reinterpret_cast<uint16_t *>(tail);
-        a.tv_ws = reinterpret_cast<uint32_t *>(tail + ((size_t)blocks_alloc * a.npl_cap * sizeof(uint16_t) + 15) / 16 * 16);
+        a.nown_ws = reinterpret_cast<uint16_t *>(tail + l16);
+        a.nkey_ws = reinterpret_cast<uint32_t *>(tail + 2 * l16);
+        a.tv_ws = reinterpret_cast<uint32_t *>(tail + 2 * l16 + (size_t)blocks_alloc * a.npl_cap * sizeof(uint32_t));
     }
 #ifdef QD_LSD_TIMING
     hipError_t e = hipMemsetAsync(a.next_slot, 0, sizeof(uint64_t) * 17, s);

@@ -615,6 +615,33 @@ def test_ler_agreement_with_double_precision_oracle_2e5_shots(gpu):
     assert abs(b - c) <= np.sqrt(b + c), (b, c)
 
 
+def test_ler_agreement_product_sum_serial_osdcs_1e5_shots(gpu):
+    """The reference wrapper's own settings (bposd.py:54 defaults + the notebooks' max_iter = 10, osd_order = 1: product_sum,
+    serial, osd_cs) at the headline window: the device's float path against ldpc's arithmetic (oracle: double, libm, bp.hpp's
+    update order; tests/golden/ler/bb144_ps_serial_osdcs1_seed1_part*.npz, made by tools/ler_productsum.py) on the same
+    100 000 Philox shots -- paired: McNemar on the discordant shots, and the failure counts within 1.5 sigma."""
+    import glob
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(helpers.GOLD.rstrip("/")), "..", "tools"))
+    import ler_productsum as lp
+    paths = sorted(glob.glob(os.path.join(helpers.GOLD, "ler", "bb144_ps_serial_osdcs1_seed1_part*.npz")))[:2]
+    assert len(paths) == 2
+    fd, fr = [], []
+    for path in paths:
+        z = np.load(path)
+        meta = json.loads(bytes(z["meta"]).decode())
+        obs, pred, conv = lp.device_predictions(meta["seed"], meta["shot0"], meta["shots"])
+        assert np.array_equal(obs, z["obs"]), "device sampler and oracle sampler disagree"
+        fd.append(pred != obs)
+        fr.append(z["pred"] != z["obs"])
+        assert (pred == z["pred"]).mean() > 0.97            # float vs double: the same prediction on all but a few per cent of the shots
+    r = lp.paired(np.concatenate(fd), np.concatenate(fr))
+    assert r["shots"] == 100000
+    assert abs(r["mcnemar_z"]) <= 3.0 and abs(r["delta_in_sigma"]) <= 1.5, r
+
+
 # ---- BP-LSD (quits/decoder/bplsd.py; csrc/lsd_kernels.hip) -------------------------------------------------------------------
 @pytest.mark.parametrize("name,shots,max_iter", [
     ("bb72_custom_r6_p0.003", 1500, 8),
