@@ -270,7 +270,7 @@ def main():
 
     # HBM bytes per BP launch from the PMC passes of tools/profile_bench.sh (rocprofv3 cannot run inside this process);
     # only quoted when the committed profile was taken on this exact workload.
-    traffic, traffic_src = None, None
+    traffic, traffic_src, sq_counters = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path):
         try:
@@ -278,6 +278,7 @@ def main():
             key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
             if key in pm and not general and args.code == "bb144":
                 traffic, traffic_src = pm[key]["bp_bytes_per_launch"], pm[key]["source"]
+                sq_counters = pm[key].get("sq_counters")
         except (ValueError, KeyError):
             pass
 
@@ -334,6 +335,8 @@ def main():
             # the same instructions priced by class: two-operand add/sub/logic/shift/fma issue in 2 clk per wavefront per SIMD,
             # compares / cndmask / min / max / med3 / three-operand logic / 64-bit shifts in 4 (profiles/r01f_valu_issue_rates.txt)
             "frac_priced_by_class": issue_clk / (bp_s * NUM_CU * 4 * CLOCK_HZ) if bp_s > 0 else 0.0,
+            # the same fraction from the hardware counters of the committed PMC pass (all VALU instructions, overhead included)
+            "frac_from_sq_counters": (sq_counters or {}).get("frac_of_2_per_cu_clk"), "sq_counters": sq_counters,
             "lds": {"achieved": lds_bytes / bp_s / 1e9 if bp_s > 0 else 0.0, "peak": NUM_CU * 256 * CLOCK_HZ / 1e9, "unit": "GB/s",
                     "frac_of_conflict_free_cycles": lds_clk / (bp_s * NUM_CU * CLOCK_HZ) if bp_s > 0 else 0.0,
                     "note": "gathers only (4 B per check-pass edge, 16 B per bit-pass edge); LDS-array cycles at the conflict-free "
