@@ -62,7 +62,8 @@ def run(trials=200, seed=1):
             synd[rng.integers(0, B)] = 0
         method, sched, edge = configs[int(rng.integers(0, len(configs)))]
         osd, order = [("osd_0", 0), ("osd_off", 0), ("osd_cs", int(rng.integers(0, 6))), ("osd_e", int(rng.integers(0, 5))), ("osd_0", 0),
-                      ("lsd_0", 0), ("osd_cs", int(rng.integers(1, 12)))][int(rng.integers(0, 7))]
+                      ("lsd_0", 0), ("osd_cs", int(rng.integers(1, 12))), ("lsd_cs", int(rng.integers(1, 9))), ("lsd_e", int(rng.integers(1, 7))),
+                      ("lsd_cs", 1)][int(rng.integers(0, 10))]
         max_iter = int(rng.integers(1, 25)) if sched == "parallel" else int(rng.integers(1, 6))
         alpha = float(rng.choice([1.0, 1.0, 0.0, 0.625]))
         try:
@@ -97,7 +98,7 @@ def run(trials=200, seed=1):
         assert np.array_equal(err[exact], ref[exact]), ("decisions", tag, np.nonzero((err != ref).any(axis=1) & exact)[0][:5])
         if osd != "osd_off":
             assert np.array_equal(((st >> 17) & 1)[exact], (1 - flags[:, 0])[exact]), ("osd flag", tag)
-            if osd in ("osd_0", "lsd_0") or order == 0:
+            if osd in ("osd_0", "lsd_0", "lsd_cs", "lsd_e") or order == 0:
                 used = (((st >> 17) & 1) == 1) & exact
                 assert np.array_equal(((st >> 20) & 0xFFF)[used], np.minimum(flags[used, 2], 4095)), ("pivots", tag)
                 assert np.array_equal(((st >> 18) & 1)[used], (flags[used, 3] != 0).astype(int)), ("inconsistent", tag)
