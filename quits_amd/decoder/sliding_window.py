@@ -22,6 +22,8 @@ from scipy.sparse import csc_matrix, csr_matrix
 from .base import spacetime, window_count
 
 _CHUNK = 1 << 16   # shots per device batch
+_CHUNK_EDGE = 5 << 14   # ... when BP runs in the one-message-per-edge kernel: five 64-shot workgroups per CU are resident on 256 CUs and the kernel's
+                        # time is per-workgroup latency (81 920 vs 65 536 shots per launch: +8 % shots/s, 98 304 -18 %; profiles/r03o)
 
 
 def _progress(it, on):
@@ -105,6 +107,7 @@ class DeviceWindowPlan:
         # the per-edge BP kernel (product_sum / serial) keeps its messages in HBM, one workspace per decoder: split a fixed
         # budget among the windows' decoders instead of letting each claim the single-decoder default
         decs = self.decoders()
+        self.chunk = _CHUNK_EDGE if any(d.info()["edge_kernel"] for d in decs) else _CHUNK
         if len(decs) > 1:
             import os
             budget = float(os.environ.get("QD_GENERAL_WS_GB", "96")) * (1 << 30)
@@ -125,7 +128,7 @@ class DeviceWindowPlan:
     def decode(self, det, stats=None):
         """det: cuda uint8 [N, ndet]  ->  cuda uint8 [N, nobs] logical predictions.
 
-        Windows outer, shots inner, in chunks of `_CHUNK` shots; everything stays on the caller's stream.  `stats`, if
+        Windows outer, shots inner, in chunks of `self.chunk` shots; everything stays on the caller's stream.  `stats`, if
         given, receives (window index, status tensor) pairs.  (Overlapping the OSD of one sub-batch with the BP of the
         next on a second stream -- qd_decode_stage exists for that -- was measured again in round 2 (tools/overlap_probe.py,
         two decoders = two workspaces): 70.6 -> 68.0 ms per 65 536 headline shots, 3.7 %.  Two BP workgroups fill a CU's
@@ -134,9 +137,9 @@ class DeviceWindowPlan:
         import torch
         N = det.shape[0]
         pred = torch.zeros((N, self.nobs), dtype=torch.uint8, device=det.device)
-        for c0 in range(0, N, _CHUNK):
-            chunk = det[c0:c0 + _CHUNK]
-            acc = pred[c0:c0 + _CHUNK]
+        for c0 in range(0, N, self.chunk):
+            chunk = det[c0:c0 + self.chunk]
+            acc = pred[c0:c0 + self.chunk]
             upd = None
             for k, w in enumerate(self.windows):
                 err_bits, status = w["dec"].decode(chunk, w["row0"], upd)
