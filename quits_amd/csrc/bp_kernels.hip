@@ -53,8 +53,9 @@ __device__ __forceinline__ float qd_min_abs(float a, float b)
 //          dynamic LDS starts at address 0 (checked on entry), so the packed 16-bit offsets are used as addresses as they are
 //   sb   = bit of `sgnw` that holds the sign of the previous check->bit message on this edge
 // Branch-free: the second minimum is the median of (min1, min2, |b|); the new sign bits are shifted in from bit 0.
-// (b <= 0) is taken as the sign bit of (bits(b) - 1): exact for every float except -0.0, which cannot occur here -- a
-// posterior is a sum that starts from a non-zero prior, and x - y only yields -0 from (-0) - (+0).
+// (b <= 0) is taken as the sign bit of (bits(b) - 1): exact for every float except -0.0, which cannot occur here: a prior that
+// rounds to zero is uploaded as +0 (qd_api.hip, on_grid), sums and differences of values that are not -0 only yield -0 from
+// (-0) - (+0), and a message's sign is ORed onto a magnitude only where it is read, never stored as a float.
 #define QD_CHECK_EDGE(off, sb) QD_CHECK_EDGE_L(off, sb, (*(const __attribute__((address_space(3))) float *)(uintptr_t)(uint32_t)(off)))
 #define QD_CHECK_EDGE_L(off, sb, Lval)                                                                       \
     {                                                                                                        \
