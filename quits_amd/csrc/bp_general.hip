@@ -53,16 +53,14 @@ __device__ __forceinline__ uint32_t qd_lanes_or(uint32_t v, uint32_t (*red)[64],
 }
 
 // D: bound on the column weight the instantiation unrolls for (4, 8 or QD_MAX_COL_DEG; registers: five arrays of D in the serial schedule)
-// LP: the rows' running prefixes of the serial schedule live in LDS slots (GenGraphDev::row_slot) instead of the [m][S] plane
-template <int METHOD, int SCHED, int G, int D, bool LP>
+template <int METHOD, int SCHED, int G, int D>
 __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                             const int32_t *__restrict__ cp, const int32_t *__restrict__ ri,
                                                             const int32_t *__restrict__ c2r, const float *__restrict__ llr0,
                                                             const int32_t *__restrict__ lvl_ptr, const int32_t *__restrict__ lvl_bits,
-                                                            const int32_t *__restrict__ row_slot, DecodeArgs a, GenWs w, int64_t shot0, int nshots)
+                                                            DecodeArgs a, GenWs w, int64_t shot0, int nshots)
 {
     __shared__ uint32_t red[G][64];
-    extern __shared__ float lpre[];                                  // [nslots][64] (LP)
     const int lane = threadIdx.x & 63;
     const int wv = G > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;    // which rows / columns this wavefront takes
     const int ls = blockIdx.x * 64 + lane;                           // shot inside this chunk = column of the workspace
@@ -278,49 +276,27 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         par ^= (v <= 0.f) ? 1u : 0u;
                     }
                 }
+                rpre[(size_t)i * S] = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
             }
             if (G > 1) __syncthreads();
             // Faults are taken level by level (see GenGraphDev): inside a level they share no check, so the G wavefronts take one
             // each; across levels every pair of faults with a common check keeps its natural order -- the result is that of the
             // natural-order sweep of bp.hpp.
-            // What a fault needs that does not change during the sweep -- the suffixes of its edges and its checks' syndrome bits --
-            // is loaded one level ahead (for the first fault this wavefront takes in the next level), so that after the barrier only
-            // the prefixes (LDS) stand between a level and its arithmetic.
-            float Xn[D];
-            uint32_t syn_n[D];
-            auto load_static = [&](int j, float (&Xv)[D], uint32_t (&sv)[D]) {
-                const int c0 = cp[j], deg = cp[j + 1] - c0;
-#pragma unroll
-                for (int k = 0; k < D; ++k)
-                    if (k < deg) {
-                        Xv[k] = suf[(size_t)c2r[c0 + k] * S];
-                        sv[k] = syn[(size_t)ri[c0 + k] * S];
-                    }
-            };
-#pragma unroll
-            for (int k = 0; k < D; ++k) { Xn[k] = 0.f; syn_n[k] = 0u; }
-            if (active && lvl_ptr[0] + wv < lvl_ptr[1]) load_static(lvl_bits[lvl_ptr[0] + wv], Xn, syn_n);
             for (int lev = 0; lev < g.nlev; ++lev) {
-            const int x0 = lvl_ptr[lev] + wv, x1 = lvl_ptr[lev + 1];
-            float X[D];
-            uint32_t sy[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) { X[k] = Xn[k]; sy[k] = syn_n[k]; }
-            if (active && lev + 1 < g.nlev && x1 + wv < lvl_ptr[lev + 2]) load_static(lvl_bits[x1 + wv], Xn, syn_n);
-            __builtin_amdgcn_sched_barrier(0);                       // (the loads stay here, ahead of this level's arithmetic)
-            for (int x = x0; active && x < x1; x += G) {
+            const int x1 = lvl_ptr[lev + 1];
+            for (int x = lvl_ptr[lev] + wv; active && x < x1; x += G) {
                 const int j = lvl_bits[x];
                 const int c0 = cp[j], deg = cp[j + 1] - c0;
                 float lj = llr0[j];
-                float P[D], cv[D], pr[D];
-                if (x != x0) load_static(j, X, sy);                  // a level of more than G faults: the later ones load now
+                float P[D], X[D], cv[D], pr[D];
+                uint32_t sy[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k)
                     if (k < deg) {
                         const int i = ri[c0 + k];
-                        // the row's first entry starts the prefix (identity); the others continue it
-                        if (c2r[c0 + k] == rp[i]) P[k] = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
-                        else P[k] = LP ? lpre[row_slot[i] * 64 + lane] : rpre[(size_t)i * S];
+                        P[k] = rpre[(size_t)i * S];
+                        X[k] = suf[(size_t)c2r[c0 + k] * S];
+                        sy[k] = syn[(size_t)i * S];
                     }
 #pragma unroll
                 for (int k = 0; k < D; ++k)
@@ -348,13 +324,12 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         if (METHOD == QD_BP_PRODUCT_SUM) {
                             const float nt = qd_tanh_half(v);
                             msg[ce] = nt;
-                            if (LP) lpre[row_slot[i] * 64 + lane] = P[k] * nt; else rpre[(size_t)i * S] = P[k] * nt;
+                            rpre[(size_t)i * S] = P[k] * nt;
                         } else {
                             msg[ce] = v;
                             const float a1 = fabsf(P[k]), av = fabsf(v);
                             const uint32_t np = (__float_as_uint(P[k]) >> 31) ^ ((v <= 0.f) ? 1u : 0u);
-                            const float nv = __uint_as_float(__float_as_uint(av < a1 ? av : a1) | (np << 31));
-                            if (LP) lpre[row_slot[i] * 64 + lane] = nv; else rpre[(size_t)i * S] = nv;
+                            rpre[(size_t)i * S] = __uint_as_float(__float_as_uint(av < a1 ? av : a1) | (np << 31));
                         }
                     }
             }
@@ -433,13 +408,8 @@ __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__rest
 template <int METHOD, int SCHED, int G, int D>
 static hipError_t launch_kd(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
 {
-    const dim3 grid((unsigned)((nshots + 63) / 64)), block(64 * G);
-    if (SCHED == QD_SCHEDULE_SERIAL && g.nslots > 0)
-        hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D, true>), grid, block, (size_t)g.nslots * 256, s, g, g.rp, g.ci, g.cp, g.ri, g.c2r,
-                           g.llr0, g.lvl_ptr, g.lvl_bits, g.row_slot, a, w, shot0, nshots);
-    else
-        hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D, false>), grid, block, 0, s, g, g.rp, g.ci, g.cp, g.ri, g.c2r,
-                           g.llr0, g.lvl_ptr, g.lvl_bits, g.row_slot, a, w, shot0, nshots);
+    hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D>), dim3((unsigned)((nshots + 63) / 64)), dim3(64 * G), 0, s, g, g.rp, g.ci,
+                       g.cp, g.ri, g.c2r, g.llr0, g.lvl_ptr, g.lvl_bits, a, w, shot0, nshots);
     return hipGetLastError();
 }
 

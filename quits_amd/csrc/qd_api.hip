@@ -120,7 +120,6 @@ struct qd_spmat {
 };
 
 #define QD_GRID_MIN_BITS 10
-#define QD_GEN_PREFIX_LDS (32 * 1024)   // LDS a workgroup of the serial BP kernel may spend on row prefixes (128 rows x 64 shots): four workgroups per CU stay resident
 static inline int align16(int x) { return (x + 15) & ~15; }
 static inline int pad64(int x) { return (x + 63) & ~63; }
 
@@ -351,28 +350,6 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             for (int j = 0; j < n; ++j) lb[fillp[lev[j]]++] = j;
             gg.nlev = nlev;
             rcg |= g->mem.upload(lp, &gg.lvl_ptr); rcg |= g->mem.upload(lb, &gg.lvl_bits);
-            // LDS slots of the rows' running prefixes: row i is live over the levels [first_i, last_i] of its faults; a slot is handed
-            // on only to a row that starts strictly after its previous owner's last level (two faults of one level write their
-            // rows in any order).  Greedy interval colouring in order of first level = the minimum number of slots.
-            std::vector<int32_t> first(m, nlev), lastl(m, -1), slot(m, 0), order(m);
-            for (int i = 0; i < m; ++i)
-                for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
-                    first[i] = std::min(first[i], lev[col_idx[e]]);
-                    lastl[i] = std::max(lastl[i], lev[col_idx[e]]);
-                }
-            std::iota(order.begin(), order.end(), 0);
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
-            std::vector<int32_t> busy_until;                // per slot: last level of its current owner
-            for (int i : order) {
-                int sidx = -1;
-                for (size_t q = 0; q < busy_until.size(); ++q)
-                    if (busy_until[q] < first[i]) { sidx = (int)q; break; }
-                if (sidx < 0) { sidx = (int)busy_until.size(); busy_until.push_back(-1); }
-                busy_until[sidx] = lastl[i];
-                slot[i] = sidx;
-            }
-            gg.nslots = (int)busy_until.size() * 256 <= QD_GEN_PREFIX_LDS ? (int)busy_until.size() : 0;
-            rcg |= g->mem.upload(slot, &gg.row_slot);
         }
         if (rcg) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while building the graph"); }
     }
@@ -739,8 +716,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         const bool ps = d->prm.bp_method == QD_BP_PRODUCT_SUM, serial = d->prm.schedule == QD_SCHEDULE_SERIAL;
         // edge planes: flooding b2c + c2b (+ th for product-sum); serial: messages (th or b2c) + suffixes (the c2b plane), and a row plane
         const int planes = serial ? 2 : (ps ? 3 : 2);
-        const bool pre_plane = serial && g->gen.nslots == 0;       // the rows' running prefixes: LDS slots when the graph allows
-        const size_t per_shot = ((size_t)g->nnz * planes + g->n + (pre_plane ? g->m : 0)) * sizeof(float) + g->m + sizeof(int32_t);
+        const size_t per_shot = ((size_t)g->nnz * planes + g->n + (serial ? g->m : 0)) * sizeof(float) + g->m + sizeof(int32_t);
         // Default budget 48 GB of the 288: the kernel is latency-bound (one wavefront per 64 shots), so a launch costs about
         // the same for 8 K or 64 K shots and chunks should be as large as memory allows -- and of equal size.
         double budget_gb = 48.0;
@@ -755,7 +731,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         if (!(ps && serial)) HIP_TRY(hipMalloc((void **)&w.b2c, sizeof(float) * (size_t)g->nnz * S));
         HIP_TRY(hipMalloc((void **)&w.c2b, sizeof(float) * (size_t)g->nnz * S));
         if (ps) HIP_TRY(hipMalloc((void **)&w.th, sizeof(float) * (size_t)g->nnz * S));
-        if (pre_plane) HIP_TRY(hipMalloc((void **)&w.pre, sizeof(float) * (size_t)g->m * S));
+        if (serial) HIP_TRY(hipMalloc((void **)&w.pre, sizeof(float) * (size_t)g->m * S));
         HIP_TRY(hipMalloc((void **)&w.llr, sizeof(float) * (size_t)g->n * S));
         HIP_TRY(hipMalloc((void **)&w.syn, (size_t)g->m * S));
         HIP_TRY(hipMalloc((void **)&w.slot, sizeof(int32_t) * (size_t)S));

@@ -54,11 +54,6 @@ struct GenGraphDev {
     int nlev;
     const int32_t *lvl_ptr;     // [nlev + 1]
     const int32_t *lvl_bits;    // [n]              faults by level, ascending index inside a level
-    // ... and the rows' running prefixes (the values the dependency chain runs through) live in LDS: a row needs one from the
-    // level of its first fault to the level of its last, so rows whose intervals do not overlap share a slot (interval
-    // colouring on the host; 112 slots for the [[144,12,12]] windows whatever their length).  nslots = 0: too many, prefixes in HBM.
-    int nslots;
-    const int32_t *row_slot;    // [m]
 };
 // ... and its per-chunk workspace, [index][shot] with S shots per row
 struct GenWs {
