@@ -376,6 +376,198 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
     }
 }
 
+// ---- flooding product-sum with the messages in LDS: one workgroup per shot -------------------------------------------------
+// The kernel above gives a lane to a shot because the serial schedule leaves a single shot almost no parallelism; the FLOODING
+// schedule does not have that problem -- every row, then every column, is independent -- and for the windows the reference
+// really decodes (W = 3..5 rounds: E <= ~25 000 edges) one float per edge fits LDS.  So here a workgroup owns a shot: a lane
+// takes an edge (tanh, log), a row (the part of the check pass that is a chain: bp.hpp's forward / backward exclusive products,
+// the row's tanh values in registers) or a fault (bit pass: posterior, then the prefix / suffix sums); check->bit messages are
+// written over the bit->check messages they were made from, message traffic never leaves the CU, and HBM sees the detector
+// bytes in and the decision out.
+// Same operations in the same order as qd_bp_edge_kernel<PRODUCT_SUM, PARALLEL> and as the float mirror bp_parallel_edge_f32:
+// the two kernels return the same bits.  The parity of the hard decisions is kept per check by LDS atomics from the (rare)
+// faults decided 1, as in bp_kernels.hip, so the convergence test costs nothing per edge.
+//   DEG = bound on the row weight the instantiation unrolls for (one register array of that length)
+#define QD_PSL_TR 4           // bit-pass trips whose records are in flight together
+template <int DEG, int T>
+__global__ void __launch_bounds__(T) qd_bp_ps_lds_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ cp,
+                                                         const int32_t *__restrict__ ri, const int32_t *__restrict__ c2r,
+                                                         const float *__restrict__ llr0, const uint32_t *__restrict__ slot_of,
+                                                         const uint16_t *__restrict__ erow, const uint4 *__restrict__ frec, int n_pad, DecodeArgs a)
+{
+    extern __shared__ __align__(16) float sm[];
+    float *msg = sm;                                                 // [nnz] CSR edge order: b2c before a check pass, c2b after it
+    float *llr = msg + ((g.nnz + 3) & ~3);                           // [n]
+    uint32_t *par = reinterpret_cast<uint32_t *>(llr + ((g.n + 3) & ~3));   // [m] bit 0 syndrome, bit 1 parity of the hard decisions on the check
+    uint32_t *red = par + ((g.m + 3) & ~3);                          // [2][16] block-OR flags, [32] fail slot
+    const int tid = threadIdx.x;
+    constexpr int NW = T / 64;
+    const int64_t shot = blockIdx.x;
+    const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
+    const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
+    auto block_or = [&](uint32_t v, int phase) -> uint32_t {
+        const unsigned long long bal = __ballot(v != 0u);
+        if ((tid & 63) == 0) red[phase * 16 + (tid >> 6)] = bal != 0ull ? 1u : 0u;
+        __syncthreads();
+        uint32_t r = 0u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) r |= red[phase * 16 + w];
+        return r;
+    };
+    uint32_t any = 0u;
+    for (int i = tid; i < g.m; i += T) {
+        uint32_t sb = det[i] & 1u;
+        if (upd && i < a.upd_rows) sb ^= upd[i] & 1u;
+        par[i] = sb;
+        any |= sb;
+    }
+    uint32_t *out = a.err_bits + shot * g.out_words;
+    if (!block_or(any, 0)) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
+        for (int x = tid; x < g.out_words; x += T) out[x] = 0u;
+        if (tid == 0) a.status[shot] = (1 << 16) | (1 << 19);
+        return;
+    }
+    for (int j = tid; j < g.n; j += T) {
+        const float l0 = llr0[j];
+        for (int e = cp[j]; e < cp[j + 1]; ++e) msg[c2r[e]] = l0;
+    }
+    __syncthreads();
+    int iters = 0, converged = 0, phase = 1;
+    const int my_r0 = tid < g.m ? rp[tid] : 0, my_deg = tid < g.m ? rp[tid + 1] - my_r0 : 0;      // this lane's first (usually only) row
+    for (int it = 1; it <= a.max_iter; ++it) {
+        // ---- check pass, in three steps so that the expensive functions run one edge per lane (every lane busy) and only the two
+        // multiply chains of a row (bp.hpp's order) run one row per lane:
+        //   tanh(b2c / 2) per edge | forward / backward exclusive products per row | sign * log((1 + c) / (1 - c)) per edge
+        // (fusing the two functions into the bit pass -- three barriers per iteration instead of five -- measured 15 % slower: a
+        //  fault has 3.2 edges of the 8 a lane unrolls for)
+        for (int e = tid; e < g.nnz; e += T) msg[e] = qd_tanh_half(msg[e]);
+        __syncthreads();
+        for (int i = tid; i < g.m; i += T) {
+            const int r0 = i == tid ? my_r0 : rp[i], deg = i == tid ? my_deg : rp[i + 1] - rp[i];
+            float th[DEG];
+            float temp = 1.0f;
+#pragma unroll
+            for (int k = 0; k < DEG; ++k)
+                if (k < deg) {
+                    const float t = msg[r0 + k];
+                    th[k] = t;
+                    msg[r0 + k] = temp;
+                    temp = temp * t;
+                }
+            temp = 1.0f;
+#pragma unroll
+            for (int k = DEG - 1; k >= 0; --k)
+                if (k < deg) {
+                    msg[r0 + k] = msg[r0 + k] * temp;
+                    temp = temp * th[k];
+                }
+        }
+        __syncthreads();
+        for (int e = tid; e < g.nnz; e += T) {
+            const float sgn = (par[erow[e]] & 1u) ? -1.0f : 1.0f;
+            msg[e] = sgn * qd_log_ratio(msg[e]);
+        }
+        __syncthreads();
+        // ---- bit pass: posterior, then the prefix / suffix sums that make the outgoing messages.  A fault comes as one 32-byte
+        // record (eight 16-bit CSR edge indices and their rows, 0xFFFF beyond the column weight); the records and priors of
+        // QD_PSL_TR trips are requested before any is used, so a pass pays one L2 latency, not one per trip.
+        for (int base = 0; base < g.n; base += T * QD_PSL_TR) {
+            uint4 rec[QD_PSL_TR];
+            float l0v[QD_PSL_TR];
+#pragma unroll
+            for (int t = 0; t < QD_PSL_TR; ++t) {
+                const int j = base + t * T + tid;
+                rec[t] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                l0v[t] = 0.f;
+                if (j < g.n) { rec[t] = frec[2 * j]; l0v[t] = llr0[j]; }
+            }
+#pragma unroll
+            for (int t = 0; t < QD_PSL_TR; ++t) {
+                const int j = base + t * T + tid;
+                if (j >= g.n) continue;
+                const uint32_t w4[4] = {rec[t].x, rec[t].y, rec[t].z, rec[t].w};
+                uint32_t idx[8];
+                float cv[8], pr[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    idx[k] = (k & 1) ? (w4[k >> 1] >> 16) : (w4[k >> 1] & 0xFFFFu);
+                    cv[k] = idx[k] != 0xFFFFu ? msg[idx[k]] : 0.f;
+                }
+                float temp = l0v[t];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (idx[k] != 0xFFFFu) { pr[k] = temp; temp += cv[k]; }
+                llr[j] = temp;
+                if (temp <= 0.f) {                                      // hard decision 1 (rare): tell the fault's checks
+                    const uint4 rr = frec[2 * j + 1];
+                    const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (idx[k] != 0xFFFFu) atomicXor(&par[(k & 1) ? (r4[k >> 1] >> 16) : (r4[k >> 1] & 0xFFFFu)], 2u);
+                }
+                temp = 0.f;
+#pragma unroll
+                for (int k = 7; k >= 0; --k)
+                    if (idx[k] != 0xFFFFu) { msg[idx[k]] = pr[k] + temp; temp += cv[k]; }
+            }
+        }
+        __syncthreads();
+        // ---- stop when the hard decision reproduces the syndrome
+        uint32_t bad = 0u;
+        for (int i = tid; i < g.m; i += T) {
+            const uint32_t v = par[i];
+            bad |= (v ^ (v >> 1)) & 1u;
+            par[i] = v & 1u;                                         // (only this lane touches the word until the next bit pass)
+        }
+        bad = block_or(bad, phase);
+        phase ^= 1;
+        iters = it;
+        if (!bad) { converged = 1; break; }
+    }
+    // ---- hard decision, packed by fault index
+    for (int x = tid; x < g.out_words; x += T) {
+        uint32_t word = 0u;
+        const int j1 = min(g.n, 32 * x + 32);
+        for (int j = 32 * x; j < j1; ++j) word |= ((llr[j] <= 0.f) ? 1u : 0u) << (j & 31);
+        out[x] = word;
+    }
+    if (tid == 0) a.status[shot] = iters | (converged << 16);
+    if (!converged && a.want_llr) {
+        if (tid == 0) { const int slot = atomicAdd(a.fail_count, 1); a.fail_list[slot] = (int32_t)shot; red[32] = (uint32_t)slot; }
+        __syncthreads();
+        float *dst = a.llr_ws + (int64_t)red[32] * n_pad;
+        for (int j = tid; j < g.n; j += T) dst[slot_of[j]] = llr[j];
+    }
+}
+
+// LDS bytes of that kernel for a window, or 0 if the window does not fit it (row weight beyond the instantiations, or too many edges)
+int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg)
+{
+    if (max_rdeg > 56 || g.n > 65535 || g.nnz > 65534 || !g.frec) return 0;          // (frec: only built for column weight <= 8)
+    const size_t b = ((size_t)((g.nnz + 3) & ~3) + ((g.n + 3) & ~3) + ((g.m + 3) & ~3) + 64) * 4;
+    return b <= (size_t)QD_LDS_BYTES - 1024 ? (int)b : 0;
+}
+
+hipError_t qd_launch_bp_ps_lds(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t B, hipStream_t s)
+{
+    const int lds = qd_bp_ps_lds_bytes(g, bg.max_rdeg);
+    if (lds == 0) return hipErrorInvalidValue;
+    const bool wide = bg.max_rdeg > 36;
+    const bool small = g.nnz <= 9000;           // threads per shot: 256 for the W = 3 windows (6624 edges: 14.1 vs 18.0 ms per launch), 512 beyond (W = 5: 28.6 vs 44.5 ms)
+    const dim3 grid((unsigned)B);
+#define QD_PSL(D_, T_)                                                                                                      \
+    {                                                                                                                       \
+        hipError_t e = hipFuncSetAttribute((const void *)qd_bp_ps_lds_kernel<D_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        if (e != hipSuccess) return e;                                                                                      \
+        hipLaunchKernelGGL((qd_bp_ps_lds_kernel<D_, T_>), grid, dim3(T_), (size_t)lds, s, g, g.rp, g.cp, g.ri, g.c2r, g.llr0, bg.bit_slot_of, g.erow, \
+                           reinterpret_cast<const uint4 *>(g.frec), bg.n_pad, a);                                           \
+    }
+    if (wide) { if (small) QD_PSL(56, 256) else QD_PSL(56, 512) }
+    else { if (small) QD_PSL(36, 256) else QD_PSL(36, 512) }
+#undef QD_PSL
+    return hipGetLastError();
+}
+
 // Posteriors of the shots BP could not finish, from [fault][shot] to the OSD workspace's [fail slot][bit slot] rows.
 // 64 x 64 tiles through LDS so that both sides move whole lines.
 __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__restrict__ llr, const int32_t *__restrict__ slot,

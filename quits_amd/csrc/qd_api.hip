@@ -14,6 +14,8 @@
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
                                 int schedule, int64_t shot0, int nshots, hipStream_t s);
+int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg);
+hipError_t qd_launch_bp_ps_lds(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
                           int blocks_full, hipStream_t s);
 hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks,
@@ -94,6 +96,7 @@ struct qd_decoder {
     int osd_blocks_fast = 0;
     int osd_w = 0;
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
+    int lds_edge = 0;           // ... its LDS-resident form (flooding product-sum on a window whose messages fit LDS): no HBM message workspace
     int lsd = 0;                // 1: BP-LSD post-processing (lsd_kernels.hip) instead of OSD
     int lsd_blocks = 0;
     int lsd_w = 0;              // higher-order LSD: 0 = LSD-0, 1 = combination sweep, 2 = exhaustive (order = prm.osd_order)
@@ -321,6 +324,20 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         rcg |= g->mem.upload(rp_v, &gg.rp); rcg |= g->mem.upload(ci_v, &gg.ci);
         rcg |= g->mem.upload(cp, &gg.cp); rcg |= g->mem.upload(ri, &gg.ri);
         rcg |= g->mem.upload(c2r, &gg.c2r); rcg |= g->mem.upload(l0, &gg.llr0);
+        gg.frec = nullptr; gg.erow = nullptr;
+        if (max_cdeg <= 8 && nnz <= 65534) {
+            std::vector<uint16_t> erow(nnz);
+            for (int i = 0; i < m; ++i)
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) erow[e] = (uint16_t)i;
+            rcg |= g->mem.upload(erow, &gg.erow);
+            std::vector<uint16_t> frec((size_t)n * 16, (uint16_t)0xFFFF);
+            for (int j = 0; j < n; ++j)
+                for (int e = cp[j]; e < cp[j + 1]; ++e) {
+                    frec[(size_t)j * 16 + (e - cp[j])] = (uint16_t)c2r[e];
+                    frec[(size_t)j * 16 + 8 + (e - cp[j])] = (uint16_t)ri[e];
+                }
+            rcg |= g->mem.upload(frec, &gg.frec);
+        }
         {
             gg.ell_w = (max_rdeg + 63) / 64 * 64;
             std::vector<int32_t> ell((size_t)m * gg.ell_w * 2, 0);
@@ -573,6 +590,8 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
     d->g = g; d->prm = *p; d->lsd = lsd ? 1 : 0;
     d->lsd_w = (lsd && p->osd_order > 0) ? (p->osd_method == QD_LSD_CS ? 1 : (p->osd_method == QD_LSD_E ? 2 : 0)) : 0;
     d->general = (p->bp_method != QD_BP_MINIMUM_SUM || p->schedule != QD_SCHEDULE_PARALLEL || (p->reserved & QD_FLAG_EDGE_MESSAGES)) ? 1 : 0;
+    d->lds_edge = (d->general && p->bp_method == QD_BP_PRODUCT_SUM && p->schedule == QD_SCHEDULE_PARALLEL && !std::getenv("QD_NO_LDS_EDGE") &&
+                   qd_bp_ps_lds_bytes(g->gen, g->max_rdeg) > 0) ? 1 : 0;
     d->osd_w = osd0 || p->osd_method == QD_OSD_OFF ? 0 : (p->osd_method == QD_OSD_CS ? 1 : 2);
     if (d->osd_w) host_rank(const_cast<qd_graph *>(g));     // the sweep needs the complete factorisation: rank pivots
     if (d->prm.max_iter == 0) d->prm.max_iter = g->n;       // ldpc: max_iter = 0 -> number of bits
@@ -711,7 +730,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         if (d->osd_blocks > 0 && spill_planes > 0)
             HIP_TRY(hipMalloc((void **)&d->q_spill, sizeof(uint64_t) * (size_t)d->osd_blocks * spill_planes * g->osd.m_pad));
     }
-    if (d->general) {
+    if (d->general && !d->lds_edge) {
         // [index][shot] message planes for a chunk of S shots; a batch larger than S is decoded chunk by chunk
         const bool ps = d->prm.bp_method == QD_BP_PRODUCT_SUM, serial = d->prm.schedule == QD_SCHEDULE_SERIAL;
         // edge planes: flooding b2c + c2b (+ th for product-sum); serial: messages (th or b2c) + suffixes (the c2b plane), and a row plane
@@ -817,7 +836,11 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
         hipEvent_t t0 = nullptr;
         if (int rc = span(0, t0)) return rc;
-        if (d->general) {
+        if (d->lds_edge) {
+            GenGraphDev gg = d->g->gen;
+            gg.llr0 = d->llr0_q;
+            HIP_TRY(qd_launch_bp_ps_lds(gg, d->g->bp, a, B, s));
+        } else if (d->general) {
             GenGraphDev gg = d->g->gen;
             gg.llr0 = d->llr0_q;
             for (int64_t b0 = 0; b0 < B; b0 += d->gws.S)

@@ -45,6 +45,9 @@ struct GenGraphDev {
     const int32_t *rp, *ci;     // [m + 1], [nnz]   CSR, columns ascending in a row
     const int32_t *cp, *ri;     // [n + 1], [nnz]   CSC, rows ascending in a column
     const int32_t *c2r;         // [nnz]            CSC edge -> CSR edge
+    const uint16_t *erow;       // [nnz]            CSR edge -> its row
+    const uint16_t *frec;       // [n][16]          the CSR edges of a fault's column (8 entries), then their rows (8), 0xFFFF beyond its weight
+                                //                  (null if a column is heavier than 8 or nnz > 65534)
     const float *llr0;          // [n]              (float)log((1 - p) / p), the log in double
     const int32_t *ell;         // [m][ell_w][2]    rows in ELL form for BP-LSD: {fault, its posterior column}, {-1, 0} padding
     int ell_w;                  //                  max row weight rounded up to a multiple of 64
