@@ -53,14 +53,16 @@ __device__ __forceinline__ uint32_t qd_lanes_or(uint32_t v, uint32_t (*red)[64],
 }
 
 // D: bound on the column weight the instantiation unrolls for (4, 8 or QD_MAX_COL_DEG; registers: five arrays of D in the serial schedule)
-template <int METHOD, int SCHED, int G, int D>
+//    LP: serial schedule with the rows' running prefixes in LDS slots (GenGraphDev::nslots > 0)
+template <int METHOD, int SCHED, int G, int D, bool LP>
 __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                             const int32_t *__restrict__ cp, const int32_t *__restrict__ ri,
                                                             const int32_t *__restrict__ c2r, const float *__restrict__ llr0,
-                                                            const int32_t *__restrict__ lvl_ptr, const int32_t *__restrict__ lvl_bits,
+                                                            const uint32_t *__restrict__ srec,
                                                             DecodeArgs a, GenWs w, int64_t shot0, int nshots)
 {
     __shared__ uint32_t red[G][64];
+    extern __shared__ float pls[];                                   // [nslots][64]  (LP)
     const int lane = threadIdx.x & 63;
     const int wv = G > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;    // which rows / columns this wavefront takes
     const int ls = blockIdx.x * 64 + lane;                           // shot inside this chunk = column of the workspace
@@ -276,36 +278,55 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         par ^= (v <= 0.f) ? 1u : 0u;
                     }
                 }
-                rpre[(size_t)i * S] = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
+                // the row's syndrome bit rides in the sign of its prefix: log_ratio is odd and a product's sign is the parity of its
+                // factors' signs, so the check->bit sign needs no separate load per edge
+                if (!LP) {
+                    const uint32_t sbit = (uint32_t)syn[(size_t)i * S] << 31;
+                    rpre[(size_t)i * S] = __uint_as_float(__float_as_uint(METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG) | sbit);
+                }
             }
             if (G > 1) __syncthreads();
             // Faults are taken level by level (see GenGraphDev): inside a level they share no check, so the G wavefronts take one
             // each; across levels every pair of faults with a common check keeps its natural order -- the result is that of the
-            // natural-order sweep of bp.hpp.
-            for (int lev = 0; lev < g.nlev; ++lev) {
-            const int x1 = lvl_ptr[lev + 1];
-            for (int x = lvl_ptr[lev] + wv; active && x < x1; x += G) {
-                const int j = lvl_bits[x];
-                const int c0 = cp[j], deg = cp[j + 1] - c0;
-                float lj = llr0[j];
+            // natural-order sweep of bp.hpp.  A wavefront's work in a step is one record, loaded (scalar) one step ahead.
+            {
+            constexpr int RW = (2 + 2 * D + 3) & ~3;
+            // lane q < RW fetches dword q of the wavefront's record for the NEXT step with one vector load (a scalar load of two
+            // records' worth of registers does not fit beside the kernel's arguments: the compiler parks it in vector lanes at once,
+            // which waits for it); the step that uses it broadcasts the dwords it needs with v_readlane
+            const uint32_t *__restrict__ rb = srec + (size_t)wv * RW + (lane < RW ? lane : 0);
+            uint32_t pf = rb[0];
+            for (int st = 0; st < g.nstep; ++st) {
+                uint32_t cur[RW];
+#pragma unroll
+                for (int q = 0; q < RW; ++q) cur[q] = __builtin_amdgcn_readlane(pf, q);
+                const uint32_t head = cur[0];
+                const int deg = (int)((head >> 24) & 31u);
                 float P[D], X[D], cv[D], pr[D];
-                uint32_t sy[D];
+                pf = rb[(size_t)(st + 1 < g.nstep ? st + 1 : st) * (G * RW)];
+                if (active && deg) {
+                const int j = (int)(head & 0xFFFFFFu);
+                float lj = __uint_as_float(cur[1]);
 #pragma unroll
                 for (int k = 0; k < D; ++k)
                     if (k < deg) {
-                        const int i = ri[c0 + k];
-                        P[k] = rpre[(size_t)i * S];
-                        X[k] = suf[(size_t)c2r[c0 + k] * S];
-                        sy[k] = syn[(size_t)i * S];
+                        if (LP) {
+                            const uint32_t rw = cur[2 + k];
+                            if (rw & 0x800000u)      // first entry of its row: nothing refreshed yet
+                                P[k] = __uint_as_float(__float_as_uint(METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG) |
+                                                       ((uint32_t)syn[(size_t)(rw & 0x7FFFFFu) * S] << 31));
+                            else P[k] = pls[(rw >> 24) * 64 + lane];
+                        } else P[k] = rpre[(size_t)cur[2 + k] * S];
+                        X[k] = suf[(size_t)cur[2 + D + k] * S];
                     }
 #pragma unroll
                 for (int k = 0; k < D; ++k)
                     if (k < deg) {
                         float c;
-                        if (METHOD == QD_BP_PRODUCT_SUM) c = (sy[k] ? -1.0f : 1.0f) * qd_log_ratio(P[k] * X[k]);
+                        if (METHOD == QD_BP_PRODUCT_SUM) c = qd_log_ratio(P[k] * X[k]);
                         else {
                             const float a1 = fabsf(P[k]), a2 = fabsf(X[k]);
-                            const uint32_t sg = (sy[k] ^ (__float_as_uint(P[k]) >> 31) ^ (__float_as_uint(X[k]) >> 31)) & 1u;
+                            const uint32_t sg = ((__float_as_uint(P[k]) >> 31) ^ (__float_as_uint(X[k]) >> 31)) & 1u;
                             c = alpha * (sg ? -1.0f : 1.0f) * (a2 < a1 ? a2 : a1);
                         }
                         cv[k] = c;
@@ -317,23 +338,24 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
 #pragma unroll
                 for (int k = D - 1; k >= 0; --k)
                     if (k < deg) {               // b2c = prefix (kept in registers) + suffix
-                        const int i = ri[c0 + k];
-                        const size_t ce = (size_t)c2r[c0 + k] * S;
+                        const size_t ce = (size_t)cur[2 + D + k] * S;
+                        float *__restrict__ pdst = LP ? &pls[(cur[2 + k] >> 24) * 64 + lane] : &rpre[(size_t)cur[2 + k] * S];
                         const float v = pr[k] + temp;
                         temp += cv[k];
                         if (METHOD == QD_BP_PRODUCT_SUM) {
                             const float nt = qd_tanh_half(v);
                             msg[ce] = nt;
-                            rpre[(size_t)i * S] = P[k] * nt;
+                            *pdst = P[k] * nt;
                         } else {
                             msg[ce] = v;
                             const float a1 = fabsf(P[k]), av = fabsf(v);
                             const uint32_t np = (__float_as_uint(P[k]) >> 31) ^ ((v <= 0.f) ? 1u : 0u);
-                            rpre[(size_t)i * S] = __uint_as_float(__float_as_uint(av < a1 ? av : a1) | (np << 31));
+                            *pdst = __uint_as_float(__float_as_uint(av < a1 ? av : a1) | (np << 31));
                         }
                     }
+                }
+                if (G > 1 && (head >> 31)) __syncthreads();
             }
-            if (G > 1) __syncthreads();
             }
         }
         // ---- stop when the hard decision reproduces the syndrome
@@ -388,8 +410,10 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
 // the two kernels return the same bits.  The parity of the hard decisions is kept per check by LDS atomics from the (rare)
 // faults decided 1, as in bp_kernels.hip, so the convergence test costs nothing per edge.
 //   DEG = bound on the row weight the instantiation unrolls for (one register array of that length)
+//   NREG = 0: posteriors in LDS.  NREG > 0 (a window whose messages alone nearly fill the LDS -- the headline's 33 192 edges = 133 KB):
+//          a lane keeps the posteriors of ITS faults (fault j belongs to lane j mod T in every bit pass) in NREG registers, n <= NREG * T
 #define QD_PSL_TR 4           // bit-pass trips whose records are in flight together
-template <int DEG, int T>
+template <int DEG, int T, int NREG>
 __global__ void __launch_bounds__(T) qd_bp_ps_lds_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ cp,
                                                          const int32_t *__restrict__ ri, const int32_t *__restrict__ c2r,
                                                          const float *__restrict__ llr0, const uint32_t *__restrict__ slot_of,
@@ -397,11 +421,13 @@ __global__ void __launch_bounds__(T) qd_bp_ps_lds_kernel(GenGraphDev g, const in
 {
     extern __shared__ __align__(16) float sm[];
     float *msg = sm;                                                 // [nnz] CSR edge order: b2c before a check pass, c2b after it
-    float *llr = msg + ((g.nnz + 3) & ~3);                           // [n]
-    uint32_t *par = reinterpret_cast<uint32_t *>(llr + ((g.n + 3) & ~3));   // [m] bit 0 syndrome, bit 1 parity of the hard decisions on the check
+    float *llr = msg + ((g.nnz + 3) & ~3);                           // [n]   (NREG = 0)
+    uint32_t *par = reinterpret_cast<uint32_t *>(llr + (NREG ? 0 : ((g.n + 3) & ~3)));   // [m] bit 0 syndrome, bit 1 parity of the hard decisions on the check
+    float lreg[NREG ? NREG : 1];
     uint32_t *red = par + ((g.m + 3) & ~3);                          // [2][16] block-OR flags, [32] fail slot
     const int tid = threadIdx.x;
     constexpr int NW = T / 64;
+    constexpr int TR = NREG ? 2 : QD_PSL_TR;                         // (registers: the NREG instantiation has 128 to live in)
     const int64_t shot = blockIdx.x;
     const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
     const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
@@ -470,19 +496,22 @@ __global__ void __launch_bounds__(T) qd_bp_ps_lds_kernel(GenGraphDev g, const in
         __syncthreads();
         // ---- bit pass: posterior, then the prefix / suffix sums that make the outgoing messages.  A fault comes as one 32-byte
         // record (eight 16-bit CSR edge indices and their rows, 0xFFFF beyond the column weight); the records and priors of
-        // QD_PSL_TR trips are requested before any is used, so a pass pays one L2 latency, not one per trip.
-        for (int base = 0; base < g.n; base += T * QD_PSL_TR) {
-            uint4 rec[QD_PSL_TR];
-            float l0v[QD_PSL_TR];
+        // TR trips are requested before any is used, so a pass pays one L2 latency, not one per trip.
 #pragma unroll
-            for (int t = 0; t < QD_PSL_TR; ++t) {
+        for (int ob = 0; ob < (NREG ? NREG / TR : 1 << 20); ++ob) {
+            const int base = ob * (T * TR);
+            if (base >= g.n) break;
+            uint4 rec[TR];
+            float l0v[TR];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
                 const int j = base + t * T + tid;
                 rec[t] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
                 l0v[t] = 0.f;
                 if (j < g.n) { rec[t] = frec[2 * j]; l0v[t] = llr0[j]; }
             }
 #pragma unroll
-            for (int t = 0; t < QD_PSL_TR; ++t) {
+            for (int t = 0; t < TR; ++t) {
                 const int j = base + t * T + tid;
                 if (j >= g.n) continue;
                 const uint32_t w4[4] = {rec[t].x, rec[t].y, rec[t].z, rec[t].w};
@@ -497,7 +526,8 @@ __global__ void __launch_bounds__(T) qd_bp_ps_lds_kernel(GenGraphDev g, const in
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (idx[k] != 0xFFFFu) { pr[k] = temp; temp += cv[k]; }
-                llr[j] = temp;
+                if (NREG) lreg[NREG ? ob * TR + t : 0] = temp;
+                else llr[j] = temp;
                 if (temp <= 0.f) {                                      // hard decision 1 (rare): tell the fault's checks
                     const uint4 rr = frec[2 * j + 1];
                     const uint32_t r4[4] = {rr.x, rr.y, rr.z, rr.w};
@@ -525,26 +555,50 @@ __global__ void __launch_bounds__(T) qd_bp_ps_lds_kernel(GenGraphDev g, const in
         if (!bad) { converged = 1; break; }
     }
     // ---- hard decision, packed by fault index
-    for (int x = tid; x < g.out_words; x += T) {
-        uint32_t word = 0u;
-        const int j1 = min(g.n, 32 * x + 32);
-        for (int j = 32 * x; j < j1; ++j) word |= ((llr[j] <= 0.f) ? 1u : 0u) << (j & 31);
-        out[x] = word;
-    }
+    if (NREG) {
+        uint32_t *ow = reinterpret_cast<uint32_t *>(msg);            // the messages are done with
+        __syncthreads();
+        for (int x = tid; x < g.out_words; x += T) ow[x] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < (NREG ? NREG : 1); ++q) {
+            const int j = q * T + tid;
+            if (j < g.n && lreg[q] <= 0.f) atomicOr(&ow[j >> 5], 1u << (j & 31));
+        }
+        __syncthreads();
+        for (int x = tid; x < g.out_words; x += T) out[x] = ow[x];
+    } else
+        for (int x = tid; x < g.out_words; x += T) {
+            uint32_t word = 0u;
+            const int j1 = min(g.n, 32 * x + 32);
+            for (int j = 32 * x; j < j1; ++j) word |= ((llr[j] <= 0.f) ? 1u : 0u) << (j & 31);
+            out[x] = word;
+        }
     if (tid == 0) a.status[shot] = iters | (converged << 16);
     if (!converged && a.want_llr) {
         if (tid == 0) { const int slot = atomicAdd(a.fail_count, 1); a.fail_list[slot] = (int32_t)shot; red[32] = (uint32_t)slot; }
         __syncthreads();
         float *dst = a.llr_ws + (int64_t)red[32] * n_pad;
-        for (int j = tid; j < g.n; j += T) dst[slot_of[j]] = llr[j];
+        if (NREG) {
+#pragma unroll
+            for (int q = 0; q < (NREG ? NREG : 1); ++q) {
+                const int j = q * T + tid;
+                if (j < g.n) dst[slot_of[j]] = lreg[q];
+            }
+        } else
+            for (int j = tid; j < g.n; j += T) dst[slot_of[j]] = llr[j];
     }
 }
 
+#define QD_PSL_BIG_T 1024
+#define QD_PSL_BIG_NREG 12
 // LDS bytes of that kernel for a window, or 0 if the window does not fit it (row weight beyond the instantiations, or too many edges)
 int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg)
 {
     if (max_rdeg > 56 || g.n > 65535 || g.nnz > 65534 || !g.frec) return 0;          // (frec: only built for column weight <= 8)
-    const size_t b = ((size_t)((g.nnz + 3) & ~3) + ((g.n + 3) & ~3) + ((g.m + 3) & ~3) + 64) * 4;
+    const size_t fixed = ((size_t)((g.nnz + 3) & ~3) + ((g.m + 3) & ~3) + 64) * 4, b = fixed + (size_t)((g.n + 3) & ~3) * 4;
+    if (b <= (size_t)QD_LDS_BYTES / 2) return (int)b;                                // two workgroups per CU
+    if (fixed <= (size_t)QD_LDS_BYTES - 1024 && g.n <= QD_PSL_BIG_T * QD_PSL_BIG_NREG && max_rdeg <= 36) return (int)fixed;   // posteriors in registers
     return b <= (size_t)QD_LDS_BYTES - 1024 ? (int)b : 0;
 }
 
@@ -554,16 +608,18 @@ hipError_t qd_launch_bp_ps_lds(const GenGraphDev &g, const BpGraphDev &bg, const
     if (lds == 0) return hipErrorInvalidValue;
     const bool wide = bg.max_rdeg > 36;
     const bool small = g.nnz <= 9000;           // threads per shot: 256 for the W = 3 windows (6624 edges: 14.1 vs 18.0 ms per launch), 512 beyond (W = 5: 28.6 vs 44.5 ms)
+    const bool regs = (size_t)lds == ((size_t)((g.nnz + 3) & ~3) + ((g.m + 3) & ~3) + 64) * 4;
     const dim3 grid((unsigned)B);
-#define QD_PSL(D_, T_)                                                                                                      \
+#define QD_PSL(D_, T_, N_)                                                                                                  \
     {                                                                                                                       \
-        hipError_t e = hipFuncSetAttribute((const void *)qd_bp_ps_lds_kernel<D_, T_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipError_t e = hipFuncSetAttribute((const void *)qd_bp_ps_lds_kernel<D_, T_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         if (e != hipSuccess) return e;                                                                                      \
-        hipLaunchKernelGGL((qd_bp_ps_lds_kernel<D_, T_>), grid, dim3(T_), (size_t)lds, s, g, g.rp, g.cp, g.ri, g.c2r, g.llr0, bg.bit_slot_of, g.erow, \
+        hipLaunchKernelGGL((qd_bp_ps_lds_kernel<D_, T_, N_>), grid, dim3(T_), (size_t)lds, s, g, g.rp, g.cp, g.ri, g.c2r, g.llr0, bg.bit_slot_of, g.erow, \
                            reinterpret_cast<const uint4 *>(g.frec), bg.n_pad, a);                                           \
     }
-    if (wide) { if (small) QD_PSL(56, 256) else QD_PSL(56, 512) }
-    else { if (small) QD_PSL(36, 256) else QD_PSL(36, 512) }
+    if (regs) QD_PSL(36, QD_PSL_BIG_T, QD_PSL_BIG_NREG)
+    else if (wide) { if (small) QD_PSL(56, 256, 0) else QD_PSL(56, 512, 0) }
+    else { if (small) QD_PSL(36, 256, 0) else QD_PSL(36, 512, 0) }
 #undef QD_PSL
     return hipGetLastError();
 }
@@ -592,16 +648,18 @@ __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__rest
     }
 }
 
-#ifndef QD_GEN_GS
-#define QD_GEN_GS 4           // wavefronts per 64 shots in the serial schedule (faults of one dependency level in parallel)
-#endif
 #define QD_GEN_G 8            // wavefronts per 64 shots in the flooding schedule
 
 template <int METHOD, int SCHED, int G, int D>
 static hipError_t launch_kd(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
 {
-    hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D>), dim3((unsigned)((nshots + 63) / 64)), dim3(64 * G), 0, s, g, g.rp, g.ci,
-                       g.cp, g.ri, g.c2r, g.llr0, g.lvl_ptr, g.lvl_bits, a, w, shot0, nshots);
+    const dim3 grid((unsigned)((nshots + 63) / 64)), block(64 * G);
+    if (SCHED == QD_SCHEDULE_SERIAL && g.nslots > 0)
+        hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D, SCHED == QD_SCHEDULE_SERIAL>), grid, block, (size_t)g.nslots * 256, s, g, g.rp, g.ci,
+                           g.cp, g.ri, g.c2r, g.llr0, g.srec, a, w, shot0, nshots);
+    else
+        hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D, false>), grid, block, 0, s, g, g.rp, g.ci,
+                           g.cp, g.ri, g.c2r, g.llr0, g.srec, a, w, shot0, nshots);
     return hipGetLastError();
 }
 

@@ -11,6 +11,8 @@
 #include <numeric>
 #include <vector>
 
+#define QD_GEN_PREFIX_LDS (32 * 1024)   // LDS a workgroup of the serial BP kernel may spend on row prefixes (128 slots x 64 shots): five workgroups per CU stay resident
+
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
                                 int schedule, int64_t shot0, int nshots, hipStream_t s);
@@ -365,8 +367,55 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             for (int l = 0; l < nlev; ++l) lp[l + 1] += lp[l];
             std::vector<int32_t> fillp(lp.begin(), lp.end() - 1);
             for (int j = 0; j < n; ++j) lb[fillp[lev[j]]++] = j;
-            gg.nlev = nlev;
-            rcg |= g->mem.upload(lp, &gg.lvl_ptr); rcg |= g->mem.upload(lb, &gg.lvl_bits);
+            // LDS slots of the rows' running prefixes (see GenGraphDev): a slot is handed on only to a row that starts strictly
+            // after its previous owner's last level (two faults of one level touch their rows in any order)
+            std::vector<int32_t> first(m, nlev), lastl(m, -1), slot(m, 0), order(m);
+            for (int i = 0; i < m; ++i)
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+                    first[i] = std::min(first[i], lev[col_idx[e]]);
+                    lastl[i] = std::max(lastl[i], lev[col_idx[e]]);
+                }
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+            std::vector<int32_t> busy_until;                // per slot: last level of its current owner
+            for (int i : order) {
+                int sidx = -1;
+                for (size_t q = 0; q < busy_until.size(); ++q)
+                    if (busy_until[q] < first[i]) { sidx = (int)q; break; }
+                if (sidx < 0) { sidx = (int)busy_until.size(); busy_until.push_back(-1); }
+                busy_until[sidx] = lastl[i];
+                slot[i] = sidx;
+            }
+            gg.nslots = ((int)busy_until.size() * 256 <= QD_GEN_PREFIX_LDS && m < (1 << 23) && !std::getenv("QD_NO_LDS_PREFIX")) ? (int)busy_until.size() : 0;
+            // one record per (step, wavefront): see GenGraphDev
+            const int G = QD_GEN_GS, D = max_cdeg <= 4 ? 4 : (max_cdeg <= 8 ? 8 : QD_MAX_COL_DEG);
+            const int RW = (2 + 2 * D + 3) & ~3;
+            size_t nstep = 0;
+            for (int l = 0; l < nlev; ++l) nstep += (size_t)(lp[l + 1] - lp[l] + G - 1) / G;
+            std::vector<uint32_t> srec(nstep * G * RW, 0u);
+            size_t st = 0;
+            for (int l = 0; l < nlev; ++l) {
+                const int cnt = lp[l + 1] - lp[l], steps = (cnt + G - 1) / G;
+                for (int q = 0; q < steps; ++q, ++st)
+                    for (int wv = 0; wv < G; ++wv) {
+                        uint32_t *r = &srec[(st * G + wv) * RW];
+                        const uint32_t bar = (q == steps - 1) ? 0x80000000u : 0u;
+                        const int x = q * G + wv;
+                        if (x >= cnt) { r[0] = bar; continue; }
+                        const int j = lb[lp[l] + x], c0 = cp[j], deg = cp[j + 1] - c0;
+                        r[0] = (uint32_t)j | ((uint32_t)deg << 24) | bar;
+                        std::memcpy(&r[1], &l0[j], 4);
+                        for (int k = 0; k < deg; ++k) {
+                            const int i = ri[c0 + k];
+                            r[2 + k] = (uint32_t)i;
+                            if (gg.nslots > 0) r[2 + k] |= ((uint32_t)slot[i] << 24) | (col_idx[row_ptr[i]] == j ? 0x800000u : 0u);
+                            r[2 + D + k] = (uint32_t)c2r[c0 + k];
+                        }
+                    }
+            }
+            gg.nlev = nlev; gg.nstep = (int)nstep; gg.srec_w = RW;
+            if (n >= (1 << 24)) { g->mem.release(); delete g; return fail(QD_EINVAL, "more than 2^24 faults"); }
+            rcg |= g->mem.upload(srec, &gg.srec);
         }
         if (rcg) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while building the graph"); }
     }
@@ -735,7 +784,8 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         const bool ps = d->prm.bp_method == QD_BP_PRODUCT_SUM, serial = d->prm.schedule == QD_SCHEDULE_SERIAL;
         // edge planes: flooding b2c + c2b (+ th for product-sum); serial: messages (th or b2c) + suffixes (the c2b plane), and a row plane
         const int planes = serial ? 2 : (ps ? 3 : 2);
-        const size_t per_shot = ((size_t)g->nnz * planes + g->n + (serial ? g->m : 0)) * sizeof(float) + g->m + sizeof(int32_t);
+        const bool pre_plane = serial && g->gen.nslots == 0;       // the rows' running prefixes: LDS slots when the graph allows
+        const size_t per_shot = ((size_t)g->nnz * planes + g->n + (pre_plane ? g->m : 0)) * sizeof(float) + g->m + sizeof(int32_t);
         // Default budget 48 GB of the 288: the kernel is latency-bound (one wavefront per 64 shots), so a launch costs about
         // the same for 8 K or 64 K shots and chunks should be as large as memory allows -- and of equal size.
         double budget_gb = 48.0;
@@ -750,7 +800,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         if (!(ps && serial)) HIP_TRY(hipMalloc((void **)&w.b2c, sizeof(float) * (size_t)g->nnz * S));
         HIP_TRY(hipMalloc((void **)&w.c2b, sizeof(float) * (size_t)g->nnz * S));
         if (ps) HIP_TRY(hipMalloc((void **)&w.th, sizeof(float) * (size_t)g->nnz * S));
-        if (serial) HIP_TRY(hipMalloc((void **)&w.pre, sizeof(float) * (size_t)g->m * S));
+        if (pre_plane) HIP_TRY(hipMalloc((void **)&w.pre, sizeof(float) * (size_t)g->m * S));
         HIP_TRY(hipMalloc((void **)&w.llr, sizeof(float) * (size_t)g->n * S));
         HIP_TRY(hipMalloc((void **)&w.syn, (size_t)g->m * S));
         HIP_TRY(hipMalloc((void **)&w.slot, sizeof(int32_t) * (size_t)S));

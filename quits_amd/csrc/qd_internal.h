@@ -40,6 +40,9 @@ struct BpGraphDev {
 
 
 // The general (one message per edge) BP kernel's view: plain CSR + CSC in fault / detector order, prior LLRs in float.
+#ifndef QD_GEN_GS
+#define QD_GEN_GS 4           // wavefronts per 64 shots in the serial schedule (faults of one dependency level in parallel)
+#endif
 struct GenGraphDev {
     int m, n, nnz, out_words;
     const int32_t *rp, *ci;     // [m + 1], [nnz]   CSR, columns ascending in a row
@@ -54,9 +57,20 @@ struct GenGraphDev {
     // serial schedule: faults grouped into dependency levels.  Two faults that share no check commute, so natural order
     // is reproduced by any order that keeps every pair of faults with a common check in index order; level(j) = 1 + the
     // highest level among earlier faults on j's checks.  Faults of one level are mutually independent.
-    int nlev;
-    const int32_t *lvl_ptr;     // [nlev + 1]
-    const int32_t *lvl_bits;    // [n]              faults by level, ascending index inside a level
+    // The G = QD_GEN_GS wavefronts that share 64 shots take the faults of a level in parallel, one barrier per level.  What a
+    // wavefront needs to know about its next fault -- index, weight, prior LLR, the rows and CSR edges of its column -- is ONE record
+    // of srec_w dwords, read with one scalar load a whole step ahead (the adjacency arrays cost 3 + 2 * weight dependent scalar
+    // round trips per fault):  srec[(step * G + wavefront) * srec_w + ...] =
+    //   [0] fault | weight << 24 | (barrier after this step) << 31     (weight 0: nothing to do in this step)
+    //   [1] prior LLR (float bits)      [2 .. 2 + D) rows      [2 + D .. 2 + 2 D) CSR edges      D = 4, 8 or QD_MAX_COL_DEG
+    int nlev, nstep, srec_w;
+    const uint32_t *srec;       // [nstep][G][srec_w]
+    // Row i's running prefix is live from the level of its first fault to the level of its last; rows whose intervals do not
+    // overlap share one of `nslots` LDS slots (64 floats each; greedy interval colouring = the minimum), so the 8 bytes per
+    // edge and sweep the prefixes would move through HBM stay on the CU.  Then a row entry of a record is
+    //   row | (first entry of its row: the prefix starts at +-1 / +-max, sign = syndrome bit) << 23 | slot << 24.
+    // nslots = 0: too many slots for the LDS budget, the prefixes live in the [m][S] plane GenWs::pre and the entry is the row.
+    int nslots;
 };
 // ... and its per-chunk workspace, [index][shot] with S shots per row
 struct GenWs {

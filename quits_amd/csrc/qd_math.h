@@ -3,10 +3,15 @@
  * ldpc's product-sum check update (src_cpp/bp.hpp; call sites quits/decoder/sliding_window.py:149,171) evaluates
  *      tanh(b2c / 2)           and          log((1 + x) / (1 - x))
  * in double through libm.  The device path computes in float, and a libm result is not reproducible across a CPU and a
- * GPU math library, so both the HIP kernel (quits_amd/csrc/bp_general.hip) and its CPU mirror (oracle/bp_core.inc with
- * REAL = float) evaluate the same expressions below: additions, multiplications, correctly rounded divisions, floorf
- * and bit casts, in a fixed order, compiled with -ffp-contract=off on both sides.  Same input bits -> same output bits.
- * tests/test_oracle.py checks them against libm in double (a few ulp) so that sharing them cannot hide an error.
+ * GPU math library, so both the HIP kernel (quits_amd/csrc/bp_general.hip) and its CPU mirror (oracle/oq_math.h, written
+ * independently from the description there) evaluate the same expressions: additions, multiplications, FUSED multiply-adds
+ * (fmaf, one rounding), correctly rounded divisions, floorf and bit casts, in a fixed order, compiled with
+ * -ffp-contract=off on both sides so that nothing else is fused.  Same input bits -> same output bits.
+ * tests/test_oracle.py checks them against libm in double so that mirroring them cannot hide an error.
+ *
+ * Both functions are ONE straight line of code (round 3): a wavefront whose lanes are shots or edges takes both sides of
+ * every data-dependent branch, so the two-branch forms of rounds 1-2 (polynomial near zero, exp / log elsewhere) cost the
+ * sum of their branches -- ~125 instructions per edge against ~70 here (one division each).
  *
  * Float-specific conventions (documented deviations from the double arithmetic of ldpc):
  *   - tanh saturates to 1 in float for |x/2| > 9; the result is clamped to +-(1 - 2^-24) so that (1+x)/(1-x) stays
@@ -39,78 +44,62 @@ QD_MATH_FN float qd_u2f(uint32_t x)
 
 #define QD_TANH_MAX 0.99999994f /* 1 - 2^-24, the largest float below 1 */
 
-/* tanh(x / 2) */
+/* tanh(x / 2) = (e^a - 1) / (e^a + 1), a = |x|:  e^a - 1 = 2^k (1 + expm1(r)) - 1 with a = k ln2 + r (Cody-Waite), expm1(r) =
+ * r (1 + r/2 + ... + r^6/5040) for |r| <= ln2 / 2.  For k = 0 this is expm1(r) itself: no cancellation near zero. */
 QD_MATH_FN float qd_tanh_half(float x)
 {
     const float ax = qd_u2f(qd_f2u(x) & 0x7FFFFFFFu);
     const uint32_t sign = qd_f2u(x) & 0x80000000u;
-    float t;
-    if (!(ax >= 0.5f)) {
-        /* |x/2| < 1/4: odd Taylor polynomial of tanh, Horner in h^2 (next term 3e-10 relative) */
-        const float h = ax * 0.5f;
-        const float h2 = h * h;
-        float p = -0.0088632355f;          /* -1382/155925 */
-        p = p * h2 + 0.021869488f;         /*  62/2835     */
-        p = p * h2 + -0.053968254f;        /* -17/315      */
-        p = p * h2 + 0.13333334f;          /*  2/15        */
-        p = p * h2 + -0.33333334f;         /* -1/3         */
-        p = p * h2 + 1.0f;
-        t = h * p;
-    } else {
-        /* tanh(x/2) = 1 - 2 / (e^x + 1), e^x by Cody-Waite reduction and a degree-6 polynomial */
-        const float a = ax > 40.0f ? 40.0f : ax;
-        const float kf = floorf(a * 1.4426950f + 0.5f);
-        float r = a - kf * 0.693145752f;   /* ln2 high part (exact product for |k| < 2^11) */
-        r = r - kf * 1.42860677e-06f;      /* ln2 low part  */
-        float p = 0.0013888889f;           /* 1/720 */
-        p = p * r + 0.008333334f;          /* 1/120 */
-        p = p * r + 0.041666668f;          /* 1/24  */
-        p = p * r + 0.16666667f;           /* 1/6   */
-        p = p * r + 0.5f;
-        p = p * r + 1.0f;
-        p = p * r + 1.0f;
-        const float e = p * qd_u2f((uint32_t)((int)kf + 127) << 23);
-        t = 1.0f - 2.0f / (e + 1.0f);
-        if (t > QD_TANH_MAX) t = QD_TANH_MAX;
-    }
+    const float a = ax > 40.0f ? 40.0f : ax;
+    const float kf = floorf(fmaf(a, 1.4426950f, 0.5f));
+    float r = fmaf(kf, -0.693145752f, a);  /* ln2 high part (exact product for |k| < 2^11) */
+    r = fmaf(kf, -1.42860677e-06f, r);     /* ln2 low part  */
+    float p = 1.9841270e-04f;              /* 1/5040 */
+    p = fmaf(p, r, 0.0013888889f);         /* 1/720  */
+    p = fmaf(p, r, 0.008333334f);          /* 1/120  */
+    p = fmaf(p, r, 0.041666668f);          /* 1/24   */
+    p = fmaf(p, r, 0.16666667f);           /* 1/6    */
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    const float em1r = r * p;                                              /* expm1(r) */
+    const float two_k = qd_u2f((uint32_t)((int)kf + 127) << 23);           /* 2^k, k in [0, 58] */
+    const float em1 = fmaf(em1r, two_k, two_k - 1.0f);                     /* e^a - 1 */
+    float t = em1 / (em1 + 2.0f);
+    if (t > QD_TANH_MAX) t = QD_TANH_MAX;
     return qd_u2f(qd_f2u(t) | sign);
 }
 
-/* log((1 + c) / (1 - c)) = 2 atanh(c) for |c| <= 1 - 2^-24 */
+/* x = 2^k m with m in [sqrt(1/2), sqrt 2) for a positive normal x: adding (1 - sqrt(1/2)) in units of the last place to the
+ * bit pattern carries into the exponent exactly when the mantissa is at least sqrt 2 */
+#define QD_SQRT_HALF_BITS 0x3F3504F3u
+QD_MATH_FN float qd_split_sqrt2(float x, int *k)
+{
+    const uint32_t b = qd_f2u(x) + (0x3F800000u - QD_SQRT_HALF_BITS);
+    *k = (int)(b >> 23);                                                   /* biased; only differences are used */
+    return qd_u2f((b & 0x007FFFFFu) + QD_SQRT_HALF_BITS);
+}
+
+/* log((1 + c) / (1 - c)) = 2 atanh(c) for |c| <= 1 - 2^-24:  1 + c = 2^ku mu, 1 - c = 2^kv mv with mu, mv in [sqrt(1/2), sqrt 2),
+ * so the ratio is 2^(ku-kv) (1 + s) / (1 - s) with s = (mu - mv) / (mu + mv), |s| <= 1/3, and the result
+ * (ku - kv) ln2 + 2 atanh(s).  When ku = kv (|c| < 0.17 at least) s is c itself, exactly: no division error, no cancellation. */
 QD_MATH_FN float qd_log_ratio(float c)
 {
-    const float ac = qd_u2f(qd_f2u(c) & 0x7FFFFFFFu);
-    if (!(ac > 0.171875f)) {
-        /* (q - 1) / (q + 1) = c exactly, so the atanh series applies to c itself: no division, no cancellation */
-        const float c2 = c * c;
-        float p = 0.15384616f;             /* 2/13 */
-        p = p * c2 + 0.18181819f;          /* 2/11 */
-        p = p * c2 + 0.22222222f;          /* 2/9  */
-        p = p * c2 + 0.2857143f;           /* 2/7  */
-        p = p * c2 + 0.4f;                 /* 2/5  */
-        p = p * c2 + 0.6666667f;           /* 2/3  */
-        p = p * c2 + 2.0f;
-        return c * p;
-    }
-    const float q = (1.0f + c) / (1.0f - c);      /* in [2^-25, 2^25]: positive and normal */
-    const uint32_t qb = qd_f2u(q);
-    int e = (int)((qb >> 23) & 255u) - 127;
-    float m = qd_u2f((qb & 0x007FFFFFu) | 0x3F800000u);          /* [1, 2) */
-    if (m > 1.4142135f) {
-        m = m * 0.5f;
-        e += 1;
-    }
-    const float s = (m - 1.0f) / (m + 1.0f);      /* |s| <= 0.1716 */
+    int ku, kv;
+    const float mu = qd_split_sqrt2(1.0f + c, &ku);
+    const float mv = qd_split_sqrt2(1.0f - c, &kv);
+    float s = (mu - mv) / (mu + mv);
+    if (ku == kv) s = c;
     const float s2 = s * s;
-    float p = 0.15384616f;
-    p = p * s2 + 0.18181819f;
-    p = p * s2 + 0.22222222f;
-    p = p * s2 + 0.2857143f;
-    p = p * s2 + 0.4f;
-    p = p * s2 + 0.6666667f;
-    p = p * s2 + 2.0f;
-    const float ef = (float)e;
-    return ef * 0.693145752f + (s * p + ef * 1.42860677e-06f);
+    float p = 0.13333334f;                 /* 2/15 */
+    p = fmaf(p, s2, 0.15384616f);          /* 2/13 */
+    p = fmaf(p, s2, 0.18181819f);          /* 2/11 */
+    p = fmaf(p, s2, 0.22222222f);          /* 2/9  */
+    p = fmaf(p, s2, 0.2857143f);           /* 2/7  */
+    p = fmaf(p, s2, 0.4f);                 /* 2/5  */
+    p = fmaf(p, s2, 0.6666667f);           /* 2/3  */
+    p = fmaf(p, s2, 2.0f);
+    const float ef = (float)(ku - kv);
+    return fmaf(ef, 0.693145752f, fmaf(s, p, ef * 1.42860677e-06f));
 }
 
 #endif
