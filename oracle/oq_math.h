@@ -1,21 +1,22 @@
-/* oq_math.h -- the oracle's own float tanh(x/2) and log((1+c)/(1-c)).
+/* oq_math.h -- the oracle's own float functions for the product-sum check update.
  *
- * TEST INFRASTRUCTURE ONLY.  ldpc's product-sum update (bp.hpp) evaluates both in double through libm; the device computes in
- * float, where a libm result is not reproducible, so the HIP kernel (quits_amd/csrc/qd_math.h) builds them from IEEE basic
- * operations in a fixed order.  This file restates that arithmetic independently -- written from the description below, not
- * included from the product -- so that the checker and the product share no code; tests/test_oracle.py holds both to libm in
- * double (a few ulp), and the GPU parity tests hold the kernel to this file bit for bit.  Compile with -ffp-contract=off.
+ * TEST INFRASTRUCTURE ONLY.  ldpc's product-sum update (bp.hpp) evaluates tanh(b2c / 2), a product over a row and
+ * log((1 + P) / (1 - P)) in double through libm.  The device computes in float, where tanh(x / 2) is 1 beyond |x| = 17.3, so it
+ * keeps u = e^-|x| = (1 - t) / (1 + t) instead of t = tanh(|x| / 2) (quits_amd/csrc/qd_math.h explains why): a product of tanh
+ * values t1 t2 is u12 = (u1 + u2) / (1 + u1 u2), and log((1 + P) / (1 - P)) = -log(u).  A libm result is not reproducible on
+ * the GPU, so the kernel builds the three functions from IEEE basic operations in a fixed order.  This file restates that
+ * arithmetic independently -- written from the description below, not included from the product -- so that the checker and
+ * the product share no code; tests/test_oracle.py holds both to libm in double, and the GPU parity tests hold the kernel to
+ * this file bit for bit.  Compile with -ffp-contract=off.
  *
- *   Every "x*y + z" below that is written fma(x, y, z) is ONE rounding (C99 fmaf); nothing else is fused (-ffp-contract=off).
+ *   Every "x*y + z" below that is written fma(x, y, z) is ONE rounding (C99 fmaf); nothing else is fused.
  *
- *   tanh(x/2), a = min(|x|, 40):  k = floor(fma(a, log2(e), 1/2)),  r = fma(k, -ln2_lo, fma(k, -ln2_hi, a)),
- *                         E = r * P(r), P = Horner by fma of 1 + r/2 + r^2/6 + ... + r^6/5040        (E = expm1(r)),
- *                         D = fma(E, 2^k, 2^k - 1)   (= e^a - 1),   t = D / (D + 2), capped at 1 - 2^-24; sign restored
- *   log((1+c)/(1-c)):     split 1+c = 2^ku mu and 1-c = 2^kv mv with mu, mv in [sqrt(1/2), sqrt 2): adding 0x3F800000 - 0x3F3504F3 to
- *                         the bit pattern carries into the exponent field exactly when the mantissa reaches sqrt 2;
- *                         s = (mu - mv) / (mu + mv), replaced by c itself when ku = kv (it is c, exactly, in that case);
- *                         result = fma(e, ln2_hi, fma(s, Q(s^2), e * ln2_lo)),  e = ku - kv,
- *                         Q = Horner by fma of 2 + 2z/3 + 2z^2/5 + ... + 2z^7/15            (s Q(s^2) = 2 atanh(s), |s| <= 1/3)
+ *   E(x) = +-e^-a, a = min(|x|, 87), sign bit of x:   k = floor(fma(a, log2(e), 1/2)),  z = fma(k, ln2_lo, fma(k, ln2_hi, -a))  (= -r),
+ *                         M = z * P(z), P = Horner by fma of 1 + z/2 + z^2/6 + ... + z^6/5040     (M = expm1(z)),   E = fma(M, 2^-k, 2^-k)
+ *   C(a, b) = min(1, (a + b) / fma(a, b, 1))          for a, b in [0, 1]
+ *   L(u) = -log(max(u, 2^-126)):  split u = 2^k m with m in [sqrt(1/2), sqrt 2) (adding 0x3F800000 - 0x3F3504F3 to the bit pattern
+ *                         carries into the exponent field exactly when the mantissa reaches sqrt 2),  s = (m - 1) / (m + 1),
+ *                         L = 0 - fma(k, ln2_hi, fma(s, Q(s^2), k * ln2_lo)),   Q = Horner by fma of 2 + 2y/3 + 2y^2/5 + ... + 2y^6/13
  */
 #ifndef OQ_MATH_H
 #define OQ_MATH_H
@@ -35,36 +36,33 @@ static inline float oq_horner_fma(const float *c, int terms, float z)
     return p;
 }
 
-static inline float oq_tanh_half_f32(float x)
+static inline float oq_exp_neg_f32(float x)
 {
-    static const float expm1_over_r[7] = {1.9841270e-04f, 0.0013888889f, 0.008333334f, 0.041666668f, 0.16666667f, 0.5f, 1.0f};   /* 1/7!, ..., 1/2!, 1 */
+    static const float expm1_over_z[7] = {1.9841270e-04f, 0.0013888889f, 0.008333334f, 0.041666668f, 0.16666667f, 0.5f, 1.0f};   /* 1/7!, ..., 1/2!, 1 */
     const uint32_t xb = oq_bits(x);
     float a = oq_float(xb & 0x7FFFFFFFu);
-    if (a > 40.0f) a = 40.0f;
+    if (a > 87.0f) a = 87.0f;
     const float k = floorf(fmaf(a, 1.4426950f, 0.5f));
-    const float r = fmaf(k, -OQ_LN2_LO, fmaf(k, -OQ_LN2_HI, a));
-    const float E = r * oq_horner_fma(expm1_over_r, 7, r);
-    const float pow2k = oq_float((uint32_t)((int)k + 127) << 23);
-    const float D = fmaf(E, pow2k, pow2k - 1.0f);
-    float t = D / (D + 2.0f);
-    if (t > 0.99999994f) t = 0.99999994f;
-    return oq_float(oq_bits(t) | (xb & 0x80000000u));
+    const float z = fmaf(k, OQ_LN2_LO, fmaf(k, OQ_LN2_HI, -a));
+    const float M = z * oq_horner_fma(expm1_over_z, 7, z);
+    const float scale = oq_float((uint32_t)(127 - (int)k) << 23);
+    return oq_float(oq_bits(fmaf(M, scale, scale)) | (xb & 0x80000000u));
 }
 
-static inline float oq_mantissa_sqrt2(float x, int *exponent)      /* x > 0 normal: x = 2^(exponent - bias) * result, result in [sqrt(1/2), sqrt 2) */
+static inline float oq_ucomb_f32(float a, float b)
 {
-    const uint32_t shifted = oq_bits(x) + (0x3F800000u - 0x3F3504F3u);
-    *exponent = (int)(shifted >> 23);
-    return oq_float((shifted & 0x007FFFFFu) + 0x3F3504F3u);
+    const float q = (a + b) / fmaf(a, b, 1.0f);
+    return q > 1.0f ? 1.0f : q;
 }
 
-static inline float oq_log_ratio_f32(float c)
+static inline float oq_neg_log_f32(float u)
 {
-    static const float atanh2_over_s[8] = {0.13333334f, 0.15384616f, 0.18181819f, 0.22222222f, 0.2857143f, 0.4f, 0.6666667f, 2.0f};   /* 2/15, 2/13, ..., 2/3, 2 */
-    int ku, kv;
-    const float mu = oq_mantissa_sqrt2(1.0f + c, &ku), mv = oq_mantissa_sqrt2(1.0f - c, &kv);
-    const float s = (ku == kv) ? c : (mu - mv) / (mu + mv);
-    const float ef = (float)(ku - kv);
-    return fmaf(ef, OQ_LN2_HI, fmaf(s, oq_horner_fma(atanh2_over_s, 8, s * s), ef * OQ_LN2_LO));
+    static const float atanh2_over_s[7] = {0.15384616f, 0.18181819f, 0.22222222f, 0.2857143f, 0.4f, 0.6666667f, 2.0f};   /* 2/13, ..., 2/3, 2 */
+    if (u < 1.17549435e-38f) u = 1.17549435e-38f;
+    const uint32_t shifted = oq_bits(u) + (0x3F800000u - 0x3F3504F3u);
+    const float k = (float)((int)(shifted >> 23) - 127);
+    const float m = oq_float((shifted & 0x007FFFFFu) + 0x3F3504F3u);
+    const float s = (m - 1.0f) / (m + 1.0f);
+    return 0.0f - fmaf(k, OQ_LN2_HI, fmaf(s, oq_horner_fma(atanh2_over_s, 7, s * s), k * OQ_LN2_LO));
 }
 #endif

@@ -79,6 +79,8 @@ def lib():
         f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
         L.oq_math_f32.argtypes = [C.c_int, f32p, f32p, C.c_int64]
         L.oq_math_f32.restype = None
+        L.oq_math_ucomb_f32.argtypes = [f32p, f32p, f32p, C.c_int64]
+        L.oq_math_ucomb_f32.restype = None
         _LIB = L
     return _LIB
 
@@ -311,9 +313,15 @@ def sample_dem(H_csc, L_csc, priors, seed, shot0, B):
     return synd, obs, nf
 
 
-def math_f32(kind: str, x):
-    """The float tanh(x/2) ('tanh_half') / log((1+c)/(1-c)) ('log_ratio') the f32 product-sum forms evaluate."""
+def math_f32(kind: str, x, x2=None):
+    """The float functions of the f32 product-sum forms (oq_math.h): 'exp_neg' (+-e^-|x|, sign of x), 'neg_log' (-log(u)),
+    'ucomb' ((a + b) / (1 + a b), two arguments)."""
     x = np.ascontiguousarray(x, np.float32)
     y = np.empty_like(x)
-    lib().oq_math_f32(0 if kind == "tanh_half" else 1, x, y, x.size)
+    if kind == "ucomb":
+        x2 = np.ascontiguousarray(x2, np.float32)
+        assert x2.shape == x.shape
+        lib().oq_math_ucomb_f32(x, x2, y, x.size)
+    else:
+        lib().oq_math_f32({"exp_neg": 0, "neg_log": 1}[kind], x, y, x.size)
     return y

@@ -88,7 +88,23 @@ static double g_max_s = 0.0;
 /* the oracle's float functions, exposed so that tests can compare them with libm in double and with the product's */
 void oq_math_f32(int kind, const float *x, float *y, int64_t count)
 {
-    for (int64_t i = 0; i < count; i++) y[i] = kind == 0 ? oq_tanh_half_f32(x[i]) : oq_log_ratio_f32(x[i]);
+    for (int64_t i = 0; i < count; i++) y[i] = kind == 0 ? oq_exp_neg_f32(x[i]) : oq_neg_log_f32(x[i]);
+}
+void oq_math_ucomb_f32(const float *a, const float *b, float *y, int64_t count)
+{
+    for (int64_t i = 0; i < count; i++) y[i] = oq_ucomb_f32(a[i], b[i]);
+}
+
+/* signed u values: magnitude in [0, 1], the sign bit is the sign of the tanh it stands for */
+static inline float oq_u_comb_signed(float a, float b)
+{
+    const uint32_t sg = (oq_bits(a) ^ oq_bits(b)) & 0x80000000u;
+    return oq_float(oq_bits(oq_ucomb_f32(fabsf(a), fabsf(b))) | sg);
+}
+static inline float oq_u_llr(float z, int syndrome_bit)      /* the check->bit message of a row product z: +-(-log|z|) */
+{
+    const uint32_t sg = (oq_bits(z) & 0x80000000u) ^ ((uint32_t)(syndrome_bit != 0) << 31);
+    return oq_float(oq_bits(oq_neg_log_f32(fabsf(z))) ^ sg);
 }
 
 /* ---------------------------------------------------------------------------------------------------------- */
@@ -190,9 +206,12 @@ void oq_graph_destroy(oq_graph *g)
 #define OQ_SERIAL_PRESUF
 #define REAL_MAX FLT_MAX
 #define REAL_ABS fabsf
-#define REAL_TANH_HALF(x) oq_tanh_half_f32(x)
-#define REAL_LOG_RATIO(c) oq_log_ratio_f32(c)
+#define OQ_UDOMAIN
+#define U_OF_LLR(x) oq_exp_neg_f32(x)
+#define U_COMB(a, b) oq_u_comb_signed(a, b)
+#define U_LLR(z, sy) oq_u_llr(z, sy)
 #include "bp_core.inc"
+#undef OQ_UDOMAIN
 #undef REAL
 #undef SFX
 #undef REAL_MAX

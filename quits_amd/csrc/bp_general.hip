@@ -38,6 +38,20 @@
 
 #define QD_GEN_MLP 8          // loads of one row issued together (the arithmetic that follows keeps bp.hpp's order)
 
+// Product-sum values travel as signed u (qd_math.h): magnitude e^-|b2c| = (1 - t) / (1 + t) of t = tanh(|b2c| / 2), sign bit = sign of the tanh.
+// u of a product of two tanh values:
+__device__ __forceinline__ float qd_ucomb_s(float a, float b)
+{
+    const uint32_t sg = (__float_as_uint(a) ^ __float_as_uint(b)) & 0x80000000u;
+    return __uint_as_float(__float_as_uint(qd_ucomb(fabsf(a), fabsf(b))) | sg);
+}
+// the check->bit message of a row product z: +-(-log |z|), negated once more by the syndrome bit
+__device__ __forceinline__ float qd_u_llr(float z, uint32_t syndrome_bit)
+{
+    const uint32_t sg = (__float_as_uint(z) & 0x80000000u) ^ (syndrome_bit << 31);
+    return __uint_as_float(__float_as_uint(qd_neg_log(fabsf(z))) ^ sg);
+}
+
 // per-lane OR across the G wavefronts of the workgroup (every wavefront gets the result)
 template <int G>
 __device__ __forceinline__ uint32_t qd_lanes_or(uint32_t v, uint32_t (*red)[64], int wv, int lane)
@@ -111,7 +125,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
             const float l0 = llr0[j];
             for (int e = cp[j]; e < cp[j + 1]; ++e) {
                 const size_t ce = (size_t)c2r[e] * S;
-                if (METHOD == QD_BP_PRODUCT_SUM && SCHED == QD_SCHEDULE_SERIAL) th[ce] = qd_tanh_half(l0);
+                if (METHOD == QD_BP_PRODUCT_SUM && SCHED == QD_SCHEDULE_SERIAL) th[ce] = qd_exp_neg(l0);
                 else b2c[ce] = l0;
             }
         }
@@ -128,8 +142,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                 const int r0 = rp[i], r1 = rp[i + 1];
                 const uint32_t si = syn[(size_t)i * S];
                 if (METHOD == QD_BP_PRODUCT_SUM) {
-                    const float sgn = si ? -1.0f : 1.0f;
-                    float temp = 1.0f;
+                    float temp = 0.0f;                               // u of the empty product
                     int e = r0;
                     for (; e + QD_GEN_MLP <= r1; e += QD_GEN_MLP) {
                         float v[QD_GEN_MLP];
@@ -137,19 +150,19 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         for (int k = 0; k < QD_GEN_MLP; ++k) v[k] = b2c[(size_t)(e + k) * S];
 #pragma unroll
                         for (int k = 0; k < QD_GEN_MLP; ++k) {
-                            const float t = qd_tanh_half(v[k]);
+                            const float t = qd_exp_neg(v[k]);
                             th[(size_t)(e + k) * S] = t;
                             c2b[(size_t)(e + k) * S] = temp;
-                            temp = temp * t;
+                            temp = qd_ucomb_s(temp, t);
                         }
                     }
                     for (; e < r1; ++e) {
-                        const float t = qd_tanh_half(b2c[(size_t)e * S]);
+                        const float t = qd_exp_neg(b2c[(size_t)e * S]);
                         th[(size_t)e * S] = t;
                         c2b[(size_t)e * S] = temp;
-                        temp = temp * t;
+                        temp = qd_ucomb_s(temp, t);
                     }
-                    temp = 1.0f;
+                    temp = 0.0f;
                     e = r1 - 1;
                     for (; e - (QD_GEN_MLP - 1) >= r0; e -= QD_GEN_MLP) {
                         float vc[QD_GEN_MLP], vt[QD_GEN_MLP];
@@ -157,15 +170,13 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         for (int k = 0; k < QD_GEN_MLP; ++k) { vc[k] = c2b[(size_t)(e - k) * S]; vt[k] = th[(size_t)(e - k) * S]; }
 #pragma unroll
                         for (int k = 0; k < QD_GEN_MLP; ++k) {
-                            const float c = vc[k] * temp;
-                            c2b[(size_t)(e - k) * S] = sgn * qd_log_ratio(c);
-                            temp = temp * vt[k];
+                            c2b[(size_t)(e - k) * S] = qd_u_llr(qd_ucomb_s(vc[k], temp), si);
+                            temp = qd_ucomb_s(temp, vt[k]);
                         }
                     }
                     for (; e >= r0; --e) {
-                        const float c = c2b[(size_t)e * S] * temp;
-                        c2b[(size_t)e * S] = sgn * qd_log_ratio(c);
-                        temp = temp * th[(size_t)e * S];
+                        c2b[(size_t)e * S] = qd_u_llr(qd_ucomb_s(c2b[(size_t)e * S], temp), si);
+                        temp = qd_ucomb_s(temp, th[(size_t)e * S]);
                     }
                 } else {
                     int total_sgn = (int)si;
@@ -250,7 +261,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
             float *__restrict__ suf = c2b;
             for (int i = wv; active && i < g.m; i += G) {
                 const int r0 = rp[i], r1 = rp[i + 1];
-                float sm = METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG;
+                float sm = METHOD == QD_BP_PRODUCT_SUM ? 0.0f : BIG;
                 uint32_t par = 0u;
                 int e = r1 - 1;
                 for (; e - (QD_GEN_MLP - 1) >= r0; e -= QD_GEN_MLP) {
@@ -259,7 +270,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                     for (int k = 0; k < QD_GEN_MLP; ++k) v[k] = msg[(size_t)(e - k) * S];
 #pragma unroll
                     for (int k = 0; k < QD_GEN_MLP; ++k) {
-                        if (METHOD == QD_BP_PRODUCT_SUM) { suf[(size_t)(e - k) * S] = sm; sm = v[k] * sm; }
+                        if (METHOD == QD_BP_PRODUCT_SUM) { suf[(size_t)(e - k) * S] = sm; sm = qd_ucomb_s(v[k], sm); }
                         else {
                             suf[(size_t)(e - k) * S] = __uint_as_float(__float_as_uint(sm) | (par << 31));
                             const float av = fabsf(v[k]);
@@ -270,7 +281,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                 }
                 for (; e >= r0; --e) {
                     const float v = msg[(size_t)e * S];
-                    if (METHOD == QD_BP_PRODUCT_SUM) { suf[(size_t)e * S] = sm; sm = v * sm; }
+                    if (METHOD == QD_BP_PRODUCT_SUM) { suf[(size_t)e * S] = sm; sm = qd_ucomb_s(v, sm); }
                     else {
                         suf[(size_t)e * S] = __uint_as_float(__float_as_uint(sm) | (par << 31));
                         const float av = fabsf(v);
@@ -282,7 +293,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                 // factors' signs, so the check->bit sign needs no separate load per edge
                 if (!LP) {
                     const uint32_t sbit = (uint32_t)syn[(size_t)i * S] << 31;
-                    rpre[(size_t)i * S] = __uint_as_float(__float_as_uint(METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG) | sbit);
+                    rpre[(size_t)i * S] = __uint_as_float(__float_as_uint(METHOD == QD_BP_PRODUCT_SUM ? 0.0f : BIG) | sbit);
                 }
             }
             if (G > 1) __syncthreads();
@@ -313,7 +324,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         if (LP) {
                             const uint32_t rw = cur[2 + k];
                             if (rw & 0x800000u)      // first entry of its row: nothing refreshed yet
-                                P[k] = __uint_as_float(__float_as_uint(METHOD == QD_BP_PRODUCT_SUM ? 1.0f : BIG) |
+                                P[k] = __uint_as_float(__float_as_uint(METHOD == QD_BP_PRODUCT_SUM ? 0.0f : BIG) |
                                                        ((uint32_t)syn[(size_t)(rw & 0x7FFFFFu) * S] << 31));
                             else P[k] = pls[(rw >> 24) * 64 + lane];
                         } else P[k] = rpre[(size_t)cur[2 + k] * S];
@@ -323,7 +334,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                 for (int k = 0; k < D; ++k)
                     if (k < deg) {
                         float c;
-                        if (METHOD == QD_BP_PRODUCT_SUM) c = qd_log_ratio(P[k] * X[k]);
+                        if (METHOD == QD_BP_PRODUCT_SUM) c = qd_u_llr(qd_ucomb_s(P[k], X[k]), 0u);
                         else {
                             const float a1 = fabsf(P[k]), a2 = fabsf(X[k]);
                             const uint32_t sg = ((__float_as_uint(P[k]) >> 31) ^ (__float_as_uint(X[k]) >> 31)) & 1u;
@@ -343,9 +354,9 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
                         const float v = pr[k] + temp;
                         temp += cv[k];
                         if (METHOD == QD_BP_PRODUCT_SUM) {
-                            const float nt = qd_tanh_half(v);
+                            const float nt = qd_exp_neg(v);
                             msg[ce] = nt;
-                            *pdst = P[k] * nt;
+                            *pdst = qd_ucomb_s(P[k], nt);
                         } else {
                             msg[ce] = v;
                             const float a1 = fabsf(P[k]), av = fabsf(v);
@@ -466,32 +477,31 @@ __global__ void __launch_bounds__(T) qd_bp_ps_lds_kernel(GenGraphDev g, const in
         //   tanh(b2c / 2) per edge | forward / backward exclusive products per row | sign * log((1 + c) / (1 - c)) per edge
         // (fusing the two functions into the bit pass -- three barriers per iteration instead of five -- measured 15 % slower: a
         //  fault has 3.2 edges of the 8 a lane unrolls for)
-        for (int e = tid; e < g.nnz; e += T) msg[e] = qd_tanh_half(msg[e]);
+        for (int e = tid; e < g.nnz; e += T) msg[e] = qd_exp_neg(msg[e]);
         __syncthreads();
         for (int i = tid; i < g.m; i += T) {
             const int r0 = i == tid ? my_r0 : rp[i], deg = i == tid ? my_deg : rp[i + 1] - rp[i];
             float th[DEG];
-            float temp = 1.0f;
+            float temp = 0.0f;                                       // u of the empty product
 #pragma unroll
             for (int k = 0; k < DEG; ++k)
                 if (k < deg) {
                     const float t = msg[r0 + k];
                     th[k] = t;
                     msg[r0 + k] = temp;
-                    temp = temp * t;
+                    temp = qd_ucomb_s(temp, t);
                 }
-            temp = 1.0f;
+            temp = 0.0f;
 #pragma unroll
             for (int k = DEG - 1; k >= 0; --k)
                 if (k < deg) {
-                    msg[r0 + k] = msg[r0 + k] * temp;
-                    temp = temp * th[k];
+                    msg[r0 + k] = qd_ucomb_s(msg[r0 + k], temp);
+                    temp = qd_ucomb_s(temp, th[k]);
                 }
         }
         __syncthreads();
         for (int e = tid; e < g.nnz; e += T) {
-            const float sgn = (par[erow[e]] & 1u) ? -1.0f : 1.0f;
-            msg[e] = sgn * qd_log_ratio(msg[e]);
+            msg[e] = qd_u_llr(msg[e], par[erow[e]] & 1u);
         }
         __syncthreads();
         // ---- bit pass: posterior, then the prefix / suffix sums that make the outgoing messages.  A fault comes as one 32-byte

@@ -1,22 +1,22 @@
-/* qd_math.h -- the two elementary functions of product-sum BP, in float, built from IEEE basic operations only.
+/* qd_math.h -- the elementary functions of product-sum BP, in float, built from IEEE basic operations only.
  *
- * ldpc's product-sum check update (src_cpp/bp.hpp; call sites quits/decoder/sliding_window.py:149,171) evaluates
- *      tanh(b2c / 2)           and          log((1 + x) / (1 - x))
- * in double through libm.  The device path computes in float, and a libm result is not reproducible across a CPU and a
- * GPU math library, so both the HIP kernel (quits_amd/csrc/bp_general.hip) and its CPU mirror (oracle/oq_math.h, written
- * independently from the description there) evaluate the same expressions: additions, multiplications, FUSED multiply-adds
- * (fmaf, one rounding), correctly rounded divisions, floorf and bit casts, in a fixed order, compiled with
- * -ffp-contract=off on both sides so that nothing else is fused.  Same input bits -> same output bits.
- * tests/test_oracle.py checks them against libm in double so that mirroring them cannot hide an error.
- *
- * Both functions are ONE straight line of code (round 3): a wavefront whose lanes are shots or edges takes both sides of
- * every data-dependent branch, so the two-branch forms of rounds 1-2 (polynomial near zero, exp / log elsewhere) cost the
- * sum of their branches -- ~125 instructions per edge against ~70 here (one division each).
- *
- * Float-specific conventions (documented deviations from the double arithmetic of ldpc):
- *   - tanh saturates to 1 in float for |x/2| > 9; the result is clamped to +-(1 - 2^-24) so that (1+x)/(1-x) stays
- *     finite.  A check-to-bit message is therefore bounded by log(2^25) = 17.33 (a double reaches 37 before the same
- *     happens); posteriors are sums and are not clamped.
+ * ldpc's product-sum check update (src_cpp/bp.hpp; call sites quits/decoder/sliding_window.py:149,171) evaluates, in double
+ * through libm,       c2b(i -> j) = +- log((1 + P) / (1 - P)),   P = product over the other edges of tanh(b2c / 2).
+ * A float cannot hold tanh(x/2) beyond |x| = 17.3 (1 - 2 e^-x rounds to 1), so a float copy of that formula has to clamp the
+ * tanh at 1 - 2^-24 and caps every check->bit message at 17.33 where the double reaches 37.4 -- and that cap is measurable:
+ * it acts as a damping and LOWERS the logical error rate (rounds 1-3 of this repo: 127 against 139 failures of 2048 on the
+ * reference's HGP phenomenological example, -0.5 sigma / McNemar z = -2.7 on 400 000 headline shots; a double-precision run
+ * with the same clamp reproduces the float numbers, profiles/r03w_*).  So the device keeps, instead of t = tanh(|x| / 2),
+ *        u = (1 - t) / (1 + t) = e^-|x|              (the full float range: |x| up to 87)
+ * with the sign of x in the sign bit.  The product rule t12 = t1 t2 becomes
+ *        u12 = (u1 + u2) / (1 + u1 u2)               (identity 0, all terms non-negative: no cancellation anywhere)
+ * and log((1 + P) / (1 - P)) = -log(u).  A relative error in u is an ABSOLUTE error in the LLR, ~1e-7 per operation.
+ * A libm result is not reproducible across a CPU and a GPU math library, so both the HIP kernels (bp_general.hip) and the CPU
+ * mirror (oracle/oq_math.h, written independently from the description there) evaluate the same expressions: additions,
+ * multiplications, FUSED multiply-adds (fmaf, one rounding), correctly rounded divisions, floorf and bit casts, in a fixed
+ * order, compiled with -ffp-contract=off on both sides so that nothing else is fused.  Same input bits -> same output bits.
+ * Each function is one straight line of code: a wavefront whose lanes are shots or edges takes both sides of every
+ * data-dependent branch.  tests/test_oracle.py checks them against libm in double.
  */
 #ifndef QD_MATH_H
 #define QD_MATH_H
@@ -42,64 +42,62 @@ QD_MATH_FN float qd_u2f(uint32_t x)
     return v.f;
 }
 
-#define QD_TANH_MAX 0.99999994f /* 1 - 2^-24, the largest float below 1 */
+#define QD_U_MIN 1.17549435e-38f  /* 2^-126: the smallest u kept (a message of 87.3) */
 
-/* tanh(x / 2) = (e^a - 1) / (e^a + 1), a = |x|:  e^a - 1 = 2^k (1 + expm1(r)) - 1 with a = k ln2 + r (Cody-Waite), expm1(r) =
- * r (1 + r/2 + ... + r^6/5040) for |r| <= ln2 / 2.  For k = 0 this is expm1(r) itself: no cancellation near zero. */
-QD_MATH_FN float qd_tanh_half(float x)
+/* +-e^-|x| with the sign bit of x:  |x| = k ln2 + r (Cody-Waite, |r| <= ln2 / 2),  e^-r = 1 + expm1(-r),
+ * expm1(z) = z (1 + z/2 + ... + z^6/5040),  scaled by 2^-k. */
+QD_MATH_FN float qd_exp_neg(float x)
 {
     const float ax = qd_u2f(qd_f2u(x) & 0x7FFFFFFFu);
     const uint32_t sign = qd_f2u(x) & 0x80000000u;
-    const float a = ax > 40.0f ? 40.0f : ax;
+    const float a = ax > 87.0f ? 87.0f : ax;
     const float kf = floorf(fmaf(a, 1.4426950f, 0.5f));
-    float r = fmaf(kf, -0.693145752f, a);  /* ln2 high part (exact product for |k| < 2^11) */
-    r = fmaf(kf, -1.42860677e-06f, r);     /* ln2 low part  */
+    float z = fmaf(kf, 0.693145752f, -a);  /* -(a - k ln2_hi): exact product for |k| < 2^11 */
+    z = fmaf(kf, 1.42860677e-06f, z);      /* + k ln2_lo:  z = -r */
     float p = 1.9841270e-04f;              /* 1/5040 */
-    p = fmaf(p, r, 0.0013888889f);         /* 1/720  */
-    p = fmaf(p, r, 0.008333334f);          /* 1/120  */
-    p = fmaf(p, r, 0.041666668f);          /* 1/24   */
-    p = fmaf(p, r, 0.16666667f);           /* 1/6    */
-    p = fmaf(p, r, 0.5f);
-    p = fmaf(p, r, 1.0f);
-    const float em1r = r * p;                                              /* expm1(r) */
-    const float two_k = qd_u2f((uint32_t)((int)kf + 127) << 23);           /* 2^k, k in [0, 58] */
-    const float em1 = fmaf(em1r, two_k, two_k - 1.0f);                     /* e^a - 1 */
-    float t = em1 / (em1 + 2.0f);
-    if (t > QD_TANH_MAX) t = QD_TANH_MAX;
-    return qd_u2f(qd_f2u(t) | sign);
+    p = fmaf(p, z, 0.0013888889f);         /* 1/720  */
+    p = fmaf(p, z, 0.008333334f);          /* 1/120  */
+    p = fmaf(p, z, 0.041666668f);          /* 1/24   */
+    p = fmaf(p, z, 0.16666667f);           /* 1/6    */
+    p = fmaf(p, z, 0.5f);
+    p = fmaf(p, z, 1.0f);
+    const float em1 = z * p;                                               /* expm1(-r) */
+    const float two_mk = qd_u2f((uint32_t)(127 - (int)kf) << 23);          /* 2^-k, k in [0, 126] */
+    const float u = fmaf(em1, two_mk, two_mk);
+    return qd_u2f(qd_f2u(u) | sign);
+}
+
+/* (a + b) / (1 + a b) for a, b in [0, 1]: the u of a product of two tanh values; capped at 1 (the quotient of the two rounded
+ * sums can exceed it by an ulp) */
+QD_MATH_FN float qd_ucomb(float a, float b)
+{
+    const float q = (a + b) / fmaf(a, b, 1.0f);
+    return q > 1.0f ? 1.0f : q;
 }
 
 /* x = 2^k m with m in [sqrt(1/2), sqrt 2) for a positive normal x: adding (1 - sqrt(1/2)) in units of the last place to the
  * bit pattern carries into the exponent exactly when the mantissa is at least sqrt 2 */
 #define QD_SQRT_HALF_BITS 0x3F3504F3u
-QD_MATH_FN float qd_split_sqrt2(float x, int *k)
-{
-    const uint32_t b = qd_f2u(x) + (0x3F800000u - QD_SQRT_HALF_BITS);
-    *k = (int)(b >> 23);                                                   /* biased; only differences are used */
-    return qd_u2f((b & 0x007FFFFFu) + QD_SQRT_HALF_BITS);
-}
 
-/* log((1 + c) / (1 - c)) = 2 atanh(c) for |c| <= 1 - 2^-24:  1 + c = 2^ku mu, 1 - c = 2^kv mv with mu, mv in [sqrt(1/2), sqrt 2),
- * so the ratio is 2^(ku-kv) (1 + s) / (1 - s) with s = (mu - mv) / (mu + mv), |s| <= 1/3, and the result
- * (ku - kv) ln2 + 2 atanh(s).  When ku = kv (|c| < 0.17 at least) s is c itself, exactly: no division error, no cancellation. */
-QD_MATH_FN float qd_log_ratio(float c)
+/* -log(u) for u in [0, 1] (u below 2^-126 counts as 2^-126):  u = 2^k m,  s = (m - 1) / (m + 1), |s| <= 0.1716,
+ * -log(u) = -(k ln2 + 2 atanh(s)),  2 atanh(s) = s (2 + 2 s^2/3 + ... + 2 s^12/13) */
+QD_MATH_FN float qd_neg_log(float u)
 {
-    int ku, kv;
-    const float mu = qd_split_sqrt2(1.0f + c, &ku);
-    const float mv = qd_split_sqrt2(1.0f - c, &kv);
-    float s = (mu - mv) / (mu + mv);
-    if (ku == kv) s = c;
+    const float uc = u < QD_U_MIN ? QD_U_MIN : u;
+    const uint32_t b = qd_f2u(uc) + (0x3F800000u - QD_SQRT_HALF_BITS);
+    const float kf = (float)((int)(b >> 23) - 127);
+    const float m = qd_u2f((b & 0x007FFFFFu) + QD_SQRT_HALF_BITS);
+    const float s = (m - 1.0f) / (m + 1.0f);
     const float s2 = s * s;
-    float p = 0.13333334f;                 /* 2/15 */
-    p = fmaf(p, s2, 0.15384616f);          /* 2/13 */
+    float p = 0.15384616f;                 /* 2/13 */
     p = fmaf(p, s2, 0.18181819f);          /* 2/11 */
     p = fmaf(p, s2, 0.22222222f);          /* 2/9  */
     p = fmaf(p, s2, 0.2857143f);           /* 2/7  */
     p = fmaf(p, s2, 0.4f);                 /* 2/5  */
     p = fmaf(p, s2, 0.6666667f);           /* 2/3  */
     p = fmaf(p, s2, 2.0f);
-    const float ef = (float)(ku - kv);
-    return fmaf(ef, 0.693145752f, fmaf(s, p, ef * 1.42860677e-06f));
+    const float lg = fmaf(kf, 0.693145752f, fmaf(s, p, kf * 1.42860677e-06f));   /* log(u) <= 0 */
+    return 0.0f - lg;
 }
 
 #endif

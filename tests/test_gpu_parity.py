@@ -619,7 +619,9 @@ def test_ler_agreement_product_sum_serial_osdcs_1e5_shots(gpu):
     """The reference wrapper's own settings (bposd.py:54 defaults + the notebooks' max_iter = 10, osd_order = 1: product_sum,
     serial, osd_cs) at the headline window: the device's float path against ldpc's arithmetic (oracle: double, libm, bp.hpp's
     update order; tests/golden/ler/bb144_ps_serial_osdcs1_seed1_part*.npz, made by tools/ler_productsum.py) on the same
-    100 000 Philox shots -- paired: McNemar on the discordant shots, and the failure counts within 1.5 sigma."""
+    100 000 Philox shots, paired.  Since the device keeps e^-|x| in place of tanh(|x| / 2) (qd_math.h: no clamp at 1 - 2^-24)
+    the two agree almost shot for shot: the same prediction on more than 99.9 % of the shots, a handful of discordant failures,
+    failure counts within a quarter sigma.  (The clamped float form of rounds 1-3 sat at -0.5 sigma, McNemar z = -2.7.)"""
     import glob
     import json
     import os
@@ -636,10 +638,10 @@ def test_ler_agreement_product_sum_serial_osdcs_1e5_shots(gpu):
         assert np.array_equal(obs, z["obs"]), "device sampler and oracle sampler disagree"
         fd.append(pred != obs)
         fr.append(z["pred"] != z["obs"])
-        assert (pred == z["pred"]).mean() > 0.97            # float vs double: the same prediction on all but a few per cent of the shots
+        assert (pred == z["pred"]).mean() > 0.999           # float vs double: the same prediction on all but a few shots in ten thousand
     r = lp.paired(np.concatenate(fd), np.concatenate(fr))
     assert r["shots"] == 100000
-    assert abs(r["mcnemar_z"]) <= 3.0 and abs(r["delta_in_sigma"]) <= 1.5, r
+    assert sum(r["discordant"]) <= 20 and abs(r["mcnemar_z"]) <= 3.0 and abs(r["delta_in_sigma"]) <= 0.25, r
 
 
 # ---- BP-LSD (quits/decoder/bplsd.py; csrc/lsd_kernels.hip) -------------------------------------------------------------------

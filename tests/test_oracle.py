@@ -171,51 +171,63 @@ def test_oracle_plugin_surface():
 
 
 def test_oracle_float_functions_equal_the_products_bit_for_bit(tmp_path):
-    """oracle/oq_math.h (the checker's own tanh(x/2) / log((1+c)/(1-c))) and quits_amd/csrc/qd_math.h (the product's, here
-    compiled for the host) share no code and must return the same bits: 400 000 inputs incl. every branch boundary."""
+    """oracle/oq_math.h (the checker's own e^-|x|, (a + b) / (1 + a b) and -log(u)) and quits_amd/csrc/qd_math.h (the product's,
+    here compiled for the host) share no code and must return the same bits: 400 000 inputs incl. the range limits."""
     import ctypes
     import subprocess
     src = tmp_path / "qd_math_host.c"
     src.write_text('#include "qd_math.h"\n#include <stdint.h>\n'
-                   'void f(int kind, const float *x, float *y, int64_t n) { for (int64_t i = 0; i < n; i++) y[i] = kind == 0 ? qd_tanh_half(x[i]) : qd_log_ratio(x[i]); }\n')
+                   'void f(int kind, const float *x, const float *x2, float *y, int64_t n) { for (int64_t i = 0; i < n; i++) '
+                   'y[i] = kind == 0 ? qd_exp_neg(x[i]) : (kind == 1 ? qd_neg_log(x[i]) : qd_ucomb(x[i], x2[i])); }\n')
     so = tmp_path / "qd_math_host.so"
     subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-std=c11",
                            "-I", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "quits_amd", "csrc"),
                            "-o", str(so), str(src), "-lm"])
     lib = ctypes.CDLL(str(so))
     f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
-    lib.f.argtypes = [ctypes.c_int, f32p, f32p, ctypes.c_int64]
+    lib.f.argtypes = [ctypes.c_int, f32p, f32p, f32p, ctypes.c_int64]
     rng = np.random.default_rng(11)
-    edge = np.float32([0.0, -0.0, 0.5, -0.5, 0.49999997, 0.50000006, 40.0, 40.000004, 1e4, -1e4, 1e-30, 0.171875, 0.17187501, -0.171875,
-                       0.99999994, -0.99999994, 1.4142135, np.inf, -np.inf])
-    x = np.concatenate([rng.uniform(-45, 45, 150000), rng.uniform(-1, 1, 150000), rng.normal(0, 1e-3, 50000),
+    edge = np.float32([0.0, -0.0, 0.5, -0.5, 0.34657359, 0.3465736, 87.0, 87.00001, 1e4, -1e4, 1e-30, 1.0, 0.70710677, 0.7071068,
+                       1.17549435e-38, 1e-45, 0.99999994, np.inf, -np.inf])
+    x = np.concatenate([rng.uniform(-95, 95, 150000), rng.uniform(-1, 1, 150000), rng.normal(0, 1e-3, 50000),
                         rng.uniform(-1, 1, 50000) * 10.0 ** rng.uniform(-30, 0, 50000), edge]).astype(np.float32)
-    for kind, name in ((0, "tanh_half"), (1, "log_ratio")):
-        xs = x if kind == 0 else np.clip(x, -0.99999994, 0.99999994).astype(np.float32)
-        y = np.empty_like(xs)
-        lib.f(kind, xs, y, xs.size)
-        assert np.array_equal(y.view(np.uint32), orc.math_f32(name, xs).view(np.uint32)), name
+    u = np.concatenate([rng.uniform(0, 1, 200000), np.exp(-rng.uniform(0, 95, 150000)), 1 - 10.0 ** rng.uniform(-8, -1, 50000),
+                        np.abs(edge[np.isfinite(edge)]).clip(0, 1)]).astype(np.float32)
+    u2 = rng.permutation(u)
+    for kind, name, a1, a2 in ((0, "exp_neg", x, x), (1, "neg_log", u, u), (2, "ucomb", u, u2)):
+        y = np.empty_like(a1)
+        lib.f(kind, a1, a2, y, a1.size)
+        assert np.array_equal(y.view(np.uint32), orc.math_f32(name, a1, a2).view(np.uint32)), name
 
 
 def test_float_elementary_functions_against_libm():
-    """tanh(x/2) and log((1+c)/(1-c)) as the float product-sum forms evaluate them (the oracle's oq_math.h; bit-identical to
-    the product's qd_math.h by the test above) against libm in double: a few ulp, monotone clamp at +-(1 - 2^-24)."""
+    """e^-|x| (sign of x kept), (a + b) / (1 + a b) and -log(u) as the float product-sum forms evaluate them (the oracle's oq_math.h;
+    bit-identical to the product's qd_math.h by the test above) against double precision: a few ulp over the whole float range the
+    device uses (|x| <= 87, u >= 2^-126), and the identities the check update rests on:
+    tanh(x1/2) tanh(x2/2) has u = C(u1, u2), and log((1 + t) / (1 - t)) = -log(u)."""
     rng = np.random.default_rng(7)
-    x = np.concatenate([rng.uniform(-40, 40, 100000), rng.uniform(-1, 1, 100000), rng.normal(0, 1e-3, 20000),
-                        [0.0, -0.0, 0.5, -0.5, 0.49999997, 17.0, 19.0, 35.0, 50.0, 1e4, 1e-30]]).astype(np.float32)
-    y = orc.math_f32("tanh_half", x)
-    ref = np.clip(np.tanh(x.astype(np.float64) / 2), -0.99999994, 0.99999994)
-    ulp = np.abs(y - ref) / np.spacing(np.maximum(np.abs(ref), 1e-30).astype(np.float32)).astype(np.float64)
-    assert ulp.max() < 8, ulp.max()
-    assert np.all(np.abs(y) <= np.float32(0.99999994)) and np.array_equal(np.signbit(y), np.signbit(x))
-    c = np.concatenate([rng.uniform(-1, 1, 100000), rng.normal(0, 1e-3, 20000), 1 - 10.0 ** rng.uniform(-7.2, -1, 50000),
-                        [0.0, 0.171875, 0.17187501, 0.99999994, -0.99999994, 1e-20]]).astype(np.float32)
-    c = np.clip(c, -0.99999994, 0.99999994)
-    y = orc.math_f32("log_ratio", c)
-    ref = 2 * np.arctanh(c.astype(np.float64))
-    ulp = np.abs(y - ref) / np.spacing(np.maximum(np.abs(ref), 1e-30).astype(np.float32)).astype(np.float64)
-    assert ulp.max() < 8, ulp.max()
-    assert abs(float(orc.math_f32("log_ratio", np.float32([0.99999994]))[0]) - 25 * np.log(2)) < 1e-5
+    x = np.concatenate([rng.uniform(-87, 87, 100000), rng.uniform(-1, 1, 100000), rng.normal(0, 1e-3, 20000),
+                        [0.0, -0.0, 0.5, -0.5, 17.0, 19.0, 35.0, 50.0, 86.9, 1e-30]]).astype(np.float32)
+    y = orc.math_f32("exp_neg", x)
+    ref = np.exp(-np.abs(x.astype(np.float64)))
+    assert (np.abs(np.abs(y) - ref) / ref).max() < 4 * 2.0 ** -24
+    assert np.array_equal(np.signbit(y), np.signbit(x)) and np.all(np.abs(y) <= 1)
+    assert abs(float(orc.math_f32("exp_neg", np.float32([1e4]))[0]) - np.exp(-87.0)) < 1e-44       # saturates at |x| = 87
+    u = np.concatenate([rng.uniform(0, 1, 100000), np.exp(-rng.uniform(0, 87, 100000)), 1 - 10.0 ** rng.uniform(-7.2, -1, 50000),
+                        [1.0, 0.5, 0.70710677, 0.7071068, 1.17549435e-38]]).astype(np.float32)
+    y = orc.math_f32("neg_log", u)
+    ref = -np.log(u.astype(np.float64))
+    assert (np.abs(y - ref) / np.maximum(ref, 1e-3)).max() < 6 * 2.0 ** -24 and np.all(y >= 0)
+    assert float(orc.math_f32("neg_log", np.float32([0.0]))[0]) == float(orc.math_f32("neg_log", np.float32([1.17549435e-38]))[0])
+    a, b = rng.permutation(u), u
+    y = orc.math_f32("ucomb", a, b)
+    ref = (a.astype(np.float64) + b) / (1 + a.astype(np.float64) * b)
+    assert (np.abs(y - ref) / np.maximum(ref, 1e-300)).max() < 4 * 2.0 ** -24 and np.all(y <= 1)
+    # the identities, in double: u of a product of tanh values, and the logarithm
+    x1, x2 = rng.uniform(0.01, 12, 1000), rng.uniform(0.01, 12, 1000)      # (beyond, the double's own 1 - t runs out of digits)
+    t = np.tanh(x1 / 2) * np.tanh(x2 / 2)
+    uu = (np.exp(-x1) + np.exp(-x2)) / (1 + np.exp(-x1 - x2))
+    assert np.allclose((1 - uu) / (1 + uu), t, rtol=1e-12) and np.allclose(-np.log(uu), np.log((1 + t) / (1 - t)), rtol=1e-8, atol=1e-12)
 
 
 @pytest.mark.parametrize("method,schedule,max_iter", [("product_sum", "parallel", 20), ("product_sum", "serial", 6),
