@@ -14,6 +14,7 @@
 #define QD_GEN_PREFIX_LDS (32 * 1024)   // LDS a workgroup of the serial BP kernel may spend on row prefixes (128 slots x 64 shots): five workgroups per CU stay resident
 
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
+hipError_t qd_launch_bp_scatter(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
                                 int schedule, int64_t shot0, int nshots, hipStream_t s);
 int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg);
@@ -81,6 +82,7 @@ struct qd_graph {
     DevAllocs mem;
     std::vector<int32_t> h_cp, h_ri;   // host CSC, for the rank
     std::vector<double> h_llr0;        // log((1-p)/p) in double, fault order
+    ScatGraphDev sc{};                 // scatter form of the flooding min-sum kernel (bp_scatter.hip); sc.ok = 0: not for this window
     std::vector<uint32_t> h_bit_rec;   // host copy of bp.bit_rec: a decoder on an LLR grid uploads its own with word 0 replaced
     std::vector<uint32_t> h_bit_orig;  // bit slot -> fault
 };
@@ -111,6 +113,11 @@ struct qd_decoder {
     const float *llr0_q = nullptr;             // fault-order LLRs for the one-message-per-edge kernel (fine grid)
     int32_t *redo_list = nullptr;
     int redo_cap = 0;
+    int scatter = 0;                           // 1: the fine-grid pass runs in qd_bp_scatter_kernel
+    const int32_t *prior_g = nullptr;          // [n_pad] fine-grid channel LLRs of the bit slots in grid units
+    float m2_limit = 0.f;
+    int32_t *recheck_list = nullptr;           // shots the scatter kernel's bound could not certify
+    int recheck_cap = 0;
     DevAllocs mem;
     int profiling = 0;
     struct Span { int kind; hipEvent_t t0, t1; };   // kind 0 = BP kernel, 1 = OSD kernel(s)
@@ -181,6 +188,9 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
 
     const int m_pad = pad64(m), n_pad = pad64(n);
     const int max_rdeg_pad = (max_rdeg + 3) & ~3;
+    const int bp_threads_ = std::max(m, (n + 9) / 10) <= 256 ? 256 : (std::max(m, (n + 9) / 10) <= 512 ? 512 : 1024);
+    // the shape conditions of the scatter kernel (its LDS fit is checked where the layouts are known)
+    const bool scatter_shape = m <= bp_threads_ && max_rdeg_pad <= 64 && *std::min_element(rdeg.begin(), rdeg.end()) >= 2;
     const int dummy_bit = n_pad, dummy_chk = m_pad;        // one extra LDS slot each
     if ((m_pad + 1) * 16 > 65535) {
         delete g;
@@ -232,6 +242,11 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     // Greedy per group of 32 check slots: at every step each check takes, among its remaining edges, the one whose bank has
     // the fewest distinct addresses so far in that step.  Headline window: 2918 -> 1463 LDS cycles per iteration for these
     // gathers (1062 without any conflict; tools/lds_model.py).
+    // The scatter kernel (bp_scatter.hip) walks the same order with ds_add_u32, and lanes of one instruction that add to the SAME
+    // address serialise like any other bank conflict (profiles/r03z_lds_atomic_rates.txt: two lanes per address 2.2 -> 4.7 ns per
+    // instruction), where a gather broadcasts for free: for the windows that kernel takes, a lane on a busy bank costs one cycle
+    // whatever its address.
+    const bool walk_for_atomics = scatter_shape && !std::getenv("QD_WALK_BROADCAST");
     std::vector<int32_t> step_of(nnz);              // CSR edge -> position in its check's walk
     {
         std::vector<std::vector<int>> rem(32);
@@ -258,13 +273,15 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
                         const uint32_t slot = (uint32_t)bit_slot_of[col_idx[r[y]]];
                         const int b = (int)(slot & 31u);
                         int c = used_cnt[b];
-                        for (uint32_t a : used_addr[b]) if (a == slot) { c = 0; break; }      // same address: a broadcast, free
+                        if (!walk_for_atomics)
+                            for (uint32_t a : used_addr[b]) if (a == slot) { c = 0; break; }  // same address: a broadcast, free
                         if (c < bestc) { bestc = c; best = y; if (c == 0) break; }
                     }
                     const uint32_t slot = (uint32_t)bit_slot_of[col_idx[r[best]]];
                     bool dup = false;
                     for (uint32_t a : used_addr[slot & 31u]) dup |= (a == slot);
-                    if (!dup) { used_addr[slot & 31u].push_back(slot); used_cnt[slot & 31u]++; }
+                    if (!dup) used_addr[slot & 31u].push_back(slot);
+                    if (!dup || walk_for_atomics) used_cnt[slot & 31u]++;
                     step_of[r[best]] = k;
                     r.erase(r.begin() + best);
                 }
@@ -464,6 +481,45 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     bp.lds_bytes = off;
     const int need = std::max(m, (n + 9) / 10);
     bp.threads = need <= 256 ? 256 : (need <= 512 ? 512 : 1024);
+
+    // Scatter form of the flooding min-sum kernel (bp_scatter.hip): one check per lane with its state in registers, two integer
+    // posterior buffers in LDS.  Admitted when every check has a lane, rows hold 2..64 faults (two sign words; a row of one fault
+    // has no second minimum) and the two buffers leave as many workgroups per CU as the gather kernel's layout does.
+    {
+        ScatGraphDev &sc = g->sc;
+        sc = ScatGraphDev{};
+        const int min_rdeg = *std::min_element(rdeg.begin(), rdeg.end());
+        const int buf = align16((n_pad + 4) * 4);
+        sc.offA = 0; sc.offB = 0; sc.off_out = buf;            // one buffer: the scatter pass works in place
+        sc.off_bmap = sc.off_out + align16(bp.out_words * 4);
+        sc.off_misc = sc.off_bmap;
+        sc.lds_bytes = sc.off_misc + 256;
+        const int by_threads = 2048 / bp.threads;
+        const int res_old = std::min(by_threads, QD_LDS_BYTES / std::max(1, bp.lds_bytes));
+        const int res_new = std::min(by_threads, QD_LDS_BYTES / sc.lds_bytes);
+        if (m <= bp.threads && max_rdeg_pad <= 64 && min_rdeg >= 2 && bp.lds_bytes <= QD_LDS_BYTES && res_new >= 1 && res_new >= res_old) {
+            const int rows = max_rdeg_pad / 4 + 1;            // one spare group row: the kernels load a group ahead unconditionally
+            std::vector<uint32_t> adjA((size_t)rows * m_pad * 4, (uint32_t)(sc.offA + n_pad * 4));
+            for (int s = 0; s < m; ++s) {
+                const int i = chk_orig[s];
+                for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+                    const int k = step_of[e];
+                    adjA[((size_t)(k >> 2) * m_pad + s) * 4 + (k & 3)] = (uint32_t)sc.offA + (uint32_t)bit_slot_of[col_idx[e]] * 4u;
+                }
+            }
+            std::vector<uint32_t> deg_w(m_pad / 64, 0u);
+            for (int w0 = 0; w0 < m; w0 += 64) {
+                int mx = 0, mn = 255;
+                for (int s = w0; s < std::min(m, w0 + 64); ++s) { mx = std::max(mx, (int)chk_deg[s]); mn = std::min(mn, (int)chk_deg[s]); }
+                deg_w[w0 / 64] = (uint32_t)((mx + 3) & ~3) | ((uint32_t)mx << 8) | ((uint32_t)mn << 16);
+            }
+            int rcs = 0;
+            rcs |= g->mem.upload(adjA, &sc.adjA); sc.adjB = sc.adjA;
+            rcs |= g->mem.upload(deg_w, &sc.deg_w); rcs |= g->mem.upload(chk_deg, &sc.chk_deg);
+            if (rcs) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while uploading the scatter adjacency"); }
+            sc.ok = 1;
+        }
+    }
 
     // OSD view
     OsdGraphDev &od = g->osd;
@@ -677,6 +733,23 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
         std::vector<float> lq(g->n);
         for (int j = 0; j < g->n; ++j) lq[j] = on_grid(g->h_llr0[j], d->grid_k);
         rc |= d->mem.upload(lq, &d->llr0_q);
+        if (g->sc.ok && !std::getenv("QD_NO_SCATTER")) {
+            // scatter kernel: fine-grid priors of the bit slots as integers (grid units) and the second-minimum bound that
+            // certifies a run (bp_scatter.hip): max|prior| + max_cdeg * max min2 < 2^23
+            std::vector<int32_t> pg((size_t)g->bp.n_pad, 0);
+            long long mxp = 0;
+            for (int s = 0; s < g->n; ++s) {
+                const long long v = std::llround(std::ldexp((double)on_grid(g->h_llr0[g->h_bit_orig[s]], d->grid_k), d->grid_k));
+                pg[s] = (int32_t)v - 1;              // an accumulator holds L - 1: (L <= 0) is its sign bit
+                mxp = std::max(mxp, std::llabs(v));
+            }
+            const long long lim = ((1ll << 23) - mxp) / std::max(1, g->max_cdeg) - 1;
+            if (mxp < (1ll << 22) && lim > 0) {
+                rc |= d->mem.upload(pg, &d->prior_g);
+                d->m2_limit = (float)lim;
+                d->scatter = 1;
+            }
+        }
         if (rc) { d->mem.release(); delete d; return fail(QD_EHIP, "device allocation failed while building the LLR grid"); }
     }
     *out = d;
@@ -712,6 +785,8 @@ static void free_ws(qd_decoder *d)
     if (d->hard_list) (void)hipFree(d->hard_list);
     if (d->hard_list2) (void)hipFree(d->hard_list2);
     if (d->redo_list) (void)hipFree(d->redo_list);
+    if (d->recheck_list) (void)hipFree(d->recheck_list);
+    d->recheck_list = nullptr; d->recheck_cap = 0;
     if (d->lsd_ws) (void)hipFree(d->lsd_ws);
     d->lsd_ws = nullptr;
     d->redo_list = nullptr; d->redo_cap = 0;
@@ -744,6 +819,10 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
     if (d->grid_k >= 0 && !d->general) {
         d->redo_cap = (int)(d->grid_floor ? max_batch : std::min<int64_t>(max_batch, 4096));
         HIP_TRY(hipMalloc((void **)&d->redo_list, sizeof(int32_t) * (size_t)d->redo_cap));
+        if (d->scatter) {
+            d->recheck_cap = (int)max_batch;
+            HIP_TRY(hipMalloc((void **)&d->recheck_list, sizeof(int32_t) * (size_t)d->recheck_cap));
+        }
     }
     if (osd) {
         int ncu = 256;
@@ -903,7 +982,19 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
             DecodeArgs a1 = a;
             a1.s_limit = std::ldexp(1.0f, 23 - d->grid_k);
             a1.redo_list = d->redo_list; a1.redo_count = redo_count; a1.redo_cap = d->redo_cap;
-            HIP_TRY(qd_launch_bp(d->bp_fine, a1, B, s));
+            if (d->scatter) {
+                // scatter kernel first; the shots its (looser) bound cannot certify are decoded again by the gather kernel,
+                // which carries the per-fault bound the coarse-grid rule is stated on
+                int32_t *recheck_count = d->fail_count + 41;
+                HIP_TRY(hipMemsetAsync(recheck_count, 0, sizeof(int32_t), s));
+                ScatArgs x{};
+                x.prior_g = d->prior_g; x.grid_inv = std::ldexp(1.0f, -d->grid_k); x.m2_limit = d->m2_limit;
+                x.recheck_list = d->recheck_list; x.recheck_count = recheck_count; x.recheck_cap = d->recheck_cap;
+                HIP_TRY(qd_launch_bp_scatter(d->bp_fine, d->g->sc, a1, x, B, s));
+                a1.shot_list = d->recheck_list; a1.shot_count = recheck_count;
+                HIP_TRY(qd_launch_bp(d->bp_fine, a1, std::min<int64_t>(B, d->recheck_cap), s));
+            } else
+                HIP_TRY(qd_launch_bp(d->bp_fine, a1, B, s));
             DecodeArgs a2 = a;
             a2.s_limit = std::ldexp(1.0f, 23 - d->grid_kc);
             a2.shot_list = d->redo_list; a2.shot_count = redo_count; a2.status_or = QD_STATUS_COARSE_GRID;

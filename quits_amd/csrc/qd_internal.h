@@ -39,6 +39,26 @@ struct BpGraphDev {
 };
 
 
+// The scatter form of the flooding min-sum kernel (bp_scatter.hip): a check keeps its state in the registers of its lane and ADDS its
+// messages to the faults' integer accumulators in LDS (ds_add_u32), so there is no bit pass.  Two posterior buffers A / B alternate
+// (one is read while the other accumulates); the adjacency exists once per buffer so that a gather / scatter needs no address add.
+struct ScatGraphDev {
+    int ok;                     // 1: this window can run in the scatter kernel (m <= threads, rows of 2..64 faults, the LDS holds both buffers)
+    const uint32_t *adjA, *adjB;// [max_rdeg_pad/4][m_pad][4] LDS byte offset of the fault's accumulator in buffer A / B, in the walk order of
+                                //                        BpGraphDev::chk_adj; the trash slot beyond a check's degree
+    const uint32_t *deg_w;      // [m_pad/64]             per wavefront of check slots: trip count (multiple of 4) | largest degree << 8 | smallest << 16
+    const uint8_t *chk_deg;     // [m_pad]                degree of the check slot (0 beyond m)
+    int offA, offB, off_out, off_bmap, off_misc, lds_bytes;
+};
+struct ScatArgs {
+    const int32_t *prior_g;     // [n_pad] channel LLR of the bit slot in grid units (llr * 2^k, an integer) MINUS ONE: the accumulators hold L - 1
+    float grid_inv;             // 2^-k
+    float m2_limit;             // the run is certified exact while every check's second minimum stays below it (grid units)
+    int32_t *recheck_list;      // shots the cheap bound could not certify: decoded again by qd_bp_minsum_kernel, which carries the per-fault bound
+    int32_t *recheck_count;
+    int recheck_cap;
+};
+
 // The general (one message per edge) BP kernel's view: plain CSR + CSC in fault / detector order, prior LLRs in float.
 #ifndef QD_GEN_GS
 #define QD_GEN_GS 4           // wavefronts per 64 shots in the serial schedule (faults of one dependency level in parallel)

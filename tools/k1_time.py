@@ -17,14 +17,14 @@ else:                                                    # any circuit fixture (
     H, L, pri = detector_error_model_to_matrix(Circuit(helpers.circuit_text(name)))
 det, obs = DemSampler(H, L, pri).sample(shots, seed=5)
 g = WindowGraph(H, pri); d = BatchDecoder(g, max_iter=mi, osd_method="osd_0")
-for stage, key in ((1, "bp_ms"), (3, "osd_ms")):
+for stage, key in ((1, "bp_ms"), (3, "osd_ms"))[:int(os.environ.get("K1_STAGES", "2"))]:
     bits, st = d.decode(det, stage=stage); torch.cuda.synchronize()
     d.set_profiling(True); d.profile()
     for _ in range(3):
         bits, st = d.decode(det, stage=stage)
     torch.cuda.synchronize()
     pr = d.profile()
-    print("%s stage %d: bp %.3f ms  osd %.3f ms per launch   crc bits %08x status %08x" % (
+    print("%s stage %d: bp %.3f ms  osd %.3f ms per launch   crc bits %08x status %08x   mean iterations %.2f" % (
         os.environ.get("QUITS_AMD_LIB", "default"), stage, pr["bp_ms"] / 3, pr["osd_ms"] / 3,
-        zlib.crc32(bits.cpu().numpy().tobytes()), zlib.crc32((st & 0xFFFFF).cpu().numpy().tobytes())))
+        zlib.crc32(bits.cpu().numpy().tobytes()), zlib.crc32((st & 0xFFFFF).cpu().numpy().tobytes()), float((st & 0x3FFF).float().mean())))
     d.set_profiling(False)
