@@ -78,7 +78,7 @@ typedef __attribute__((address_space(3))) int32_t qs_lds_i32;
 #define QS_SCAT(off, k_, bit_, TAILFIX)                                                                      \
     {                                                                                                        \
         const int dm_ = __builtin_amdgcn_sbfe((int)xw, bit_, 1), sm_ = __builtin_amdgcn_sbfe((int)own, bit_, 1); \
-        const int mg_ = pdif ^ (pxq & dm_);                                                                  \
+        const int mg_ = (int)__builtin_amdgcn_bitop3_b32((uint32_t)pdif, (uint32_t)pxq, (uint32_t)dm_, 0x78);   /* pdif ^ (pxq & dm) */ \
         int v_ = (mg_ ^ sm_) - sm_;                                                                          \
         TAILFIX(v_, k_)                                                                                      \
         QS_ADD(off, v_)                                                                                      \
@@ -137,6 +137,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
     uint32_t kold = 0xFFFFFFFFu, o0 = 0u, o1 = 0u;
     const uint32_t cur = (uint32_t)sg.offA;
     const uint4 *adj = reinterpret_cast<const uint4 *>(sg.adjA);
+    const uint4 g0 = adj[c];                                                    // the first four offsets of my walk: never reloaded
     int t = 0, converged = 0;
     for (;;) {
         // ---- gather pass t+1 over L(t); the parity of the hard decisions it meets is the convergence test of iteration t
@@ -152,12 +153,12 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
                 const int kend = min(trip - k0, 32);                  // multiple of 4
                 const int kplain = min(max(wmin4 - k0, 0), kend);     // groups every lane of the wavefront has in full
                 const uint4 *ap = adj + (size_t)(k0 >> 2) * m_pad + c;
-                uint4 nx = ap[0];
+                uint4 nx = k0 ? ap[0] : g0;
                 int kk = 0;
 #pragma unroll 1
                 for (; kk < kplain; kk += 4) {
                     const uint4 e4 = nx;
-                    nx = ap[(size_t)((kk >> 2) + 1) * m_pad];         // next four offsets (the table has one spare group row)
+                    nx = ap[(size_t)((kk >> 2) + 1) * m_pad];         // next four offsets (the table has spare group rows)
                     const int sb = kend - 1 - kk, k = k0 + kk;
                     QS_EDGE(e4.x, k, sb, QS_NOFIX)
                     QS_EDGE(e4.y, k + 1, sb - 1, QS_NOFIX)
@@ -209,30 +210,45 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
             const uint32_t *adj32 = reinterpret_cast<const uint32_t *>(adj);
             const uint32_t fixn_off = adj32[(((size_t)(kst >> 2) * m_pad + c) << 2) + (kst & 3u)];
             const uint32_t fixo_off = adj32[(((size_t)(ko >> 2) * m_pad + c) << 2) + (ko & 3u)];
-            for (int k0 = 0; k0 < trip; k0 += 32) {
-                const int kend = min(trip - k0, 32);
-                const int kplain = min(max(wmin4 - k0, 0), kend);
-                uint32_t own = (k0 ? q1 : q0) << (32 - kend), xw = ((k0 ? q1 : q0) ^ (k0 ? o1 : o0)) << (32 - kend);
-                const uint4 *ap = adj + (size_t)(k0 >> 2) * m_pad + c;
-                uint4 e4 = ap[0];
-                int kk = 0;
+            // groups of four edges, two in flight: a group's offsets are requested while the previous group is added (a group is
+            // a few dozen cycles of work: a load per group on the critical path made this pass latency-bound); the first group's
+            // offsets stay in registers for the whole shot
+            const int ng = trip >> 2, kend0 = min(trip, 32);
+            const uint4 *ap = adj + c;
+            uint32_t own = q0 << (32 - kend0), xw = (q0 ^ o0) << (32 - kend0);
+            uint4 ea = g0, eb;
+#define QS_GROUP(e4, gi_)                                                                                                            \
+            {                                                                                                                        \
+                const int k = (gi_) * 4;                                                                                             \
+                if (k + 4 <= wmin4) {                                                                                                \
+                    QS_SCAT(e4.x, 0, 31, QS_NOFIX) QS_SCAT(e4.y, 0, 30, QS_NOFIX) QS_SCAT(e4.z, 0, 29, QS_NOFIX) QS_SCAT(e4.w, 0, 28, QS_NOFIX) \
+                } else {                                                                                                             \
+                    QS_SCAT(e4.x, k, 31, QS_TAILZERO)                                                                                \
+                    if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, 30, QS_TAILZERO)                                                          \
+                    if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, 29, QS_TAILZERO)                                                          \
+                    if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, 28, QS_TAILZERO)                                                          \
+                }                                                                                                                    \
+                own <<= 4; xw <<= 4;                                                                                                 \
+            }
+            const int ng0 = min(ng, 8);                               // groups of the first sign word
 #pragma unroll 1
-                for (; kk < kplain; kk += 4) {
-                    QS_SCAT(e4.x, 0, 31, QS_NOFIX) QS_SCAT(e4.y, 0, 30, QS_NOFIX) QS_SCAT(e4.z, 0, 29, QS_NOFIX) QS_SCAT(e4.w, 0, 28, QS_NOFIX)
-                    own <<= 4; xw <<= 4;
-                    e4 = ap[(size_t)((kk >> 2) + 1) * m_pad];         // (the table has one spare group row)
-                }
+            for (int gi = 0; gi < ng0; gi += 2) {
+                eb = ap[(size_t)(gi + 1) * m_pad];                    // (the table has two spare group rows)
+                QS_GROUP(ea, gi)
+                ea = ap[(size_t)(gi + 2) * m_pad];
+                if (gi + 1 < ng0) QS_GROUP(eb, gi + 1)
+            }
+            if (ng > 8) {                                             // ... and of the second: `ea` already holds group 8
+                own = q1 << (64 - trip); xw = (q1 ^ o1) << (64 - trip);
 #pragma unroll 1
-                for (; kk < kend; kk += 4) {
-                    const int k = k0 + kk;
-                    QS_SCAT(e4.x, k, 31, QS_TAILZERO)
-                    if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, 30, QS_TAILZERO)
-                    if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, 29, QS_TAILZERO)
-                    if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, 28, QS_TAILZERO)
-                    own <<= 4; xw <<= 4;
-                    e4 = ap[(size_t)((kk >> 2) + 1) * m_pad];
+                for (int gi = 8; gi < ng; gi += 2) {
+                    eb = ap[(size_t)(gi + 1) * m_pad];
+                    QS_GROUP(ea, gi)
+                    ea = ap[(size_t)(gi + 2) * m_pad];
+                    if (gi + 1 < ng) QS_GROUP(eb, gi + 1)
                 }
             }
+#undef QS_GROUP
             // the argmin edges carry min2, not min1: the new one gains +-(min2 - min1), the old one gives its own back
             {
                 const int kw = (int)(kst >> 5), kendw = min(trip - 32 * kw, 32);

@@ -498,7 +498,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         const int res_old = std::min(by_threads, QD_LDS_BYTES / std::max(1, bp.lds_bytes));
         const int res_new = std::min(by_threads, QD_LDS_BYTES / sc.lds_bytes);
         if (m <= bp.threads && max_rdeg_pad <= 64 && min_rdeg >= 2 && bp.lds_bytes <= QD_LDS_BYTES && res_new >= 1 && res_new >= res_old) {
-            const int rows = max_rdeg_pad / 4 + 1;            // one spare group row: the kernels load a group ahead unconditionally
+            const int rows = max_rdeg_pad / 4 + 2;            // two spare group rows: the kernel loads up to two groups ahead unconditionally
             std::vector<uint32_t> adjA((size_t)rows * m_pad * 4, (uint32_t)(sc.offA + n_pad * 4));
             for (int s = 0; s < m; ++s) {
                 const int i = chk_orig[s];
@@ -747,6 +747,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
             if (mxp < (1ll << 22) && lim > 0) {
                 rc |= d->mem.upload(pg, &d->prior_g);
                 d->m2_limit = (float)lim;
+                if (const char *ev = std::getenv("QD_SCATTER_M2_LIMIT")) d->m2_limit = std::min(d->m2_limit, (float)std::atof(ev));   // test knob: force the recheck pass
                 d->scatter = 1;
             }
         }
@@ -759,7 +760,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
 extern "C" int qd_decoder_info(const qd_decoder *d, int32_t *info)
 {
     if (!d || !info) return fail(QD_EINVAL, "null argument");
-    info[0] = d->grid_k; info[1] = d->grid_kc; info[2] = d->general; info[3] = 0;
+    info[0] = d->grid_k; info[1] = d->grid_kc; info[2] = d->general; info[3] = d->scatter;
     return QD_OK;
 }
 

@@ -887,3 +887,41 @@ def test_osdw_row_form_and_column_form_agree(gpu, monkeypatch):
         for b in range(shots):
             ref, st = g.osd_w(synd[b], llr[b].astype(np.float64), "osd_cs", 3, fixed=True)
             assert np.array_equal(out[0][0][b], ref), (m, b, st)
+
+
+@pytest.mark.parametrize("name,shots,max_iter", [
+    ("bb144_custom_r12_p0.003", 4096, 50),        # the headline window: 1008 checks on 1024 lanes, rows of 16..35 faults (two sign words)
+    ("bb72_custom_r6_p0.003", 4096, 30),
+    ("hgp225_cardinal_r3_p0.01", 2048, 20),       # rows of very different weights in one wavefront (the predicated tail groups)
+])
+def test_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, name, shots, max_iter):
+    """Flooding min-sum on the LLR grid has two kernels: the scatter form (bp_scatter.hip: checks add their messages to integer
+    accumulators; the default where the window fits it) and the gather form (bp_kernels.hip, QD_NO_SCATTER=1).  Both are exact, so
+    hard decisions, status words (iteration counts, convergence) and the OSD outputs computed from the posteriors must be
+    identical -- also when the scatter kernel's cheap exactness bound is made to fail for most shots (QD_SCATTER_M2_LIMIT), so that
+    they are decoded again by the gather kernel in the recheck pass -- and equal to the double-precision oracle."""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph, unpack_bits
+    H, L, pri = helpers.dem_matrices(name)
+    det, _ = DemSampler(H, L, pri).sample(shots, seed=11, shot0=3)
+    det[0] = 0
+    wg = WindowGraph(H, pri)
+    out = {}
+    for tag, env in (("gather", {"QD_NO_SCATTER": "1"}), ("scatter", {}), ("recheck", {"QD_SCATTER_M2_LIMIT": "40000"})):
+        monkeypatch.delenv("QD_NO_SCATTER", raising=False)
+        monkeypatch.delenv("QD_SCATTER_M2_LIMIT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dec = BatchDecoder(wg, max_iter=max_iter, osd_method="osd_0")
+        assert dec.info()["scatter_kernel"] == (tag != "gather"), (tag, dec.info())
+        for stage in (1, 3):
+            bits, status = dec.decode(det, stage=stage)
+            out[(tag, stage)] = (unpack_bits(bits, wg.n).cpu().numpy(), status.cpu().numpy())
+    for tag in ("scatter", "recheck"):
+        for stage in (1, 3):
+            assert np.array_equal(out[(tag, stage)][0], out[("gather", stage)][0]), (tag, stage)
+            assert np.array_equal(out[(tag, stage)][1], out[("gather", stage)][1]), (tag, stage)
+    nref = 256
+    g, prm = _oracle(H, pri, max_iter, "osd_0")
+    ref, flags = g.decode_batch(np.ascontiguousarray(det[:nref].cpu().numpy()), prm)
+    assert np.array_equal(out[("scatter", 3)][0][:nref], ref)

@@ -112,6 +112,28 @@ def main():
         print("# bit pass, the %d blocks holding the %d check-state gathers of a fault: " % (len(bg), g) + ", ".join("%s %d" % (k, v) for k, v in tot.items() if v))
         print("#   per edge: %.2f fast + %.2f slow VALU = %.1f issue clk at 2 / 4 clk" % (tot["valu_fast"] / g, tot["valu_slow"] / g,
               (2 * tot["valu_fast"] + 4 * tot["valu_slow"]) / g))
+    # scatter kernel (bp_scatter.hip): the gather pass's innermost loop (four ds_read_b32 per trip) and the scatter pass's loop
+    # (ds_add_u32: two groups of four edges per trip, every block of that loop counted)
+    gl = [cnt for b, cnt in rows if b["inner"] and sum(i.startswith("ds_read_b32") for i in b["ins"]) == 4
+          and not any(i.startswith("ds_add_u32") for i in b["ins"])]
+    if gl and "scatter" in a.kernel:
+        c = gl[0]
+        summary["gather_pass_loop_4_edges"] = c
+        print("\n# gather pass, innermost loop (4 edges per trip): " + ", ".join("%s %d" % (k, v) for k, v in c.items() if v))
+        print("#   per edge: %.2f fast + %.2f slow VALU = %.1f issue clk at 2 / 4 clk" % (c["valu_fast"] / 4, c["valu_slow"] / 4,
+              (2 * c["valu_fast"] + 4 * c["valu_slow"]) / 4))
+        # the scatter loop = the consecutive blocks from its header (the first block after the gather pass that adds four times
+        # without a tail predicate) to the back edge; its plain path adds 8 times per trip
+        sl = [(b, cnt) for b, cnt in rows if sum(i.startswith("ds_add_u32") for i in b["ins"]) == 4
+              and not any(i.startswith("v_cndmask") for i in b["ins"])]
+        if sl:
+            tot = {k: sum(cnt[k] for _, cnt in sl) for k in classes}
+            adds = sum(sum(i.startswith("ds_add_u32") for i in b["ins"]) for b, _ in sl)
+            summary["scatter_pass_plain_blocks"] = tot
+            summary["scatter_pass_adds"] = adds
+            print("# scatter pass, the %d plain blocks of a trip (%d adds): " % (len(sl), adds) + ", ".join("%s %d" % (k, v) for k, v in tot.items() if v))
+            print("#   per edge: %.2f fast + %.2f slow VALU = %.1f issue clk at 2 / 4 clk" % (tot["valu_fast"] / adds, tot["valu_slow"] / adds,
+                  (2 * tot["valu_fast"] + 4 * tot["valu_slow"]) / adds))
     mn = {}
     for b, cnt in rows:
         for ins in b["ins"]:
