@@ -276,7 +276,8 @@ def main():
         try:
             pm = json.load(open(pmc_path))
             key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
-            if key in pm and not general and args.code == "bb144":
+            kname = "qd_bp_scatter_kernel" if decs[0].info().get("scatter_kernel") else "qd_bp_minsum_kernel"
+            if key in pm and not general and args.code == "bb144" and pm[key].get("kernel", "qd_bp_minsum_kernel") == kname:
                 traffic, traffic_src = pm[key]["bp_bytes_per_launch"], pm[key]["source"]
                 sq_counters = pm[key].get("sq_counters")
         except (ValueError, KeyError):
@@ -318,20 +319,40 @@ def main():
                 pass
         cf, cs = mdl["check_pass_loop_4_edges"]["valu_fast"] / 4.0, mdl["check_pass_loop_4_edges"]["valu_slow"] / 4.0
         bf, bs = (mdl["bit_pass_gather_blocks"][k] / float(mdl["bit_pass_gathers"]) for k in ("valu_fast", "valu_slow"))
+        scatter = bool(decs[0].info().get("scatter_kernel"))
+        if scatter:
+            # scatter kernel (bp_scatter.hip): both passes walk the CHECKS' edges -- gather pass (minima, signs, decision parity) and
+            # scatter pass (one ds_add_u32 per edge); per-edge counts from profiles/k1s_issue_model.json <- tools/isa_histogram.py
+            ms = {"gather_pass_loop_4_edges": {"valu_fast": 26, "valu_slow": 32}, "scatter_pass_plain_block": {"valu_fast": 6, "valu_slow": 9},
+                  "scatter_pass_edges_in_block": 3}
+            try:
+                ms = json.load(open(os.path.join(ROOT, "profiles", "k1s_issue_model.json")))["summary"]
+            except (OSError, ValueError, KeyError):
+                pass
+            cf, cs = ms["gather_pass_loop_4_edges"]["valu_fast"] / 4.0, ms["gather_pass_loop_4_edges"]["valu_slow"] / 4.0
+            bf, bs = (ms["scatter_pass_plain_block"][k] / float(ms["scatter_pass_edges_in_block"]) for k in ("valu_fast", "valu_slow"))
+            ws_b_tot = ws_c_tot                                                          # the scatter pass pads like the gather pass
         n_inst = ws_c_tot * (cf + cs) + ws_b_tot * (bf + bs)
         issue_clk = ws_c_tot * (2 * cf + 4 * cs) + ws_b_tot * (2 * bf + 4 * bs)          # SIMD-cycles, fast class 2 clk, slow class 4
-        lds_clk = ws_c_tot * 2 + ws_b_tot * 4                                            # ds_read_b32 2 cycles, ds_read_b128 4 (conflict-free)
-        lds_bytes = ws_c_tot * 64 * 4 + ws_b_tot * 64 * 16
+        if scatter:
+            lds_clk = ws_c_tot * 2 + ws_b_tot * 4                                        # ds_read_b32 2 cycles; ds_add_u32 ~4 (1.75 ns measured, conflict-free)
+            lds_bytes = (ws_c_tot + ws_b_tot) * 64 * 4
+        else:
+            lds_clk = ws_c_tot * 2 + ws_b_tot * 4                                        # ds_read_b32 2 cycles, ds_read_b128 4 (conflict-free)
+            lds_bytes = ws_c_tot * 64 * 4 + ws_b_tot * 64 * 16
         peak_inst = NUM_CU * 2.0 * CLOCK_HZ / 1e9
         ach_inst = n_inst / bp_s / 1e9 if bp_s > 0 else 0.0
         roofline = {
             "bound": "valu", "achieved": ach_inst, "peak": peak_inst, "unit": "G wave-instructions/s", "frac": ach_inst / peak_inst,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": "qd_bp_minsum_kernel",
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": "qd_bp_scatter_kernel" if scatter else "qd_bp_minsum_kernel",
             "avg_launch_ms": prof["bp_ms"] / nlaunch,
             "algorithmic_instructions_per_launch": n_inst / nlaunch,
-            "model": "VALU wave-instructions = check-pass wave-steps x %.2f + bit-pass wave-steps x %.2f (per edge, from "
-                     "profiles/r02_k1_isa_histogram.txt), summed over the BP iterations each shot really ran; per-node overhead "
-                     "outside the two edge loops is not counted, so `achieved` is a floor" % (cf + cs, bf + bs),
+            "model": ("VALU wave-instructions = check-side wave-steps x (%.2f gather pass + %.2f scatter pass) (per edge, from "
+                      "profiles/r03z_k1s_isa_histogram.txt), summed over the BP iterations each shot really ran; per-check overhead "
+                      "outside the two edge loops is not counted, so `achieved` is a floor" % (cf + cs, bf + bs)) if scatter else
+                     ("VALU wave-instructions = check-pass wave-steps x %.2f + bit-pass wave-steps x %.2f (per edge, from "
+                      "profiles/r02_k1_isa_histogram.txt), summed over the BP iterations each shot really ran; per-node overhead "
+                      "outside the two edge loops is not counted, so `achieved` is a floor" % (cf + cs, bf + bs)),
             # the same instructions priced by class: two-operand add/sub/logic/shift/fma issue in 2 clk per wavefront per SIMD,
             # compares / cndmask / min / max / med3 / three-operand logic / 64-bit shifts in 4 (profiles/r01f_valu_issue_rates.txt)
             "frac_priced_by_class": issue_clk / (bp_s * NUM_CU * 4 * CLOCK_HZ) if bp_s > 0 else 0.0,
@@ -339,9 +360,12 @@ def main():
             "frac_from_sq_counters": (sq_counters or {}).get("frac_of_2_per_cu_clk"), "sq_counters": sq_counters,
             "lds": {"achieved": lds_bytes / bp_s / 1e9 if bp_s > 0 else 0.0, "peak": NUM_CU * 256 * CLOCK_HZ / 1e9, "unit": "GB/s",
                     "frac_of_conflict_free_cycles": lds_clk / (bp_s * NUM_CU * CLOCK_HZ) if bp_s > 0 else 0.0,
-                    "note": "gathers only (4 B per check-pass edge, 16 B per bit-pass edge); LDS-array cycles at the conflict-free "
-                            "rate of MI355X_MICROARCH.md (ds_read_b32 2 clk, ds_read_b128 4 clk per wavefront); bank conflicts add to it "
-                            "(tools/lds_model.py, profiles/r02_pmc_*)"},
+                    "note": ("4 B gathered and 4 B added (ds_add_u32) per edge and iteration; LDS-array cycles at ds_read_b32 2 clk "
+                             "(MI355X_MICROARCH.md) and ds_add_u32 ~4 clk per wavefront (profiles/r03z_lds_atomic_rates.txt: 1.75 ns "
+                             "conflict-free, 2.2 ns scattered); bank conflicts add to it") if scatter else
+                            ("gathers only (4 B per check-pass edge, 16 B per bit-pass edge); LDS-array cycles at the conflict-free "
+                             "rate of MI355X_MICROARCH.md (ds_read_b32 2 clk, ds_read_b128 4 clk per wavefront); bank conflicts add to it "
+                             "(tools/lds_model.py, profiles/r02_pmc_*)")},
             "hbm": {"achieved": hbm_algo / bp_s / 1e9 if bp_s > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": hbm_algo / bp_s / 1e9 / HBM_PEAK_GBS if bp_s > 0 else 0.0,
                     "algorithmic_bytes_per_launch": hbm_algo / nlaunch,

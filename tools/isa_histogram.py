@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = os.path.join(ROOT, "quits_amd", "csrc")
 DEFAULT = "qd_bp_minsum_kernelILi1024ELi2ELi1E15HIP_vector_typeIjLj4EELi8E"      # the headline window's instantiation
 
-SLOW = re.compile(r"^v_(cmp|cmpx|cndmask|min|max|med3|lshl_or|and_or|or3|xad|bfi|bfe|alignbit|alignbyte|lshl_add|add_lshl|add3|"
+SLOW = re.compile(r"^v_(cmp|cmpx|cndmask|min|max|med3|lshl_or|and_or|or3|xad|bitop3|bfi|bfe|alignbit|alignbyte|lshl_add|add_lshl|add3|"
                   r"lshlrev_b64|lshrrev_b64|ashrrev_i64|readfirstlane|readlane|writelane|mad_|mul_lo|mul_hi|perm|sad|pk_|"
                   r"add_co|sub_co|addc|subb|add_f64|fma_f64|mul_f64|rcp|rsq|sqrt|exp|log|sin|cos|ldexp|frexp|div_|trig)")
 
@@ -122,18 +122,16 @@ def main():
         print("\n# gather pass, innermost loop (4 edges per trip): " + ", ".join("%s %d" % (k, v) for k, v in c.items() if v))
         print("#   per edge: %.2f fast + %.2f slow VALU = %.1f issue clk at 2 / 4 clk" % (c["valu_fast"] / 4, c["valu_slow"] / 4,
               (2 * c["valu_fast"] + 4 * c["valu_slow"]) / 4))
-        # the scatter loop = the consecutive blocks from its header (the first block after the gather pass that adds four times
-        # without a tail predicate) to the back edge; its plain path adds 8 times per trip
-        sl = [(b, cnt) for b, cnt in rows if sum(i.startswith("ds_add_u32") for i in b["ins"]) == 4
-              and not any(i.startswith("v_cndmask") for i in b["ins"])]
+        # the scatter pass's plain path: the block that builds three of a group's four values back to back (v_bitop3 0x78 =
+        # pdif ^ (pxq & differ-mask), no tail predicate); the fourth is computed in the loop header, the same five instructions
+        sl = [(b, cnt) for b, cnt in rows if sum("bitop3:0x78" in i for i in b["ins"]) == 3 and not any(i.startswith("v_cndmask") for i in b["ins"])]
         if sl:
-            tot = {k: sum(cnt[k] for _, cnt in sl) for k in classes}
-            adds = sum(sum(i.startswith("ds_add_u32") for i in b["ins"]) for b, _ in sl)
-            summary["scatter_pass_plain_blocks"] = tot
-            summary["scatter_pass_adds"] = adds
-            print("# scatter pass, the %d plain blocks of a trip (%d adds): " % (len(sl), adds) + ", ".join("%s %d" % (k, v) for k, v in tot.items() if v))
-            print("#   per edge: %.2f fast + %.2f slow VALU = %.1f issue clk at 2 / 4 clk" % (tot["valu_fast"] / adds, tot["valu_slow"] / adds,
-                  (2 * tot["valu_fast"] + 4 * tot["valu_slow"]) / adds))
+            b, cnt = sl[0]
+            summary["scatter_pass_plain_block"] = cnt
+            summary["scatter_pass_edges_in_block"] = 3
+            print("# scatter pass, plain block (3 of a group's 4 edges): " + ", ".join("%s %d" % (k, v) for k, v in cnt.items() if v))
+            print("#   per edge: %.2f fast + %.2f slow VALU = %.1f issue clk at 2 / 4 clk" % (cnt["valu_fast"] / 3, cnt["valu_slow"] / 3,
+                  (2 * cnt["valu_fast"] + 4 * cnt["valu_slow"]) / 3))
     mn = {}
     for b, cnt in rows:
         for ins in b["ins"]:
