@@ -190,7 +190,9 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int max_rdeg_pad = (max_rdeg + 3) & ~3;
     const int bp_threads_ = std::max(m, (n + 9) / 10) <= 256 ? 256 : (std::max(m, (n + 9) / 10) <= 512 ? 512 : 1024);
     // the shape conditions of the scatter kernel (its LDS fit is checked where the layouts are known)
-    const bool scatter_shape = m <= bp_threads_ && max_rdeg_pad <= 64 && *std::min_element(rdeg.begin(), rdeg.end()) >= 2;
+    // (windows small enough for 256-thread workgroups stay with the gather kernel: measured 4.0 vs 4.7 ms per launch on the W = 3
+    // windows of the [[72,12,6]] code, 9.0 vs 9.8 ms on those of the [[144,12,12]] code, profiles/r03z_scatter_other_configs.txt)
+    const bool scatter_shape = m <= bp_threads_ && bp_threads_ >= 512 && max_rdeg_pad <= 64 && *std::min_element(rdeg.begin(), rdeg.end()) >= 2;
     const int dummy_bit = n_pad, dummy_chk = m_pad;        // one extra LDS slot each
     if ((m_pad + 1) * 16 > 65535) {
         delete g;
@@ -497,7 +499,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         const int by_threads = 2048 / bp.threads;
         const int res_old = std::min(by_threads, QD_LDS_BYTES / std::max(1, bp.lds_bytes));
         const int res_new = std::min(by_threads, QD_LDS_BYTES / sc.lds_bytes);
-        if (m <= bp.threads && max_rdeg_pad <= 64 && min_rdeg >= 2 && bp.lds_bytes <= QD_LDS_BYTES && res_new >= 1 && res_new >= res_old) {
+        if (scatter_shape && min_rdeg >= 2 && bp.lds_bytes <= QD_LDS_BYTES && res_new >= 1 && res_new >= res_old) {
             const int rows = max_rdeg_pad / 4 + 2;            // two spare group rows: the kernel loads up to two groups ahead unconditionally
             std::vector<uint32_t> adjA((size_t)rows * m_pad * 4, (uint32_t)(sc.offA + n_pad * 4));
             for (int s = 0; s < m; ++s) {
