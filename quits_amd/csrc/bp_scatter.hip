@@ -37,6 +37,8 @@ __device__ __forceinline__ float qs_min_abs(float a, float b)       // min(a, |b
     asm("v_min_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 qs_as_uint4(qs_u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
 typedef __attribute__((address_space(3))) int32_t qs_lds_i32;
 #define QS_LDS(off) ((qs_lds_i32 *)(uintptr_t)(uint32_t)(off))
 #define QS_BIG 1.0e30f
@@ -139,8 +141,12 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
     float s1 = 0.f, s2 = 0.f, mx2 = 0.f;
     uint32_t kold = 0xFFFFFFFFu, o0 = 0u, o1 = 0u;
     const uint32_t cur = (uint32_t)sg.offA;
-    const uint4 *adj = reinterpret_cast<const uint4 *>(sg.adjA);
-    const uint4 g0 = adj[c];                                                    // the first four offsets of my walk: never reloaded
+    // offsets through buffer loads: the per-lane offset c * 16 never changes, the group row is a scalar offset -- no vector address
+    // arithmetic per group
+    const __amdgpu_buffer_rsrc_t adj_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sg.adjA, 0, (g.max_rdeg_pad / 4 + 2) * m_pad * 16, 0x00020000);
+    const int adj_voff = c * 16, adj_row = m_pad * 16;
+#define QS_ADJ(row_) qs_as_uint4(__builtin_amdgcn_raw_buffer_load_b128(adj_rsrc, adj_voff, (row_) * adj_row, 0))
+    const uint4 g0 = QS_ADJ(0);                                                 // the first four offsets of my walk: never reloaded
     int t = 0, converged = 0;
     for (;;) {
         // ---- gather pass t+1 over L(t); the parity of the hard decisions it meets is the convergence test of iteration t
@@ -155,13 +161,13 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
                 uint32_t neww = 0u, ltw = 0u;
                 const int kend = min(trip - k0, 32);                  // multiple of 4
                 const int kplain = min(max(wmin4 - k0, 0), kend);     // groups every lane of the wavefront has in full
-                const uint4 *ap = adj + (size_t)(k0 >> 2) * m_pad + c;
-                uint4 nx = k0 ? ap[0] : g0;
+                const int row0 = k0 >> 2;
+                uint4 nx = k0 ? QS_ADJ(row0) : g0;
                 int kk = 0;
 #pragma unroll 1
                 for (; kk < kplain; kk += 4) {
                     const uint4 e4 = nx;
-                    nx = ap[(size_t)((kk >> 2) + 1) * m_pad];         // next four offsets (the table has spare group rows)
+                    nx = QS_ADJ(row0 + (kk >> 2) + 1);                // next four offsets (the table has spare group rows)
                     const int sb = kend - 1 - kk, k = k0 + kk;
                     QS_EDGE(e4.x, k, sb, QS_NOFIX)
                     QS_EDGE(e4.y, k + 1, sb - 1, QS_NOFIX)
@@ -171,7 +177,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
 #pragma unroll 1
                 for (; kk < kend; kk += 4) {
                     const uint4 e4 = nx;
-                    nx = ap[(size_t)((kk >> 2) + 1) * m_pad];
+                    nx = QS_ADJ(row0 + (kk >> 2) + 1);
                     const int sb = kend - 1 - kk, k = k0 + kk;
                     QS_EDGE(e4.x, k, sb, QS_TAILFIX)                  // (k < wmax: a group starts below the largest degree)
                     if (k + 1 < wmax) QS_EDGE(e4.y, k + 1, sb - 1, QS_TAILFIX) else { neww <<= 1; ltw <<= 1; }
@@ -211,14 +217,12 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
             const int n1i = (int)a1, s1i = (int)s1;
             const int pdif = n1i - s1i, pxq = pdif ^ (n1i + s1i);
             const uint32_t ko = kold == 0xFFFFFFFFu ? 0u : kold;     // (no message sent yet: s1 = s2 = 0, any edge will do)
-            const uint32_t *adj32 = reinterpret_cast<const uint32_t *>(adj);
-            const uint32_t fixn_off = adj32[(((size_t)(kst >> 2) * m_pad + c) << 2) + (kst & 3u)];
-            const uint32_t fixo_off = adj32[(((size_t)(ko >> 2) * m_pad + c) << 2) + (ko & 3u)];
+            const uint32_t fixn_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((kst >> 2) * (uint32_t)adj_row + (kst & 3u) * 4u) + adj_voff, 0, 0);
+            const uint32_t fixo_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((ko >> 2) * (uint32_t)adj_row + (ko & 3u) * 4u) + adj_voff, 0, 0);
             // groups of four edges, two in flight: a group's offsets are requested while the previous group is added (a group is
             // a few dozen cycles of work: a load per group on the critical path made this pass latency-bound); the first group's
             // offsets stay in registers for the whole shot
             const int ng = trip >> 2, kend0 = min(trip, 32);
-            const uint4 *ap = adj + c;
             uint32_t own = q0 << (32 - kend0), xw = (q0 ^ o0) << (32 - kend0);
             uint4 ea = g0, eb;
 #define QS_GROUP(e4, gi_)                                                                                                            \
@@ -237,18 +241,18 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
             const int ng0 = min(ng, 8);                               // groups of the first sign word
 #pragma unroll 1
             for (int gi = 0; gi < ng0; gi += 2) {
-                eb = ap[(size_t)(gi + 1) * m_pad];                    // (the table has two spare group rows)
+                eb = QS_ADJ(gi + 1);                                  // (the table has two spare group rows)
                 QS_GROUP(ea, gi)
-                ea = ap[(size_t)(gi + 2) * m_pad];
+                ea = QS_ADJ(gi + 2);
                 if (gi + 1 < ng0) QS_GROUP(eb, gi + 1)
             }
             if (ng > 8) {                                             // ... and of the second: `ea` already holds group 8
                 own = q1 << (64 - trip); xw = (q1 ^ o1) << (64 - trip);
 #pragma unroll 1
                 for (int gi = 8; gi < ng; gi += 2) {
-                    eb = ap[(size_t)(gi + 1) * m_pad];
+                    eb = QS_ADJ(gi + 1);
                     QS_GROUP(ea, gi)
-                    ea = ap[(size_t)(gi + 2) * m_pad];
+                    ea = QS_ADJ(gi + 2);
                     if (gi + 1 < ng) QS_GROUP(eb, gi + 1)
                 }
             }
