@@ -164,10 +164,30 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
                 const int row0 = k0 >> 2;
                 uint4 nx = k0 ? QS_ADJ(row0) : g0;
                 int kk = 0;
+                {
+                    // two groups per trip, two register sets: the next group's offsets are requested while this one is worked on,
+                    // without copying them
+                    uint4 eb;
+#pragma unroll 1
+                    for (; kk + 8 <= kplain; kk += 8) {
+                        eb = QS_ADJ(row0 + (kk >> 2) + 1);            // (the table has spare group rows)
+                        {
+                            const int sb = kend - 1 - kk, k = k0 + kk;
+                            QS_EDGE(nx.x, k, sb, QS_NOFIX) QS_EDGE(nx.y, k + 1, sb - 1, QS_NOFIX)
+                            QS_EDGE(nx.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(nx.w, k + 3, sb - 3, QS_NOFIX)
+                        }
+                        nx = QS_ADJ(row0 + (kk >> 2) + 2);
+                        {
+                            const int sb = kend - 5 - kk, k = k0 + kk + 4;
+                            QS_EDGE(eb.x, k, sb, QS_NOFIX) QS_EDGE(eb.y, k + 1, sb - 1, QS_NOFIX)
+                            QS_EDGE(eb.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(eb.w, k + 3, sb - 3, QS_NOFIX)
+                        }
+                    }
+                }
 #pragma unroll 1
                 for (; kk < kplain; kk += 4) {
                     const uint4 e4 = nx;
-                    nx = QS_ADJ(row0 + (kk >> 2) + 1);                // next four offsets (the table has spare group rows)
+                    nx = QS_ADJ(row0 + (kk >> 2) + 1);
                     const int sb = kend - 1 - kk, k = k0 + kk;
                     QS_EDGE(e4.x, k, sb, QS_NOFIX)
                     QS_EDGE(e4.y, k + 1, sb - 1, QS_NOFIX)

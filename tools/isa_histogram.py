@@ -114,12 +114,13 @@ def main():
               (2 * tot["valu_fast"] + 4 * tot["valu_slow"]) / g))
     # scatter kernel (bp_scatter.hip): the gather pass's innermost loop (four ds_read_b32 per trip) and the scatter pass's loop
     # (ds_add_u32: two groups of four edges per trip, every block of that loop counted)
-    gl = [cnt for b, cnt in rows if b["inner"] and sum(i.startswith("ds_read_b32") for i in b["ins"]) == 4
-          and not any(i.startswith("ds_add_u32") for i in b["ins"])]
+    gl = [(sum(i.startswith("ds_read_b32") for i in b["ins"]), cnt) for b, cnt in rows if b["inner"]
+          and sum(i.startswith("ds_read_b32") for i in b["ins"]) >= 4 and not any(i.startswith("ds_add_u32") for i in b["ins"])]
     if gl and "scatter" in a.kernel:
-        c = gl[0]
+        ne, c8 = max(gl, key=lambda t: t[0])                  # the main loop: two groups of four edges per trip
+        c = {k: v * 4.0 / ne for k, v in c8.items()}          # ... normalised to four edges, the unit bench.py prices
         summary["gather_pass_loop_4_edges"] = c
-        print("\n# gather pass, innermost loop (4 edges per trip): " + ", ".join("%s %d" % (k, v) for k, v in c.items() if v))
+        print("\n# gather pass, innermost loop (%d edges per trip; counts per 4 edges): " % ne + ", ".join("%s %.1f" % (k, v) for k, v in c.items() if v))
         print("#   per edge: %.2f fast + %.2f slow VALU = %.1f issue clk at 2 / 4 clk" % (c["valu_fast"] / 4, c["valu_slow"] / 4,
               (2 * c["valu_fast"] + 4 * c["valu_slow"]) / 4))
         # the scatter pass's plain path: the block that builds three of a group's four values back to back (v_bitop3 0x78 =
