@@ -344,7 +344,7 @@ def main():
         ach_inst = n_inst / bp_s / 1e9 if bp_s > 0 else 0.0
         roofline = {
             "bound": "valu", "achieved": ach_inst, "peak": peak_inst, "unit": "G wave-instructions/s", "frac": ach_inst / peak_inst,
-            "traffic": traffic, "traffic_source": traffic_src, "kernel": "qd_bp_scatter_kernel" if scatter else "qd_bp_minsum_kernel",
+            "traffic": traffic, "traffic_source": traffic_src, "kernel": ("qd_bp_scatter_wide_kernel" if decs[0].info().get("scatter_wide_kernel") else "qd_bp_scatter_kernel") if scatter else "qd_bp_minsum_kernel",
             "avg_launch_ms": prof["bp_ms"] / nlaunch,
             "algorithmic_instructions_per_launch": n_inst / nlaunch,
             "model": ("VALU wave-instructions = check-side wave-steps x (%.2f gather pass + %.2f scatter pass) (per edge, from "

@@ -31,64 +31,7 @@
 #include "../../include/quits_amd.h"
 #include <float.h>
 
-__device__ __forceinline__ float qs_min_abs(float a, float b)       // min(a, |b|) as one instruction (see bp_kernels.hip)
-{
-    float r;
-    asm("v_min_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-typedef uint32_t qs_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 qs_as_uint4(qs_u32x4 v) { return make_uint4(v.x, v.y, v.z, v.w); }
-typedef __attribute__((address_space(3))) int32_t qs_lds_i32;
-#define QS_LDS(off) ((qs_lds_i32 *)(uintptr_t)(uint32_t)(off))
-#define QS_BIG 1.0e30f
-#ifndef QS_PRIO
-#define QS_PRIO 1         // wavefront priority during the scatter pass (short, bound by the LDS): 53.4 -> 52.8 ms at the headline
-#endif
-
-// Gather pass, one edge.  off = LDS byte offset of the fault's accumulator (L - 1) in the buffer being read; k_ = position of the
-// edge in the check's walk (wave-uniform), compared with the argmin label of the last pass; sb = bit of `sgnw` that holds the sign of the message this check sent
-// on the edge.  d_ = (L - 1) - prev = bm - 1 is an integer-valued float, so (bm <= 0) is its sign bit (-0.0 cannot occur: an
-// integer converted to float is never -0, and x - y is -0 only for x = -0).
-#define QS_EDGE(off, k_, sb, TAILFIX)                                                                        \
-    {                                                                                                        \
-        const int A_ = *QS_LDS(off);                                                                         \
-        const float mag_ = ((uint32_t)(k_) == kold) ? s2 : s1;                                               \
-        const float prev_ = __uint_as_float(((sgnw >> (sb)) & 1u) << 31 | __float_as_uint(mag_));            \
-        float d_ = (float)A_ - prev_;                                                                        \
-        TAILFIX(d_, k_)                                                                                      \
-        const float bm_ = d_ + 1.0f;                                                                         \
-        hp ^= (uint32_t)A_;                                                                                  \
-        neww = __builtin_amdgcn_alignbit(neww, __float_as_uint(d_), 31);                                     \
-        /* ltw = ltw << 1 | (|bm| < a1): the argmin is the edge of the LAST strict improvement */           \
-        asm("v_cmp_lt_f32 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ltw) : "v"(bm_), "v"(a1) : "vcc"); \
-        a2 = __builtin_amdgcn_fmed3f(a1, a2, fabsf(bm_));                                                    \
-        a1 = qs_min_abs(a1, bm_);                                                                            \
-    }
-#define QS_NOFIX(x_, k_)
-// beyond this lane's degree the walk reads the trash slot (0 for ever: no hard decision); the difference must be neither negative
-// nor a minimum
-#define QS_TAILFIX(x_, k_) x_ = ((int)(k_) < dc) ? x_ : QS_BIG;
-
-#if defined(QS_ABL_STORE)       /* timing experiments only (wrong results): a plain store instead of the atomic add ... */
-#define QS_ADD(off, v_) *QS_LDS(off) = v_;
-#elif defined(QS_ABL_CONSTV)    /* ... the atomic add of a constant (the value's arithmetic is dead code) */
-#define QS_ADD(off, v_) (void)__hip_atomic_fetch_add(QS_LDS(off), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-#define QS_ADD(off, v_) (void)__hip_atomic_fetch_add(QS_LDS(off), v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-// Scatter pass, one edge: (new message) - (message sent in the last iteration) = sn a - so b with a, b = min1 of the two passes
-// (the argmin edges are corrected after the loop) and sn, so = +-1 the outgoing signs: sn (a - b) where the signs agree, sn (a + b)
-// where they differ.  `own` holds the new signs, `xw` = new ^ sent, edge i of the group at bit 31 - i; pdif = a - b, pxq = (a - b) ^ (a + b).
-#define QS_SCAT(off, k_, bit_, TAILFIX)                                                                      \
-    {                                                                                                        \
-        const int dm_ = __builtin_amdgcn_sbfe((int)xw, bit_, 1), sm_ = __builtin_amdgcn_sbfe((int)own, bit_, 1); \
-        const int mg_ = (int)__builtin_amdgcn_bitop3_b32((uint32_t)pdif, (uint32_t)pxq, (uint32_t)dm_, 0x78);   /* pdif ^ (pxq & dm) */ \
-        int v_ = (mg_ ^ sm_) - sm_;                                                                          \
-        TAILFIX(v_, k_)                                                                                      \
-        QS_ADD(off, v_)                                                                                      \
-    }
-#define QS_TAILZERO(v_, k_) v_ = ((int)(k_) < dc) ? v_ : 0;
+#include "bp_scatter_edge.h"
 
 template <int T, int MW>
 __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, ScatGraphDev sg, DecodeArgs a, ScatArgs x)

@@ -1,0 +1,311 @@
+// bp_scatter_wide.hip -- the scatter form of flooding min-sum BP (bp_scatter.hip) for windows that have more checks than a workgroup
+// has lanes, or rows of more than 64 faults: CPL checks per lane, NSW 32-bit sign words per check.
+//
+// Replaces ldpc.BpOsdDecoder.decode -> BpDecoder::bp_decode_parallel (MINIMUM_SUM, ms_scaling_factor 1) as the reference calls it at
+// quits/decoder/sliding_window.py:171,182 on the windows of BASELINE configs[4] (QLP [[1020,136]], W = 3: 1326 checks of up to 78
+// faults, 18 900 faults).  Same arithmetic, same certificate and the same outputs as qd_bp_scatter_kernel and qd_bp_minsum_kernel, bit for
+// bit; oracle: oracle/bp_core.inc bp_parallel_edge in double on the same LLR grid.
+//
+// Why.  qd_bp_minsum_kernel keeps 16 bytes of packed state per check plus sign words plus a float posterior per fault in LDS: 112 KB
+// per QLP shot, ONE workgroup of 1024 threads per CU, four wavefronts per SIMD.  In the scatter form the LDS holds one int32 accumulator
+// per fault (76 KB), so TWO shots share a CU; a workgroup of 704 threads (11 wavefronts) gives every lane two checks, whose state
+// (two minima, argmin position, three sign words, twice: what was sent and what the gather pass just found) stays in registers.
+// Check slots are sorted by degree, lane l owns slots l and T + l: a wavefront's 64 checks of one round are 64 consecutive slots, so
+// the trip count stays wave-uniform.
+//
+// One iteration = [gather pass of check 0, then of check 1] barrier [converged? | scatter pass of check 0, then of check 1] barrier,
+// in place as in bp_scatter.hip (every gather of the iteration precedes every add).
+#include "qd_internal.h"
+#include "../../include/quits_amd.h"
+#include "bp_scatter_edge.h"
+
+template <int T, int MW, int CPL, int NSW>
+__global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g, ScatGraphDev sg, DecodeArgs a, ScatArgs x)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem;
+    if (lds_base != 0u) __builtin_trap();   // no static LDS in this kernel: byte offsets into smem are LDS addresses
+    uint32_t *outw = reinterpret_cast<uint32_t *>(smem + sg.off_out);
+    int *misc = reinterpret_cast<int *>(smem + sg.off_misc);             // [0..31] qd_block_or, [32..47] convergence flags, [48] fail slot
+    constexpr int NW = T / 64;
+    static_assert(T % 64 == 0 && NW <= 16, "workgroup shape");
+
+    const int tid = threadIdx.x;
+    const int64_t shot = blockIdx.x;
+    const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
+    const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
+    const int m_pad = g.m_pad, n_pad = g.n_pad;
+
+    // ---- the window syndrome (sliding_window.py:168-169), the accumulators at the priors (minus one)
+    int any = 0;
+    uint32_t synd[CPL];
+    int dcs[CPL];
+    bool act[CPL];
+    if (tid < 64) misc[tid] = 0;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = j * T + tid;
+        act[j] = c < g.m;
+        synd[j] = 0u; dcs[j] = 0;
+        if (act[j]) {
+            const uint32_t o = g.chk_orig[c];
+            synd[j] = det[o] & 1u;
+            if (upd && (int)o < a.upd_rows) synd[j] ^= upd[o] & 1u;
+            any |= (int)synd[j];
+            dcs[j] = sg.chk_deg[c];
+        }
+    }
+    {
+        int32_t *bA = reinterpret_cast<int32_t *>(smem + sg.offA);
+        for (int b = tid; b < n_pad + 4; b += T) bA[b] = b < g.n ? x.prior_g[b] : 0;    // slots beyond n: padding and the trash slot of the short rows (stay 0)
+    }
+    for (int w = tid; w < g.out_words; w += T) outw[w] = 0u;
+    __syncthreads();
+    any = qd_block_or(any, misc, NW, 0);
+    if (!any) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
+        for (int w = tid; w < g.out_words; w += T) a.err_bits[shot * g.out_words + w] = 0u;
+        if (tid == 0) a.status[shot] = (1 << 16) | (1 << 19) | a.status_or;
+        return;
+    }
+
+    // per wavefront and round: trip count | largest degree << 8 | smallest << 16 (scalar); a round whose 64 slots lie beyond the window has 0
+    int dws[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int wslot = __builtin_amdgcn_readfirstlane((j * T + tid) >> 6);
+        dws[j] = wslot < (m_pad >> 6) ? (int)sg.deg_w[wslot] : 0;
+    }
+    // check state, in registers: what each check SENT in the last scatter pass (the two minima, the position of the argmin edge, the
+    // outgoing signs: edge k of a word of kend edges at bit kend - 1 - k) and what the gather pass of this iteration found
+    float S1[CPL], S2[CPL], A1[CPL], A2[CPL], mx2 = 0.f;
+    uint32_t KOLD[CPL], KST[CPL], O[CPL][NSW], Q[CPL][NSW];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        S1[j] = 0.f; S2[j] = 0.f; A1[j] = FLT_MAX; A2[j] = FLT_MAX; KOLD[j] = 0xFFFFFFFFu; KST[j] = 0u;
+#pragma unroll
+        for (int w = 0; w < NSW; ++w) { O[j][w] = 0u; Q[j][w] = 0u; }
+    }
+    const uint32_t cur = (uint32_t)sg.offA;
+    const __amdgpu_buffer_rsrc_t adj_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sg.adjA, 0, (g.max_rdeg_pad / 4 + 2) * m_pad * 16, 0x00020000);
+    const int adj_row = m_pad * 16;
+#define QS_ADJ(row_) qs_as_uint4(__builtin_amdgcn_raw_buffer_load_b128(adj_rsrc, adj_voff, (row_) * adj_row, 0))
+    int t = 0, converged = 0;
+    for (;;) {
+        // ---- gather pass t+1 over L(t); the parity of the hard decisions it meets is the convergence test of iteration t
+        bool us = false;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            float a1 = FLT_MAX, a2 = FLT_MAX;
+            uint32_t kst = 0u;
+            if (act[j]) {
+                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
+                const int adj_voff = (j * T + tid) * 16;
+                const float s1 = S1[j], s2 = S2[j];
+                const uint32_t kold = KOLD[j];
+                const int dc = dcs[j];
+                uint32_t hp = 0u, par = 0u;
+                uint32_t neg[NSW];
+#pragma unroll
+                for (int w = 0; w < NSW; ++w) {
+                    neg[w] = 0u;
+                    const int k0 = 32 * w;
+                    if (k0 < trip) {
+                        const uint32_t sgnw = O[j][w];
+                        uint32_t neww = 0u, ltw = 0u;
+                        const int kend = min(trip - k0, 32);                  // multiple of 4
+                        const int kplain = min(max(wmin4 - k0, 0), kend);     // groups every lane of the wavefront has in full
+                        const int row0 = k0 >> 2;
+                        uint4 nx = QS_ADJ(row0);
+                        int kk = 0;
+                        {
+                            uint4 eb;                                         // two groups per trip on two register sets (bp_scatter.hip)
+#pragma unroll 1
+                            for (; kk + 8 <= kplain; kk += 8) {
+                                eb = QS_ADJ(row0 + (kk >> 2) + 1);            // (the table has spare group rows)
+                                {
+                                    const int sb = kend - 1 - kk, k = k0 + kk;
+                                    QS_EDGE(nx.x, k, sb, QS_NOFIX) QS_EDGE(nx.y, k + 1, sb - 1, QS_NOFIX)
+                                    QS_EDGE(nx.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(nx.w, k + 3, sb - 3, QS_NOFIX)
+                                }
+                                nx = QS_ADJ(row0 + (kk >> 2) + 2);
+                                {
+                                    const int sb = kend - 5 - kk, k = k0 + kk + 4;
+                                    QS_EDGE(eb.x, k, sb, QS_NOFIX) QS_EDGE(eb.y, k + 1, sb - 1, QS_NOFIX)
+                                    QS_EDGE(eb.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(eb.w, k + 3, sb - 3, QS_NOFIX)
+                                }
+                            }
+                        }
+#pragma unroll 1
+                        for (; kk < kplain; kk += 4) {
+                            const uint4 e4 = nx;
+                            nx = QS_ADJ(row0 + (kk >> 2) + 1);
+                            const int sb = kend - 1 - kk, k = k0 + kk;
+                            QS_EDGE(e4.x, k, sb, QS_NOFIX)
+                            QS_EDGE(e4.y, k + 1, sb - 1, QS_NOFIX)
+                            QS_EDGE(e4.z, k + 2, sb - 2, QS_NOFIX)
+                            QS_EDGE(e4.w, k + 3, sb - 3, QS_NOFIX)
+                        }
+#pragma unroll 1
+                        for (; kk < kend; kk += 4) {
+                            const uint4 e4 = nx;
+                            nx = QS_ADJ(row0 + (kk >> 2) + 1);
+                            const int sb = kend - 1 - kk, k = k0 + kk;
+                            QS_EDGE(e4.x, k, sb, QS_TAILFIX)                  // (k < wmax: a group starts below the largest degree)
+                            if (k + 1 < wmax) QS_EDGE(e4.y, k + 1, sb - 1, QS_TAILFIX) else { neww <<= 1; ltw <<= 1; }
+                            if (k + 2 < wmax) QS_EDGE(e4.z, k + 2, sb - 2, QS_TAILFIX) else { neww <<= 1; ltw <<= 1; }
+                            if (k + 3 < wmax) QS_EDGE(e4.w, k + 3, sb - 3, QS_TAILFIX) else { neww <<= 1; ltw <<= 1; }
+                        }
+                        neg[w] = neww;
+                        par ^= neww;
+                        if (ltw) kst = (uint32_t)(k0 + kend - 1 - (int)__builtin_ctz(ltw));   // a later word's improvement overrides an earlier one's
+                    }
+                }
+                // outgoing sign on edge k = syndrome ^ (parity of all incoming signs) ^ incoming sign k
+                const uint32_t flip = 0u - ((synd[j] ^ (uint32_t)__popc(par)) & 1u);
+#pragma unroll
+                for (int w = 0; w < NSW; ++w) Q[j][w] = neg[w] ^ flip;
+                mx2 = fmaxf(mx2, a2);
+                us = us || (((synd[j] ^ (hp >> 31)) & 1u) != 0u);
+            }
+            A1[j] = a1; A2[j] = a2; KST[j] = kst;
+        }
+        {
+            const unsigned long long bal = __ballot(us);
+            if ((tid & 63) == 0) misc[32 + (tid >> 6)] = (bal != 0ull);
+        }
+        __syncthreads();
+        int anyun = 0;
+        {
+            const int4 *f4 = reinterpret_cast<const int4 *>(misc + 32);
+            for (int w = 0; w < (NW + 3) / 4; ++w) {
+                const int4 v = f4[w];
+                anyun |= v.x | v.y | v.z | v.w;
+            }
+        }
+        if (t >= 1 && !anyun) { converged = 1; break; }
+        if (t == a.max_iter) break;
+        // ---- scatter pass, in place: each edge's accumulator moves by (new message) - (message sent last time)
+        __builtin_amdgcn_s_setprio(QS_PRIO);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            if (act[j]) {
+                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
+                const int adj_voff = (j * T + tid) * 16;
+                const int dc = dcs[j];
+                const int n1i = (int)A1[j], s1i = (int)S1[j];
+                const int pdif = n1i - s1i, pxq = pdif ^ (n1i + s1i);
+                const uint32_t kst = KST[j];
+                const uint32_t ko = KOLD[j] == 0xFFFFFFFFu ? 0u : KOLD[j];     // (no message sent yet: s1 = s2 = 0, any edge will do)
+                const uint32_t fixn_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((kst >> 2) * (uint32_t)adj_row + (kst & 3u) * 4u) + adj_voff, 0, 0);
+                const uint32_t fixo_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((ko >> 2) * (uint32_t)adj_row + (ko & 3u) * 4u) + adj_voff, 0, 0);
+                const int ng = trip >> 2;
+#define QS_GROUP(e4, gi_)                                                                                                            \
+                {                                                                                                                    \
+                    const int k = (gi_) * 4;                                                                                         \
+                    if (k + 4 <= wmin4) {                                                                                            \
+                        QS_SCAT(e4.x, 0, 31, QS_NOFIX) QS_SCAT(e4.y, 0, 30, QS_NOFIX) QS_SCAT(e4.z, 0, 29, QS_NOFIX) QS_SCAT(e4.w, 0, 28, QS_NOFIX) \
+                    } else {                                                                                                         \
+                        QS_SCAT(e4.x, k, 31, QS_TAILZERO)                                                                            \
+                        if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, 30, QS_TAILZERO)                                                      \
+                        if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, 29, QS_TAILZERO)                                                      \
+                        if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, 28, QS_TAILZERO)                                                      \
+                    }                                                                                                                \
+                    own <<= 4; xw <<= 4;                                                                                             \
+                }
+#pragma unroll
+                for (int w = 0; w < NSW; ++w) {
+                    if (32 * w < trip) {
+                        const int kendw = min(trip - 32 * w, 32);
+                        uint32_t own = Q[j][w] << (32 - kendw), xw = (Q[j][w] ^ O[j][w]) << (32 - kendw);
+                        const int g1 = min(ng, 8 * w + 8);
+                        uint4 ea = QS_ADJ(8 * w), eb;
+#pragma unroll 1
+                        for (int gi = 8 * w; gi < g1; gi += 2) {
+                            eb = QS_ADJ(gi + 1);                              // (the table has two spare group rows)
+                            QS_GROUP(ea, gi)
+                            ea = QS_ADJ(gi + 2);
+                            if (gi + 1 < g1) QS_GROUP(eb, gi + 1)
+                        }
+                    }
+                }
+#undef QS_GROUP
+                // the argmin edges carry min2, not min1: the new one gains +-(min2 - min1), the old one gives its own back
+                {
+                    const int kw = (int)(kst >> 5), kendw = min(trip - 32 * kw, 32);
+                    uint32_t wd = Q[j][0];
+#pragma unroll
+                    for (int w = 1; w < NSW; ++w) wd = (kw == w) ? Q[j][w] : wd;
+                    const uint32_t sg_ = (wd >> (kendw - 1 - (int)(kst & 31u))) & 1u;
+                    const int dlt = (int)A2[j] - n1i;
+                    (void)__hip_atomic_fetch_add(QS_LDS(fixn_off), sg_ ? -dlt : dlt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                {
+                    const int kw = (int)(ko >> 5), kendw = min(trip - 32 * kw, 32);
+                    uint32_t wd = O[j][0];
+#pragma unroll
+                    for (int w = 1; w < NSW; ++w) wd = (kw == w) ? O[j][w] : wd;
+                    const uint32_t sg_ = (wd >> (kendw - 1 - (int)(ko & 31u))) & 1u;
+                    const int dlt = (int)S2[j] - s1i;
+                    (void)__hip_atomic_fetch_add(QS_LDS(fixo_off), sg_ ? dlt : -dlt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            S1[j] = A1[j]; S2[j] = A2[j]; KOLD[j] = KST[j];
+#pragma unroll
+            for (int w = 0; w < NSW; ++w) O[j][w] = Q[j][w];
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        ++t;
+    }
+#undef QS_ADJ
+    // L(t) - 1 is in the buffer: the scatter pass of the last iteration did not run
+
+    // ---- did the bound hold?
+    {
+        const int tripped = qd_block_or(!(mx2 < x.m2_limit) ? 1 : 0, misc, NW, 0);
+        if (tripped) {
+            if (tid == 0) {
+                const int at = atomicAdd(x.recheck_count, 1);
+                if (at < x.recheck_cap) x.recheck_list[at] = (int32_t)shot;
+            }
+            return;
+        }
+    }
+    // ---- hard decision, packed by fault index
+    for (int b = tid; b < g.n; b += T)
+        if (*QS_LDS(cur + 4u * (uint32_t)b) < 0) {
+            const uint32_t jf = g.bit_orig[b];
+            atomicOr(&outw[jf >> 5], 1u << (jf & 31u));
+        }
+    if (!converged && a.want_llr && tid == 0) misc[48] = atomicAdd(a.fail_count, 1);
+    __syncthreads();
+    for (int w = tid; w < g.out_words; w += T) a.err_bits[shot * g.out_words + w] = outw[w];
+    if (!converged && a.want_llr) {
+        const int slot = misc[48];
+        float *dst = a.llr_ws + (int64_t)slot * n_pad;
+        for (int b = tid; b < g.n; b += T) dst[b] = (float)(*QS_LDS(cur + 4u * (uint32_t)b) + 1) * x.grid_inv;
+        if (tid == 0) a.fail_list[slot] = (int32_t)shot;
+    }
+    if (tid == 0) a.status[shot] = t | (converged << 16) | a.status_or;
+}
+
+template <int T, int MW, int CPL, int NSW>
+static hipError_t launch_scatter_wide_t(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s)
+{
+    auto k = qd_bp_scatter_wide_kernel<T, MW, CPL, NSW>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, sg.lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned)B), dim3(T), sg.lds_bytes, s, g, sg, a, x);
+    return hipGetLastError();
+}
+
+// sg.wide_threads is one of the workgroup sizes instantiated here (qd_graph_create chooses it: the smallest that gives every check a lane
+// slot with two checks per lane)
+hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s)
+{
+    switch (sg.wide_threads) {
+    case 704: return launch_scatter_wide_t<704, 6, 2, 3>(g, sg, a, x, B, s);      // 11 wavefronts; two workgroups per CU: <= 6 per SIMD, 80 registers
+    case 1024: return launch_scatter_wide_t<1024, 4, 2, 3>(g, sg, a, x, B, s);
+    default: return hipErrorInvalidValue;
+    }
+}

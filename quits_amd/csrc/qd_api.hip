@@ -15,6 +15,7 @@
 
 hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_scatter(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s);
+hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
                                 int schedule, int64_t shot0, int nshots, hipStream_t s);
 int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg);
@@ -192,7 +193,14 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     // the shape conditions of the scatter kernel (its LDS fit is checked where the layouts are known)
     // (windows small enough for 256-thread workgroups stay with the gather kernel: measured 4.0 vs 4.7 ms per launch on the W = 3
     // windows of the [[72,12,6]] code, 9.0 vs 9.8 ms on those of the [[144,12,12]] code, profiles/r03z_scatter_other_configs.txt)
-    const bool scatter_shape = m <= bp_threads_ && bp_threads_ >= 512 && max_rdeg_pad <= 64 && *std::min_element(rdeg.begin(), rdeg.end()) >= 2;
+    const int min_rdeg_ = *std::min_element(rdeg.begin(), rdeg.end());
+    const bool scatter_narrow = m <= bp_threads_ && bp_threads_ >= 512 && max_rdeg_pad <= 64 && min_rdeg_ >= 2;
+    // ... and of its two-checks-per-lane form (bp_scatter_wide.hip): more checks than a workgroup has lanes, or rows of 65..96 faults --
+    // the QLP windows of BASELINE configs[4] (1326 checks of up to 78 faults on 704 lanes)
+    const int wide_threads_ = pad64((m + 1) / 2) <= 704 ? 704 : 1024;
+    const bool scatter_wide = !scatter_narrow && bp_threads_ == 1024 && m <= 2 * wide_threads_ && max_rdeg_pad <= 96 && min_rdeg_ >= 2 &&
+                              (m > 1024 || max_rdeg_pad > 64) && !std::getenv("QD_NO_SCATTER_WIDE");
+    const bool scatter_shape = scatter_narrow || scatter_wide;
     const int dummy_bit = n_pad, dummy_chk = m_pad;        // one extra LDS slot each
     if ((m_pad + 1) * 16 > 65535) {
         delete g;
@@ -498,7 +506,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         sc.lds_bytes = sc.off_misc + 256;
         const int by_threads = 2048 / bp.threads;
         const int res_old = std::min(by_threads, QD_LDS_BYTES / std::max(1, bp.lds_bytes));
-        const int res_new = std::min(by_threads, QD_LDS_BYTES / sc.lds_bytes);
+        const int res_new = std::min(2048 / (scatter_wide ? wide_threads_ : bp.threads), QD_LDS_BYTES / sc.lds_bytes);
         if (scatter_shape && min_rdeg >= 2 && bp.lds_bytes <= QD_LDS_BYTES && res_new >= 1 && res_new >= res_old) {
             const int rows = max_rdeg_pad / 4 + 2;            // two spare group rows: the kernel loads up to two groups ahead unconditionally
             std::vector<uint32_t> adjA((size_t)rows * m_pad * 4, (uint32_t)(sc.offA + n_pad * 4));
@@ -520,6 +528,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             rcs |= g->mem.upload(deg_w, &sc.deg_w); rcs |= g->mem.upload(chk_deg, &sc.chk_deg);
             if (rcs) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while uploading the scatter adjacency"); }
             sc.ok = 1;
+            sc.wide_threads = scatter_wide ? wide_threads_ : 0;
         }
     }
 
@@ -762,7 +771,7 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
 extern "C" int qd_decoder_info(const qd_decoder *d, int32_t *info)
 {
     if (!d || !info) return fail(QD_EINVAL, "null argument");
-    info[0] = d->grid_k; info[1] = d->grid_kc; info[2] = d->general; info[3] = d->scatter;
+    info[0] = d->grid_k; info[1] = d->grid_kc; info[2] = d->general; info[3] = d->scatter ? (d->g->sc.wide_threads ? 2 : 1) : 0;
     return QD_OK;
 }
 
@@ -993,7 +1002,8 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
                 ScatArgs x{};
                 x.prior_g = d->prior_g; x.grid_inv = std::ldexp(1.0f, -d->grid_k); x.m2_limit = d->m2_limit;
                 x.recheck_list = d->recheck_list; x.recheck_count = recheck_count; x.recheck_cap = d->recheck_cap;
-                HIP_TRY(qd_launch_bp_scatter(d->bp_fine, d->g->sc, a1, x, B, s));
+                if (d->g->sc.wide_threads) HIP_TRY(qd_launch_bp_scatter_wide(d->bp_fine, d->g->sc, a1, x, B, s));
+                else HIP_TRY(qd_launch_bp_scatter(d->bp_fine, d->g->sc, a1, x, B, s));
                 a1.shot_list = d->recheck_list; a1.shot_count = recheck_count;
                 HIP_TRY(qd_launch_bp(d->bp_fine, a1, std::min<int64_t>(B, d->recheck_cap), s));
             } else

@@ -90,7 +90,7 @@ class BatchDecoder:
         arr = (C.c_int32 * 4)()
         _lib.check(self._L.qd_decoder_info(self._h, arr))
         return {"llr_grid_bits": int(arr[0]), "llr_coarse_bits": int(arr[1]), "edge_kernel": bool(arr[2]),
-                "scatter_kernel": bool(arr[3])}
+                "scatter_kernel": bool(arr[3]), "scatter_wide_kernel": int(arr[3]) == 2}
 
     def set_workspace_limit(self, nbytes: int):
         """Cap the HBM message workspace of the one-message-per-edge BP kernel (product_sum / serial); no effect on the LDS kernel."""

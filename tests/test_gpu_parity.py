@@ -889,6 +889,44 @@ def test_osdw_row_form_and_column_form_agree(gpu, monkeypatch):
             assert np.array_equal(out[0][0][b], ref), (m, b, st)
 
 
+@pytest.mark.parametrize("scale,shots,max_iter", [(1.0 / 3.0, 1024, 30), (1.0, 256, 12)])
+def test_wide_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, scale, shots, max_iter):
+    """configs[4] windows (QLP [[1020,136]], W = 3: 1350 checks of up to 78 faults, 18 900 faults) run flooding min-sum in the
+    two-checks-per-lane scatter kernel (bp_scatter_wide.hip: 704 lanes, three sign words).  Same contract as the one-check-per-lane
+    form: hard decisions, status words and OSD-0 outputs identical to the gather kernel's (QD_NO_SCATTER=1), also through the recheck
+    pass, and equal to the double-precision oracle on the same LLR grid.  Priors of the fixture (p = 3e-3, above threshold: nearly
+    every shot runs all iterations) and scaled to ~1e-3 (most shots converge, at different iterations)."""
+    from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph, unpack_bits
+    w = helpers.window_set("qlp1020_cardinal_r20_p0.003", 3, 1)[1]
+    H, L, pri = w["H"], w["L"], np.asarray(w["priors"], dtype=np.float64) * scale
+    assert H.shape == (1350, 18900)
+    det, _ = DemSampler(H, L, pri).sample(shots, seed=5, shot0=1)
+    det[0] = 0
+    wg = WindowGraph(H, pri)
+    out = {}
+    for tag, env in (("gather", {"QD_NO_SCATTER": "1"}), ("scatter", {}), ("recheck", {"QD_SCATTER_M2_LIMIT": "30000"})):
+        monkeypatch.delenv("QD_NO_SCATTER", raising=False)
+        monkeypatch.delenv("QD_SCATTER_M2_LIMIT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dec = BatchDecoder(wg, max_iter=max_iter, osd_method="osd_0")
+        assert dec.info()["scatter_kernel"] == (tag != "gather"), (tag, dec.info())
+        for stage in (1, 3):
+            bits, status = dec.decode(det, stage=stage)
+            out[(tag, stage)] = (unpack_bits(bits, wg.n).cpu().numpy(), status.cpu().numpy())
+    for tag in ("scatter", "recheck"):
+        for stage in (1, 3):
+            assert np.array_equal(out[(tag, stage)][1], out[("gather", stage)][1]), (tag, stage)
+            assert np.array_equal(out[(tag, stage)][0], out[("gather", stage)][0]), (tag, stage)
+    st = out[("scatter", 1)][1]
+    conv = ((st >> 16) & 1).mean()
+    assert (conv > 0.5) if scale < 1.0 else (conv < 0.9), conv
+    nref = 48
+    g, prm = _oracle(H, pri, max_iter, "osd_0")
+    ref, flags = g.decode_batch(np.ascontiguousarray(det[:nref].cpu().numpy()), prm)
+    assert np.array_equal(out[("scatter", 3)][0][:nref], ref)
+
+
 @pytest.mark.parametrize("name,shots,max_iter", [
     ("bb144_custom_r12_p0.003", 4096, 50),        # the headline window: 1008 checks on 1024 lanes, rows of 16..35 faults (two sign words)
     ("bb72_custom_r6_p0.003", 4096, 30),
