@@ -299,13 +299,20 @@ static hipError_t launch_scatter_wide_t(const BpGraphDev &g, const ScatGraphDev 
     return hipGetLastError();
 }
 
-// sg.wide_threads is one of the workgroup sizes instantiated here (qd_graph_create chooses it: the smallest that gives every check a lane
-// slot with two checks per lane)
+// (sg.wide_threads, sg.wide_cpl) is one of the shapes instantiated here (qd_graph_create chooses it); rows of up to 64 faults take two
+// sign words, up to 96 three
 hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s)
 {
-    switch (sg.wide_threads) {
-    case 704: return launch_scatter_wide_t<704, 6, 2, 3>(g, sg, a, x, B, s);      // 11 wavefronts; two workgroups per CU: <= 6 per SIMD, 80 registers
-    case 1024: return launch_scatter_wide_t<1024, 4, 2, 3>(g, sg, a, x, B, s);
+    const bool two_words = g.max_rdeg_pad <= 64;
+    switch (sg.wide_threads * 8 + sg.wide_cpl) {
+    case 512 * 8 + 2:           // headline-size windows (513..1024 checks) on half the lanes: four workgroups per CU
+        return two_words ? launch_scatter_wide_t<512, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
+    case 256 * 8 + 2:           // 257..512 checks: eight workgroups per CU
+        return two_words ? launch_scatter_wide_t<256, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
+    case 704 * 8 + 2:           // 11 wavefronts; two workgroups per CU: <= 6 per SIMD, 80 registers
+        return launch_scatter_wide_t<704, 6, 2, 3>(g, sg, a, x, B, s);
+    case 1024 * 8 + 2: return launch_scatter_wide_t<1024, 4, 2, 3>(g, sg, a, x, B, s);
+    case 512 * 8 + 3: return launch_scatter_wide_t<512, 4, 3, 3>(g, sg, a, x, B, s);      // (A/B: QD_SCATTER_WIDE_T512)
     default: return hipErrorInvalidValue;
     }
 }

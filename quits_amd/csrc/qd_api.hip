@@ -528,7 +528,19 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             rcs |= g->mem.upload(deg_w, &sc.deg_w); rcs |= g->mem.upload(chk_deg, &sc.chk_deg);
             if (rcs) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while uploading the scatter adjacency"); }
             sc.ok = 1;
-            sc.wide_threads = scatter_wide ? wide_threads_ : 0;
+            // Several checks per lane (bp_scatter_wide.hip).  (a) windows the one-check-per-lane kernel cannot take: two checks per lane
+            // on 704 (or 1024) lanes.  (b) windows it can take, on HALF the lanes with two checks each: the same number of wavefronts per
+            // CU in twice as many workgroups, i.e. half as many wavefronts per barrier -- headline BP 50.3 -> 44.2 ms per 65 536 shots,
+            // same bits (profiles/r03x_scatter_cpl2_ab.txt); taken when the LDS holds twice the workgroups.  QD_SCATTER_CPL1=1 keeps
+            // one check per lane.
+            sc.wide_threads = 0; sc.wide_cpl = 0;
+            if (scatter_wide) {
+                sc.wide_threads = wide_threads_; sc.wide_cpl = 2;
+                if (std::getenv("QD_SCATTER_WIDE_T512") && m <= 1536) { sc.wide_threads = 512; sc.wide_cpl = 3; }     // A/B switch
+            } else if (!std::getenv("QD_SCATTER_CPL1")) {
+                if (bp.threads == 1024 && 4 * sc.lds_bytes <= QD_LDS_BYTES) { sc.wide_threads = 512; sc.wide_cpl = 2; }
+                else if (bp.threads == 512 && 8 * sc.lds_bytes <= QD_LDS_BYTES && !std::getenv("QD_SCATTER_NO_CPL2_256")) { sc.wide_threads = 256; sc.wide_cpl = 2; }
+            }
         }
     }
 

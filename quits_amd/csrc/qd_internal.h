@@ -49,8 +49,8 @@ struct ScatGraphDev {
     const uint32_t *deg_w;      // [m_pad/64]             per wavefront of check slots: trip count (multiple of 4) | largest degree << 8 | smallest << 16
     const uint8_t *chk_deg;     // [m_pad]                degree of the check slot (0 beyond m)
     int offA, offB, off_out, off_bmap, off_misc, lds_bytes;
-    int wide_threads;           // 0: one check per lane (bp_scatter.hip); else the workgroup size of qd_bp_scatter_wide_kernel (two checks per
-                                //    lane, three sign words: more checks than lanes, or rows of 65..96 faults; bp_scatter_wide.hip)
+    int wide_threads, wide_cpl; // 0: one check per lane (bp_scatter.hip); else the workgroup size and the checks per lane of
+                                //    qd_bp_scatter_wide_kernel (bp_scatter_wide.hip)
 };
 struct ScatArgs {
     const int32_t *prior_g;     // [n_pad] channel LLR of the bit slot in grid units (llr * 2^k, an integer) MINUS ONE: the accumulators hold L - 1

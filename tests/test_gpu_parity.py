@@ -896,10 +896,12 @@ def test_wide_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, scale, sh
     form: hard decisions, status words and OSD-0 outputs identical to the gather kernel's (QD_NO_SCATTER=1), also through the recheck
     pass, and equal to the double-precision oracle on the same LLR grid.  Priors of the fixture (p = 3e-3, above threshold: nearly
     every shot runs all iterations) and scaled to ~1e-3 (most shots converge, at different iterations)."""
+    from scipy.sparse import csc_matrix
     from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph, unpack_bits
     w = helpers.window_set("qlp1020_cardinal_r20_p0.003", 3, 1)[1]
-    H, L, pri = w["H"], w["L"], np.asarray(w["priors"], dtype=np.float64) * scale
+    H, pri = w["H"], np.asarray(w["priors"], dtype=np.float64) * scale
     assert H.shape == (1350, 18900)
+    L = csc_matrix(np.ones((1, H.shape[1]), dtype=np.uint8))      # the sampler wants an observable matrix over the window's faults; not used
     det, _ = DemSampler(H, L, pri).sample(shots, seed=5, shot0=1)
     det[0] = 0
     wg = WindowGraph(H, pri)
@@ -920,7 +922,7 @@ def test_wide_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, scale, sh
             assert np.array_equal(out[(tag, stage)][0], out[("gather", stage)][0]), (tag, stage)
     st = out[("scatter", 1)][1]
     conv = ((st >> 16) & 1).mean()
-    assert (conv > 0.5) if scale < 1.0 else (conv < 0.9), conv
+    assert (0.05 < conv < 0.95) if scale < 1.0 else (conv < 0.9), conv       # a mix of iteration counts / mostly max_iter
     nref = 48
     g, prm = _oracle(H, pri, max_iter, "osd_0")
     ref, flags = g.decode_batch(np.ascontiguousarray(det[:nref].cpu().numpy()), prm)
