@@ -10,8 +10,8 @@
 // per QLP shot, ONE workgroup of 1024 threads per CU, four wavefronts per SIMD.  In the scatter form the LDS holds one int32 accumulator
 // per fault (76 KB), so TWO shots share a CU; a workgroup of 704 threads (11 wavefronts) gives every lane two checks, whose state
 // (two minima, argmin position, three sign words, twice: what was sent and what the gather pass just found) stays in registers.
-// Check slots are sorted by degree, lane l owns slots l and T + l: a wavefront's 64 checks of one round are 64 consecutive slots, so
-// the trip count stays wave-uniform.
+// Check slots are sorted by degree; a wavefront's 64 checks of one round are 64 consecutive slots (sg.wave_map), so the trip count stays
+// wave-uniform, and the rounds are dealt out so that the wavefronts of a workgroup walk equally many edges between two barriers.
 //
 // One iteration = [gather pass of check 0, then of check 1] barrier [converged? | scatter pass of check 0, then of check 1] barrier,
 // in place as in bp_scatter.hip (every gather of the iteration precedes every add).
@@ -42,10 +42,13 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
     int dcs[CPL];
     bool act[CPL];
     if (tid < 64) misc[tid] = 0;
+    int cs[CPL];                                       // my check slot of round j (sg.wave_map: 64 consecutive slots per wavefront and round)
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const int c = j * T + tid;
-        act[j] = c < g.m;
+        const int sw = __builtin_amdgcn_readfirstlane(sg.wave_map[j * NW + (tid >> 6)]);
+        const int c = sw * 64 + (tid & 63);
+        cs[j] = c;
+        act[j] = sw >= 0 && c < g.m;
         synd[j] = 0u; dcs[j] = 0;
         if (act[j]) {
             const uint32_t o = g.chk_orig[c];
@@ -72,8 +75,8 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
     int dws[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
-        const int wslot = __builtin_amdgcn_readfirstlane((j * T + tid) >> 6);
-        dws[j] = wslot < (m_pad >> 6) ? (int)sg.deg_w[wslot] : 0;
+        const int wslot = __builtin_amdgcn_readfirstlane(cs[j] >> 6);
+        dws[j] = wslot >= 0 ? (int)sg.deg_w[wslot] : 0;
     }
     // check state, in registers: what each check SENT in the last scatter pass (the two minima, the position of the argmin edge, the
     // outgoing signs: edge k of a word of kend edges at bit kend - 1 - k) and what the gather pass of this iteration found
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             uint32_t kst = 0u;
             if (act[j]) {
                 const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
-                const int adj_voff = (j * T + tid) * 16;
+                const int adj_voff = cs[j] * 16;
                 const float s1 = S1[j], s2 = S2[j];
                 const uint32_t kold = KOLD[j];
                 const int dc = dcs[j];
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
         for (int j = 0; j < CPL; ++j) {
             if (act[j]) {
                 const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
-                const int adj_voff = (j * T + tid) * 16;
+                const int adj_voff = cs[j] * 16;
                 const int dc = dcs[j];
                 const int n1i = (int)A1[j], s1i = (int)S1[j];
                 const int pdif = n1i - s1i, pxq = pdif ^ (n1i + s1i);
@@ -309,10 +312,12 @@ hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg
         return two_words ? launch_scatter_wide_t<512, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
     case 256 * 8 + 2:           // 257..512 checks: eight workgroups per CU
         return two_words ? launch_scatter_wide_t<256, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
+    case 128 * 8 + 2:           // <= 256 checks: sixteen workgroups of two wavefronts per CU (A/B: QD_SCATTER_SMALL)
+        return two_words ? launch_scatter_wide_t<128, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
     case 704 * 8 + 2:           // 11 wavefronts; two workgroups per CU: <= 6 per SIMD, 80 registers
         return launch_scatter_wide_t<704, 6, 2, 3>(g, sg, a, x, B, s);
     case 1024 * 8 + 2: return launch_scatter_wide_t<1024, 4, 2, 3>(g, sg, a, x, B, s);
-    case 512 * 8 + 3: return launch_scatter_wide_t<512, 4, 3, 3>(g, sg, a, x, B, s);      // (A/B: QD_SCATTER_WIDE_T512)
+    case 512 * 8 + 3: return launch_scatter_wide_t<512, 4, 3, 3>(g, sg, a, x, B, s);      // QLP windows: 8 wavefronts x 3 rounds, 89 registers, two workgroups per CU
     default: return hipErrorInvalidValue;
     }
 }

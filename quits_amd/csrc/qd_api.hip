@@ -194,7 +194,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     // (windows small enough for 256-thread workgroups stay with the gather kernel: measured 4.0 vs 4.7 ms per launch on the W = 3
     // windows of the [[72,12,6]] code, 9.0 vs 9.8 ms on those of the [[144,12,12]] code, profiles/r03z_scatter_other_configs.txt)
     const int min_rdeg_ = *std::min_element(rdeg.begin(), rdeg.end());
-    const bool scatter_narrow = m <= bp_threads_ && bp_threads_ >= 512 && max_rdeg_pad <= 64 && min_rdeg_ >= 2;
+    const bool scatter_narrow = m <= bp_threads_ && (bp_threads_ >= 512 || std::getenv("QD_SCATTER_SMALL")) && max_rdeg_pad <= 64 && min_rdeg_ >= 2;
     // ... and of its two-checks-per-lane form (bp_scatter_wide.hip): more checks than a workgroup has lanes, or rows of 65..96 faults --
     // the QLP windows of BASELINE configs[4] (1326 checks of up to 78 faults on 704 lanes)
     const int wide_threads_ = pad64((m + 1) / 2) <= 704 ? 704 : 1024;
@@ -528,18 +528,70 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             rcs |= g->mem.upload(deg_w, &sc.deg_w); rcs |= g->mem.upload(chk_deg, &sc.chk_deg);
             if (rcs) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while uploading the scatter adjacency"); }
             sc.ok = 1;
-            // Several checks per lane (bp_scatter_wide.hip).  (a) windows the one-check-per-lane kernel cannot take: two checks per lane
-            // on 704 (or 1024) lanes.  (b) windows it can take, on HALF the lanes with two checks each: the same number of wavefronts per
-            // CU in twice as many workgroups, i.e. half as many wavefronts per barrier -- headline BP 50.3 -> 44.2 ms per 65 536 shots,
-            // same bits (profiles/r03x_scatter_cpl2_ab.txt); taken when the LDS holds twice the workgroups.  QD_SCATTER_CPL1=1 keeps
-            // one check per lane.
+            // Several checks per lane (bp_scatter_wide.hip).  (a) windows the one-check-per-lane kernel cannot take: three checks per
+            // lane on 512 lanes (or two on 704 / 1024).  (b) windows it can take, on HALF the lanes with two checks each: the same number
+            // of wavefronts per CU in twice as many workgroups, i.e. half as many wavefronts per barrier -- headline BP 50.3 -> 44.2 ms per
+            // 65 536 shots, same bits (profiles/r03x_scatter_cpl2_ab.txt); taken when the LDS holds twice the workgroups.
+            // QD_SCATTER_CPL1=1 keeps one check per lane.  Measured and not kept (profiles/r03x_scatter_shapes2_ab.txt): four checks per
+            // lane on a quarter of the lanes (headline 46.2 -> 50.9 ms), 384 lanes x 4 checks for the QLP windows (19.2 -> 24.4 ms).
             sc.wide_threads = 0; sc.wide_cpl = 0;
             if (scatter_wide) {
                 sc.wide_threads = wide_threads_; sc.wide_cpl = 2;
-                if (std::getenv("QD_SCATTER_WIDE_T512") && m <= 1536) { sc.wide_threads = 512; sc.wide_cpl = 3; }     // A/B switch
+                if (m <= 1536 && !std::getenv("QD_SCATTER_WIDE_T704")) { sc.wide_threads = 512; sc.wide_cpl = 3; }    // 19.8 -> 19.3 ms per QLP launch
             } else if (!std::getenv("QD_SCATTER_CPL1")) {
-                if (bp.threads == 1024 && 4 * sc.lds_bytes <= QD_LDS_BYTES) { sc.wide_threads = 512; sc.wide_cpl = 2; }
+                if (bp.threads == 1024 && 4 * sc.lds_bytes <= QD_LDS_BYTES) {
+                    sc.wide_threads = 512; sc.wide_cpl = 2;
+                }
                 else if (bp.threads == 512 && 8 * sc.lds_bytes <= QD_LDS_BYTES && !std::getenv("QD_SCATTER_NO_CPL2_256")) { sc.wide_threads = 256; sc.wide_cpl = 2; }
+                else if (bp.threads == 256 && 16 * sc.lds_bytes <= QD_LDS_BYTES) { sc.wide_threads = 128; sc.wide_cpl = 2; }    // (only with QD_SCATTER_SMALL: A/B)
+            }
+            if (sc.wide_threads) {
+                // deal the slot-waves (64 consecutive check slots, heaviest first) to the workgroup's wavefronts so that the largest
+                // number of edges a wavefront walks between two barriers is small: each goes to the wavefront with the fewest edges so
+                // far that still has a free round (longest-processing-time rule), then single moves / swaps out of the heaviest
+                // wavefront while they lower the maximum (QLP windows on 8 wavefronts x 3 rounds: 222 -> 202 edge steps)
+                const int nw = sc.wide_threads / 64, nsw = m_pad / 64, cpl = sc.wide_cpl;
+                const bool natural = std::getenv("QD_SCATTER_NATURAL_ROUNDS") != nullptr;      // A/B: round j of wavefront w = slot-wave j * nw + w
+                auto cost = [&](int sw) { return (int)(deg_w[sw] & 0xFF) + 6; };               // trip count + the per-check work outside the edge loops
+                std::vector<std::vector<int>> bins(nw);
+                std::vector<int> load(nw, 0);
+                for (int sw = 0; sw < nsw; ++sw) {
+                    int best = -1;
+                    if (natural) best = sw % nw;
+                    else
+                        for (int w = 0; w < nw; ++w)
+                            if ((int)bins[w].size() < cpl && (best < 0 || load[w] < load[best])) best = w;
+                    if (best < 0 || (int)bins[best].size() >= cpl) { g->mem.release(); delete g; return fail(QD_ECAPACITY, "scatter kernel shape does not cover the window"); }
+                    bins[best].push_back(sw); load[best] += cost(sw);
+                }
+                for (int pass = 0; pass < 1000 && !natural; ++pass) {
+                    const int hi = (int)(std::max_element(load.begin(), load.end()) - load.begin()), Lh = load[hi];
+                    int gain = 0, bi = -1, bw = -1, bk = -1;
+                    for (int i = 0; i < (int)bins[hi].size(); ++i) {
+                        const int x = cost(bins[hi][i]);
+                        for (int w = 0; w < nw; ++w) {
+                            if (w == hi) continue;
+                            if ((int)bins[w].size() < cpl) {
+                                const int nl = std::max(Lh - x, load[w] + x);
+                                if (Lh - nl > gain) { gain = Lh - nl; bi = i; bw = w; bk = -1; }
+                            }
+                            for (int k = 0; k < (int)bins[w].size(); ++k) {
+                                const int y = cost(bins[w][k]);
+                                if (y >= x) continue;
+                                const int nl = std::max(Lh - x + y, load[w] - y + x);
+                                if (Lh - nl > gain) { gain = Lh - nl; bi = i; bw = w; bk = k; }
+                            }
+                        }
+                    }
+                    if (bi < 0) break;
+                    const int x = cost(bins[hi][bi]);
+                    if (bk < 0) { bins[bw].push_back(bins[hi][bi]); bins[hi].erase(bins[hi].begin() + bi); load[hi] -= x; load[bw] += x; }
+                    else { const int y = cost(bins[bw][bk]); std::swap(bins[hi][bi], bins[bw][bk]); load[hi] += y - x; load[bw] += x - y; }
+                }
+                std::vector<int32_t> wmap((size_t)cpl * nw, -1);
+                for (int w = 0; w < nw; ++w)
+                    for (int j = 0; j < (int)bins[w].size(); ++j) wmap[(size_t)j * nw + w] = bins[w][j];
+                if (g->mem.upload(wmap, &sc.wave_map)) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while uploading the scatter wave map"); }
             }
         }
     }

@@ -49,6 +49,8 @@ struct ScatGraphDev {
     const uint32_t *deg_w;      // [m_pad/64]             per wavefront of check slots: trip count (multiple of 4) | largest degree << 8 | smallest << 16
     const uint8_t *chk_deg;     // [m_pad]                degree of the check slot (0 beyond m)
     int offA, offB, off_out, off_bmap, off_misc, lds_bytes;
+    const int32_t *wave_map;    // [wide_cpl][wide_threads / 64] the 64 consecutive check slots (index / 64) a wavefront takes in its j-th round, -1:
+                                //                        none; chosen so that the wavefronts of a workgroup walk equally many edges (slots are sorted by degree)
     int wide_threads, wide_cpl; // 0: one check per lane (bp_scatter.hip); else the workgroup size and the checks per lane of
                                 //    qd_bp_scatter_wide_kernel (bp_scatter_wide.hip)
 };

@@ -892,7 +892,7 @@ def test_osdw_row_form_and_column_form_agree(gpu, monkeypatch):
 @pytest.mark.parametrize("scale,shots,max_iter", [(1.0 / 3.0, 1024, 30), (1.0, 256, 12)])
 def test_wide_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, scale, shots, max_iter):
     """configs[4] windows (QLP [[1020,136]], W = 3: 1350 checks of up to 78 faults, 18 900 faults) run flooding min-sum in the
-    two-checks-per-lane scatter kernel (bp_scatter_wide.hip: 704 lanes, three sign words).  Same contract as the one-check-per-lane
+    several-checks-per-lane scatter kernel (bp_scatter_wide.hip: 512 lanes x 3 checks, or 704 x 2; three sign words).  Same contract as the one-check-per-lane
     form: hard decisions, status words and OSD-0 outputs identical to the gather kernel's (QD_NO_SCATTER=1), also through the recheck
     pass, and equal to the double-precision oracle on the same LLR grid.  Priors of the fixture (p = 3e-3, above threshold: nearly
     every shot runs all iterations) and scaled to ~1e-3 (most shots converge, at different iterations)."""
@@ -906,17 +906,19 @@ def test_wide_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, scale, sh
     det[0] = 0
     wg = WindowGraph(H, pri)
     out = {}
-    for tag, env in (("gather", {"QD_NO_SCATTER": "1"}), ("scatter", {}), ("recheck", {"QD_SCATTER_M2_LIMIT": "30000"})):
-        monkeypatch.delenv("QD_NO_SCATTER", raising=False)
-        monkeypatch.delenv("QD_SCATTER_M2_LIMIT", raising=False)
+    for tag, env in (("gather", {"QD_NO_SCATTER": "1"}), ("scatter", {}), ("recheck", {"QD_SCATTER_M2_LIMIT": "30000"}),
+                     ("two_checks_704_lanes", {"QD_SCATTER_WIDE_T704": "1"})):
+        for k in ("QD_NO_SCATTER", "QD_SCATTER_M2_LIMIT", "QD_SCATTER_WIDE_T704"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        dec = BatchDecoder(wg, max_iter=max_iter, osd_method="osd_0")
+        dec = BatchDecoder(WindowGraph(H, pri), max_iter=max_iter, osd_method="osd_0")
         assert dec.info()["scatter_kernel"] == (tag != "gather"), (tag, dec.info())
+        assert dec.info()["scatter_wide_kernel"] == (tag != "gather"), (tag, dec.info())
         for stage in (1, 3):
             bits, status = dec.decode(det, stage=stage)
             out[(tag, stage)] = (unpack_bits(bits, wg.n).cpu().numpy(), status.cpu().numpy())
-    for tag in ("scatter", "recheck"):
+    for tag in ("scatter", "recheck", "two_checks_704_lanes"):
         for stage in (1, 3):
             assert np.array_equal(out[(tag, stage)][1], out[("gather", stage)][1]), (tag, stage)
             assert np.array_equal(out[(tag, stage)][0], out[("gather", stage)][0]), (tag, stage)
@@ -935,8 +937,9 @@ def test_wide_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, scale, sh
     ("hgp225_cardinal_r3_p0.01", 2048, 20),       # rows of very different weights in one wavefront (the predicated tail groups)
 ])
 def test_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, name, shots, max_iter):
-    """Flooding min-sum on the LLR grid has two kernels: the scatter form (bp_scatter.hip: checks add their messages to integer
-    accumulators; the default where the window fits it) and the gather form (bp_kernels.hip, QD_NO_SCATTER=1).  Both are exact, so
+    """Flooding min-sum on the LLR grid has two kernels: the scatter form (checks add their messages to integer accumulators; the
+    default where the window fits it: bp_scatter_wide.hip with two checks per lane on half the lanes, or bp_scatter.hip with one,
+    QD_SCATTER_CPL1=1) and the gather form (bp_kernels.hip, QD_NO_SCATTER=1).  All are exact, so
     hard decisions, status words (iteration counts, convergence) and the OSD outputs computed from the posteriors must be
     identical -- also when the scatter kernel's cheap exactness bound is made to fail for most shots (QD_SCATTER_M2_LIMIT), so that
     they are decoded again by the gather kernel in the recheck pass -- and equal to the double-precision oracle."""
@@ -947,17 +950,20 @@ def test_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, name, shots, m
     det[0] = 0
     wg = WindowGraph(H, pri)
     out = {}
-    for tag, env in (("gather", {"QD_NO_SCATTER": "1"}), ("scatter", {}), ("recheck", {"QD_SCATTER_M2_LIMIT": "40000"})):
-        monkeypatch.delenv("QD_NO_SCATTER", raising=False)
-        monkeypatch.delenv("QD_SCATTER_M2_LIMIT", raising=False)
+    for tag, env in (("gather", {"QD_NO_SCATTER": "1"}), ("scatter", {}), ("recheck", {"QD_SCATTER_M2_LIMIT": "40000"}),
+                     ("one_check_per_lane", {"QD_SCATTER_CPL1": "1"}), ("natural_rounds", {"QD_SCATTER_NATURAL_ROUNDS": "1"})):
+        for k in ("QD_NO_SCATTER", "QD_SCATTER_M2_LIMIT", "QD_SCATTER_CPL1", "QD_SCATTER_NATURAL_ROUNDS"):
+            monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        dec = BatchDecoder(wg, max_iter=max_iter, osd_method="osd_0")
+        wg_t = WindowGraph(H, pri)       # the kernel shape is a property of the graph object (qd_graph_create)
+        dec = BatchDecoder(wg_t, max_iter=max_iter, osd_method="osd_0")
         assert dec.info()["scatter_kernel"] == (tag != "gather"), (tag, dec.info())
+        assert dec.info()["scatter_wide_kernel"] == (tag not in ("gather", "one_check_per_lane")), (tag, dec.info())
         for stage in (1, 3):
             bits, status = dec.decode(det, stage=stage)
             out[(tag, stage)] = (unpack_bits(bits, wg.n).cpu().numpy(), status.cpu().numpy())
-    for tag in ("scatter", "recheck"):
+    for tag in ("scatter", "recheck", "one_check_per_lane", "natural_rounds"):
         for stage in (1, 3):
             assert np.array_equal(out[(tag, stage)][0], out[("gather", stage)][0]), (tag, stage)
             assert np.array_equal(out[(tag, stage)][1], out[("gather", stage)][1]), (tag, stage)
