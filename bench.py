@@ -276,7 +276,8 @@ def main():
         try:
             pm = json.load(open(pmc_path))
             key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
-            kname = "qd_bp_scatter_kernel" if decs[0].info().get("scatter_kernel") else "qd_bp_minsum_kernel"
+            kname = (("qd_bp_scatter_wide_kernel" if decs[0].info().get("scatter_wide_kernel") else "qd_bp_scatter_kernel")
+                     if decs[0].info().get("scatter_kernel") else "qd_bp_minsum_kernel")
             if key in pm and not general and args.code == "bb144" and pm[key].get("kernel", "qd_bp_minsum_kernel") == kname:
                 traffic, traffic_src = pm[key]["bp_bytes_per_launch"], pm[key]["source"]
                 sq_counters = pm[key].get("sq_counters")
