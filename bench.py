@@ -99,8 +99,8 @@ def cpu_baseline(args, circ, hz, R, W, F, batch, plan, gpu_value):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--p", type=float, default=0.003)

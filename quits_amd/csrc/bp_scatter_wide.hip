@@ -19,6 +19,14 @@
 #include "../../include/quits_amd.h"
 #include "bp_scatter_edge.h"
 
+// Wavefront priorities.  A wavefront raises its priority for its last gather round (0 -> 2; the scatter pass runs at QS_PRIO = 1 as
+// in bp_scatter.hip): the wavefronts closest to the barrier go first, so a workgroup's stragglers are fewer.  Headline BP stage 44.1 ->
+// 43.2 ms per 65 536 shots; the other way round (first round high) 43.7, scatter pass at 0 / 2 / 3 no change, alternate wavefronts
+// high no change (profiles/r03x_wavefront_priority_ab.txt).
+#ifndef QSW_GPRIO
+#define QSW_GPRIO 1
+#endif
+
 template <int T, int MW, int CPL, int NSW>
 __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g, ScatGraphDev sg, DecodeArgs a, ScatArgs x)
 {
@@ -100,6 +108,9 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
         for (int j = 0; j < CPL; ++j) {
             float a1 = FLT_MAX, a2 = FLT_MAX;
             uint32_t kst = 0u;
+#if QSW_GPRIO       /* the later gather rounds of a wavefront run at a higher priority (see QSW_GPRIO above) */
+            if (j == 0) __builtin_amdgcn_s_setprio(0); else if (j == CPL - 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#endif
             if (act[j]) {
                 const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
                 const int adj_voff = cs[j] * 16;
@@ -172,6 +183,9 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             }
             A1[j] = a1; A2[j] = a2; KST[j] = kst;
         }
+#if QSW_GPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         {
             const unsigned long long bal = __ballot(us);
             if ((tid & 63) == 0) misc[32 + (tid >> 6)] = (bal != 0ull);

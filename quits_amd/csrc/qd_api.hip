@@ -191,10 +191,12 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int max_rdeg_pad = (max_rdeg + 3) & ~3;
     const int bp_threads_ = std::max(m, (n + 9) / 10) <= 256 ? 256 : (std::max(m, (n + 9) / 10) <= 512 ? 512 : 1024);
     // the shape conditions of the scatter kernel (its LDS fit is checked where the layouts are known)
-    // (windows small enough for 256-thread workgroups stay with the gather kernel: measured 4.0 vs 4.7 ms per launch on the W = 3
-    // windows of the [[72,12,6]] code, 9.0 vs 9.8 ms on those of the [[144,12,12]] code, profiles/r03z_scatter_other_configs.txt)
+    // (windows small enough for 256-thread workgroups: the one-check-per-lane kernel measured 4.0 vs 4.7 ms per launch on the W = 3
+    // windows of the [[72,12,6]] code, 9.0 vs 9.8 ms on those of the [[144,12,12]] code, profiles/r03z_scatter_other_configs.txt; on
+    // 128 lanes x 2 checks it is 3.98 -> 3.75 ms on the former (108 checks: taken) and 8.95 -> 9.45 ms on the latter (216 checks:
+    // stay with the gather kernel unless QD_SCATTER_SMALL is set), profiles/r03x_scatter_shapes_ab.txt)
     const int min_rdeg_ = *std::min_element(rdeg.begin(), rdeg.end());
-    const bool scatter_narrow = m <= bp_threads_ && (bp_threads_ >= 512 || std::getenv("QD_SCATTER_SMALL")) && max_rdeg_pad <= 64 && min_rdeg_ >= 2;
+    const bool scatter_narrow = m <= bp_threads_ && (bp_threads_ >= 512 || m <= 128 || std::getenv("QD_SCATTER_SMALL")) && max_rdeg_pad <= 64 && min_rdeg_ >= 2;
     // ... and of its two-checks-per-lane form (bp_scatter_wide.hip): more checks than a workgroup has lanes, or rows of 65..96 faults --
     // the QLP windows of BASELINE configs[4] (1326 checks of up to 78 faults on 704 lanes)
     const int wide_threads_ = pad64((m + 1) / 2) <= 704 ? 704 : 1024;
@@ -543,7 +545,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
                     sc.wide_threads = 512; sc.wide_cpl = 2;
                 }
                 else if (bp.threads == 512 && 8 * sc.lds_bytes <= QD_LDS_BYTES && !std::getenv("QD_SCATTER_NO_CPL2_256")) { sc.wide_threads = 256; sc.wide_cpl = 2; }
-                else if (bp.threads == 256 && 16 * sc.lds_bytes <= QD_LDS_BYTES) { sc.wide_threads = 128; sc.wide_cpl = 2; }    // (only with QD_SCATTER_SMALL: A/B)
+                else if (bp.threads == 256 && 16 * sc.lds_bytes <= QD_LDS_BYTES) { sc.wide_threads = 128; sc.wide_cpl = 2; }    // (<= 128 checks, or QD_SCATTER_SMALL)
             }
             if (sc.wide_threads) {
                 // deal the slot-waves (64 consecutive check slots, heaviest first) to the workgroup's wavefronts so that the largest
