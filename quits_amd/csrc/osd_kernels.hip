@@ -27,9 +27,6 @@
 //                        rows in registers with a write-through LDS mirror, ~80 KB of LDS -> two workgroups per CU.
 //   qd_osd0_full_kernel  sorts every column up front, all state in LDS, one workgroup per CU; used when a window has
 //                        more than 2048 detectors.  Same results by construction: both consume the same column order.
-#ifndef QD_OSD_PANEL_PRIO
-#define QD_OSD_PANEL_PRIO 0
-#endif
 #include "qd_internal.h"
 #include <cstdlib>
 #include <algorithm>
@@ -1300,13 +1297,7 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : QD_OSD0_WPS)) qd_osd0_re
                             __syncthreads();                                             // list, S.tb, S.sp, S.q are in place
                             if (tid < 64) {
                                 int dn = 0;
-#if QD_OSD_PANEL_PRIO
-                                __builtin_amdgcn_s_setprio(QD_OSD_PANEL_PRIO);       // the one wavefront the other seven wait for
-#endif
                                 const int np2 = qd_osd_panel_wave0(S, list, (int)nL, npiv, oflag, m_pad, &dn);
-#if QD_OSD_PANEL_PRIO
-                                __builtin_amdgcn_s_setprio(0);
-#endif
                                 if (tid == 0) { buf[48] = (uint32_t)np2; buf[49] = (uint32_t)dn; }
                             }
                             __syncthreads();
