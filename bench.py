@@ -189,8 +189,15 @@ def main():
         pred = plan.decode(det, stats)
         return count_mismatch(pred, obs), pred
 
+    # warm-up: the same loop body as the timed region (count accumulation and per-step statistics included), so that nothing is
+    # loaded lazily inside the timed region -- a rocprofv3 timeline showed a one-off 14 ms host stall at the first `fails += c`
+    # (profiles/r03f_bench_under_trace.json: 60.5 ms per step timed vs 55.6 ms for the same steps run again)
+    fails_w = torch.zeros((1,), dtype=torch.int64, device="cuda")
+    stats_w = []
     for i in range(args.warmup):
-        step(i)
+        c, _ = step(i, stats_w)
+        fails_w += c
+    del stats_w
     torch.cuda.synchronize()
 
     # ---- the timed region: K steps, no event recording inside (the per-launch hipEventCreate/Record pairs were
