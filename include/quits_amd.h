@@ -101,7 +101,8 @@ void qd_decoder_destroy(qd_decoder *d);
  * (QD_STATUS_COARSE_GRID), and flagged QD_STATUS_INEXACT if that trips too.  k = max(10, r), r = 23 - ceil(log2(8 * max|llr| * max_iter))
  * clamped to [2, 20]; info[1] = max(r - 4, 0) if r >= 10, else r (the rule's own grid takes the shots that outgrow 2^-10).  info[2] = 1 if BP runs in the one-message-per-edge kernel.  info[3] = 1 if the fine-grid pass of flooding min-sum runs in
  * the scatter kernel (bp_scatter.hip: same results, bit for bit; QD_NO_SCATTER=1 in the environment keeps the gather kernel),
- * 2 if in its two-checks-per-lane form (bp_scatter_wide.hip: windows of more than 1024 checks or rows of 65..96 faults).
+ * 2 if in its several-checks-per-lane form (bp_scatter_wide.hip: the default shape -- two checks per lane on half the lanes; three per
+ * lane for windows of more than 1024 checks or rows of 65..96 faults).
  * No reference counterpart (ldpc computes in double). */
 int qd_decoder_info(const qd_decoder *d, int32_t *info);
 /* Pre-size the device workspace for batches of up to max_batch shots (otherwise grown on demand, which
