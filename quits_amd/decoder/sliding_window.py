@@ -130,10 +130,11 @@ class DeviceWindowPlan:
 
         Windows outer, shots inner, in chunks of `self.chunk` shots; everything stays on the caller's stream.  `stats`, if
         given, receives (window index, status tensor) pairs.  (Overlapping the OSD of one sub-batch with the BP of the
-        next on a second stream -- qd_decode_stage exists for that -- was measured again in round 2 (tools/overlap_probe.py,
-        two decoders = two workspaces): 70.6 -> 68.0 ms per 65 536 headline shots, 3.7 %.  Two BP workgroups fill a CU's
-        32 wavefront slots, so an OSD workgroup only gets in by displacing one of them; not worth a second set of
-        workspaces in the driver.)"""
+        next on a second stream -- qd_decode_stage exists for that -- was measured in round 2 (tools/overlap_probe.py,
+        two decoders = two workspaces): 70.6 -> 68.0 ms per 65 536 headline shots, 3.7 %, and again with the round-3 BP kernel:
+        53.3 -> 49.3-50.3 ms, 6-8 % in the steady state of a long job (profiles/r03x_overlap_probe.txt).  Inside one call the
+        last sub-batch's OSD stays exposed and every kernel's tail is paid twice per split, so a 65 536-shot call would gain
+        about half of that; left for the next round together with a second set of workspaces in the driver.)"""
         import torch
         N = det.shape[0]
         pred = torch.zeros((N, self.nobs), dtype=torch.uint8, device=det.device)
