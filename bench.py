@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--shots", type=int, default=65536, help="shots per step per GPU")
+    ap.add_argument("--shots", type=int, default=262144, help="shots per step per GPU (decoded in chunks of 65536: single-window plans run a chunk's OSD beside the next chunk's BP)")
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--p", type=float, default=0.003)
     ap.add_argument("--bp-method", default="minimum_sum", choices=["minimum_sum", "product_sum"])
@@ -221,6 +221,11 @@ def main():
 
     # ---- the same K steps once more with the library's HIP events on (recorded on the launch stream around each kernel):
     # per-kernel device time for the roofline object
+    # (kernels back to back on one stream in this pass: the per-kernel times the roofline is priced on are those of a kernel that
+    # has the GPU to itself, as under rocprofv3 --kernel-trace of a QD_NO_PIPELINE=1 run; the timed region above overlaps them)
+    pipeline_setting = plan.pipeline
+    pipelined = bool(plan.pipeline and args.shots >= 2 * plan.chunk)
+    plan.pipeline = False
     for d in decs:
         d.set_profiling(True)
         d.profile(reset=True)
@@ -230,6 +235,7 @@ def main():
         step(i)
     torch.cuda.synchronize()
     elapsed_ev = time.perf_counter() - t1
+    plan.pipeline = pipeline_setting
     prof = {"bp_ms": 0.0, "osd_ms": 0.0, "bp_launches": 0, "osd_launches": 0}
     for d in decs:
         pr = d.profile(reset=True)
@@ -282,7 +288,7 @@ def main():
     if os.path.exists(pmc_path):
         try:
             pm = json.load(open(pmc_path))
-            key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, args.shots)
+            key = "p%g_it%d_W%d_F%d_shots%d" % (args.p, args.max_iter, W, F, min(args.shots, plan.chunk))      # per BP launch (one chunk)
             kname = (("qd_bp_scatter_wide_kernel" if decs[0].info().get("scatter_wide_kernel") else "qd_bp_scatter_kernel")
                      if decs[0].info().get("scatter_kernel") else "qd_bp_minsum_kernel")
             if key in pm and not general and args.code == "bb144" and pm[key].get("kernel", "qd_bp_minsum_kernel") == kname:
@@ -406,6 +412,9 @@ def main():
         "lfr_per_round": 1.0 - (1.0 - pl) ** (1.0 / R),
         "bp_converged_frac": conv_frac, "osd_frac": osd_frac, "mean_bp_iters": total_iters / max(1, st.numel()),
         "ms_per_step_with_kernel_events": 1e3 * elapsed_ev / args.steps,
+        "pipeline": {"osd_beside_next_chunk_bp": pipelined, "chunk_shots": plan.chunk,
+                     "note": "timed region: chunk i's post-processing on a second stream beside chunk i+1's BP (two workspaces); "
+                             "ms_per_step_with_kernel_events and the roofline's per-kernel times are from a pass with the kernels back to back"},
         # early exit makes the work data-dependent -- shot-windows by BP iterations used (index = iterations)
         "bp_iters_hist": torch.bincount(iters.clamp(max=args.max_iter), minlength=args.max_iter + 1).tolist(),
         "roofline": roofline,

@@ -103,16 +103,22 @@ class DeviceWindowPlan:
                 Uk = csr_matrix(updates[k])
                 Uk = csr_matrix((Uk.data, Uk.indices, Uk.indptr), shape=(Uk.shape[0], graph.n))
                 U = GF2Matrix(Uk)
-            self.windows.append({"dec": dec, "graph": graph, "L": GF2Matrix(Lk), "U": U, "row0": int(row0[k]), "H": checks[k]})
+            self.windows.append({"dec": dec, "graph": graph, "L": GF2Matrix(Lk), "U": U, "row0": int(row0[k]), "H": checks[k], "kw": kw})
         # the per-edge BP kernel (product_sum / serial) keeps its messages in HBM, one workspace per decoder: split a fixed
         # budget among the windows' decoders instead of letting each claim the single-decoder default
         decs = self.decoders()
         self.chunk = _CHUNK_EDGE if any(d.info()["edge_kernel"] for d in decs) else _CHUNK
+        import os
         if len(decs) > 1:
-            import os
             budget = float(os.environ.get("QD_GENERAL_WS_GB", "96")) * (1 << 30)
             for d in decs:
                 d.set_workspace_limit(max(1 << 28, int(budget / len(decs))))
+        # calls of two or more chunks: the post-processing of one chunk beside the BP of another (_decode_pipelined_impl);
+        # QD_NO_PIPELINE=1 or plan.pipeline = False keeps everything on the caller's stream.  Not the default where BP runs in the
+        # per-edge kernel: HBM-bound, it loses more to the co-running post-processor than the overlap returns (W = 5 / F = 3
+        # windows with the reference's settings 219 k -> 209 k shots/s, profiles/r03x_pipelined_driver_multiwindow_ab.txt)
+        self.pipeline = not os.environ.get("QD_NO_PIPELINE") and not any(d.info()["edge_kernel"] for d in decs)
+        self._side = None
 
     def window_matrices(self):
         """Host copies of the window check matrices, in window order (bench.py derives its work model from them)."""
@@ -128,15 +134,16 @@ class DeviceWindowPlan:
     def decode(self, det, stats=None):
         """det: cuda uint8 [N, ndet]  ->  cuda uint8 [N, nobs] logical predictions.
 
-        Windows outer, shots inner, in chunks of `self.chunk` shots; everything stays on the caller's stream.  `stats`, if
-        given, receives (window index, status tensor) pairs.  (Overlapping the OSD of one sub-batch with the BP of the
-        next on a second stream -- qd_decode_stage exists for that -- was measured in round 2 (tools/overlap_probe.py,
-        two decoders = two workspaces): 70.6 -> 68.0 ms per 65 536 headline shots, 3.7 %, and again with the round-3 BP kernel:
-        53.3 -> 49.3-50.3 ms, 6-8 % in the steady state of a long job (profiles/r03x_overlap_probe.txt).  Inside one call the
-        last sub-batch's OSD stays exposed and every kernel's tail is paid twice per split, so a 65 536-shot call would gain
-        about half of that; left for the next round together with a second set of workspaces in the driver.)"""
+        Chunks of `self.chunk` shots, windows inner.  `stats`, if given, receives (window index, status tensor) pairs.
+        A call of two or more chunks runs a chunk's post-processing on a second stream beside the BP of the other chunk of its
+        pair (_decode_pipelined_impl: headline 1.21 -> 1.30 M shots/s, BP-LSD order 1 690 k -> 866 k, p = 6e-3 320 k -> 355 k,
+        W = 3 / F = 1 windows 511 k -> 539 k, identical outputs; profiles/r03x_pipelined_driver_ab.txt,
+        r03x_pipelined_driver_multiwindow_ab.txt); results are delivered in order on the caller's stream.  QD_NO_PIPELINE=1 or
+        `plan.pipeline = False` turns it off; it is off by default for plans whose BP runs in the per-edge kernel."""
         import torch
         N = det.shape[0]
+        if self.pipeline and N >= 2 * self.chunk:
+            return self._decode_pipelined(det, stats)
         pred = torch.zeros((N, self.nobs), dtype=torch.uint8, device=det.device)
         for c0 in range(0, N, self.chunk):
             chunk = det[c0:c0 + self.chunk]
@@ -151,6 +158,83 @@ class DeviceWindowPlan:
                 if stats is not None:
                     stats.append((k, status))
         return pred
+
+    def _decode_pipelined(self, det, stats=None):
+        return _decode_pipelined_impl(self, det, stats)
+
+
+def _decode_pipelined_impl(plan, det, stats):
+    """Calls of two or more chunks: the BP stages run on one side stream, the post-processing (OSD / LSD over the shots BP
+    parked, acc ^= L e, the hand-off U e) on a second one, so that a chunk's post-processing runs beside the BP of the other
+    chunk of its pair -- the post-processors are chains of dependent steps that leave most issue slots of a CU idle, BP fills
+    them (profiles/r03x_overlap_probe.txt, r03x_pipelined_driver_ab.txt).  Chunks are taken two at a time (lanes 0 / 1, each
+    with its own set of decoders = workspaces), windows outer inside a pair:
+
+        BP stream:    BP(A, 0)  BP(B, 0)    BP(A, 1)    BP(B, 1)   ...
+        post stream:            post(A, 0)  post(B, 0)  post(A, 1) ...
+
+    BP(X, k) waits for post(X, k - 1) (its syndrome needs that hand-off; it also frees the lane's buffers and decoder), post(X, k)
+    for BP(X, k); both streams are in order.  Both start after everything queued on the caller's stream so far (inputs, the
+    zeroed accumulator); the caller's stream resumes after the last post stage, which by stream order is after all the others.
+    Every buffer is allocated on the caller's stream before the side streams start and none is released before that point."""
+    import torch
+    from .device import BatchDecoder
+    if plan._side is None:
+        import os
+        second = {}
+        for w in plan.windows:
+            if id(w["dec"]) not in second:
+                second[id(w["dec"])] = BatchDecoder(w["graph"], **w["kw"])
+            w["dec2"] = second[id(w["dec"])]
+        if any(d.info()["edge_kernel"] for d in plan.decoders()):
+            budget = float(os.environ.get("QD_GENERAL_WS_GB", "96")) * (1 << 30)
+            both = plan.decoders() + list(second.values())
+            for d in both:
+                d.set_workspace_limit(max(1 << 28, int(budget / len(both))))
+        plan._side = (torch.cuda.Stream(), torch.cuda.Stream())
+    s_bp, s_post = plan._side
+    N, C, nwin = det.shape[0], plan.chunk, len(plan.windows)
+    dev = det.device
+    cur = torch.cuda.current_stream()
+    pred = torch.zeros((N, plan.nobs), dtype=torch.uint8, device=dev)
+    words = max(w["graph"].words for w in plan.windows)
+    err_l = [torch.empty((C * words,), dtype=torch.int32, device=dev) for _ in range(2)]
+    upd_l = [torch.empty((C, plan.nz), dtype=torch.uint8, device=dev) for _ in range(2)] if nwin > 1 else [None, None]
+    st_all = torch.empty((nwin if stats is not None else 1, (N if stats is not None else 2 * C)), dtype=torch.int32, device=dev)
+    start = torch.cuda.Event()
+    start.record(cur)
+    s_bp.wait_event(start)
+    s_post.wait_event(start)
+    post_done = [None, None]
+    for p0 in range(0, N, 2 * C):
+        lanes = [(lane, c0) for lane, c0 in enumerate((p0, p0 + C)) if c0 < N]
+        for k, w in enumerate(plan.windows):
+            for lane, c0 in lanes:
+                d = w["dec"] if lane == 0 else w["dec2"]
+                chunk, acc = det[c0:c0 + C], pred[c0:c0 + C]
+                B = chunk.shape[0]
+                err = err_l[lane][:B * w["graph"].words].view(B, w["graph"].words)
+                st = st_all[k, c0:c0 + B] if stats is not None else st_all[0, lane * C:lane * C + B]
+                upd = upd_l[lane][:B] if k > 0 else None
+                if post_done[lane] is not None:
+                    s_bp.wait_event(post_done[lane])
+                d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=1, stream=s_bp)
+                bp_done = torch.cuda.Event()
+                bp_done.record(s_bp)
+                s_post.wait_event(bp_done)
+                d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=2, stream=s_post)
+                w["L"].xor_apply(err, acc, accumulate=True, stream=s_post)
+                if w["U"] is not None:
+                    w["U"].xor_apply(err, upd_l[lane][:B], accumulate=False, stream=s_post)
+                e = torch.cuda.Event()
+                e.record(s_post)
+                post_done[lane] = e
+                if stats is not None:
+                    stats.append((k, st))
+    last = [e for e in post_done if e is not None]
+    for e in last:
+        cur.wait_event(e)
+    return pred
 
 
 def _kwargs_for_device(d, cls):

@@ -469,6 +469,47 @@ def _circuit_dem(name, p_from=None, p_to=None):
     return circ, detector_error_model_to_matrix(circ)
 
 
+@pytest.mark.parametrize("W,F,opts", [
+    (8, 1, dict(bp_method="minimum_sum", schedule="parallel", max_iter=20, osd_method="osd_0", osd_order=0)),      # single window
+    (8, 1, dict(bp_method="minimum_sum", schedule="parallel", max_iter=20, osd_method="lsd_cs", osd_order=1)),
+    (3, 1, dict(bp_method="minimum_sum", schedule="parallel", max_iter=20, osd_method="osd_0", osd_order=0)),      # six windows, hand-off
+    (3, 1, dict(bp_method="product_sum", schedule="serial", max_iter=4, osd_method="osd_cs", osd_order=1)),        # the per-edge BP kernel
+])
+def test_pipelined_chunks_equal_single_stream(gpu, W, F, opts):
+    """A call of two or more chunks runs the post-processing (OSD / LSD, acc ^= L e, the hand-off U e) on a second stream
+    beside the BP of the other chunk of a pair, with a second set of decoders (sliding_window.py _decode_pipelined_impl).
+    Predictions and status words must equal the single-stream path's, shot for shot -- three chunks, the last one ragged, twice
+    in a row (workspaces, buffers and streams reused), with work queued on the caller's stream before (the syndromes are
+    sampled there) and after (the comparison)."""
+    import torch
+    from quits_amd.decoder.device import DemSampler
+    from quits_amd.decoder.sliding_window import build_circuit_plan
+    name, R = "bb72_custom_r6_p0.003", 6
+    circ, (H, L, pri) = _circuit_dem(name)
+    hz = helpers.code("bb72")["hz"]
+    plan = build_circuit_plan(circ, hz, W, F, R, dict(opts), dict(opts))
+    assert len(plan.windows) == (1 if W == 8 else 6)
+    assert plan.pipeline == (opts["bp_method"] == "minimum_sum")      # on by default for the LDS kernels only
+    plan.pipeline = True
+    N = 2 * plan.chunk + 12345
+    sampler = DemSampler(H, L, pri)
+    for rep in range(2):
+        det, obs = sampler.sample(N, seed=77 + rep)
+        st_p, st_s = [], []
+        pred_p = plan.decode(det, st_p)
+        plan.pipeline = False
+        pred_s = plan.decode(det, st_s)
+        plan.pipeline = True
+        assert len(st_p) == len(st_s) == 3 * len(plan.windows)
+        assert torch.equal(pred_p, pred_s)
+        by_p = {k: torch.cat([t for kk, t in st_p if kk == k]) for k in range(len(plan.windows))}
+        by_s = {k: torch.cat([t for kk, t in st_s if kk == k]) for k in range(len(plan.windows))}
+        for k in by_p:
+            assert torch.equal(by_p[k], by_s[k]), k
+        frac_post = float(((by_p[0] >> 17) & 1).float().mean())
+        assert 0.005 < frac_post < 0.98, frac_post          # the post-processor is exercised
+
+
 @pytest.mark.parametrize("p,shots", [(0.001, 400), (0.006, 200)])
 def test_config3_p_sweep_points_bit_exact(gpu, p, shots):
     """configs[3]: the [[144,12,12]] single window at the two ends of the p-sweep (p = 1e-3: BP converges on ~98 % of the shots;

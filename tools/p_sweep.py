@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--shots", type=int, default=1000000, help="shots per p-point, whole job")
-    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--batch", type=int, default=262144)
     ap.add_argument("--max-iter", type=int, default=50)
     ap.add_argument("--points", type=float, nargs="*", default=[0.001, 0.002, 0.003, 0.004, 0.005, 0.006])
     ap.add_argument("--seed", type=int, default=1)

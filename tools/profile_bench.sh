@@ -7,6 +7,9 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# per-kernel durations and counters are those of kernels that have the GPU to themselves (as bench.py's roofline pass): no overlap of
+# the post-processing with the next chunk's BP in these runs
+export QD_NO_PIPELINE=1
 ARGS="--steps 3 --warmup 1 --no-cpu $*"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o trace -- python $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE -f csv -d $OUT/pmc_fetch -o fetch -- python $REPO/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
