@@ -191,7 +191,9 @@ def _decode_pipelined_impl(plan, det, stats):
             both = plan.decoders() + list(second.values())
             for d in both:
                 d.set_workspace_limit(max(1 << 28, int(budget / len(both))))
-        plan._side = (torch.cuda.Stream(), torch.cuda.Stream())
+        # (a high-priority post-processing stream, QD_POST_STREAM_PRIORITY=-1, measured no different: profiles/r03x_post_stream_priority_ab.txt)
+        import os as _os
+        plan._side = (torch.cuda.Stream(), torch.cuda.Stream(priority=int(_os.environ.get("QD_POST_STREAM_PRIORITY", "0"))))
     s_bp, s_post = plan._side
     N, C, nwin = det.shape[0], plan.chunk, len(plan.windows)
     dev = det.device
