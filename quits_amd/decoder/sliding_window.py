@@ -109,6 +109,8 @@ class DeviceWindowPlan:
         decs = self.decoders()
         self.chunk = _CHUNK_EDGE if any(d.info()["edge_kernel"] for d in decs) else _CHUNK
         import os
+        if os.environ.get("QD_CHUNK_SHOTS"):                      # A/B switch (profiles/r03x_chunk_size_pipelined_ab.txt)
+            self.chunk = int(os.environ["QD_CHUNK_SHOTS"])
         if len(decs) > 1:
             budget = float(os.environ.get("QD_GENERAL_WS_GB", "96")) * (1 << 30)
             for d in decs:
