@@ -1,20 +1,26 @@
-// bp_scatter_wide.hip -- the scatter form of flooding min-sum BP (bp_scatter.hip) for windows that have more checks than a workgroup
-// has lanes, or rows of more than 64 faults: CPL checks per lane, NSW 32-bit sign words per check.
+// bp_scatter_wide.hip -- the scatter form of flooding min-sum BP (bp_scatter.hip) with CPL checks per lane and NSW 32-bit sign words
+// per check.  The default shape of flooding min-sum on the LLR grid:
+//   * windows bp_scatter.hip could take with one check per lane run here on HALF the lanes with two checks each -- the headline window
+//     (1008 checks) on 512 lanes: the same 32 wavefronts per CU in four workgroups instead of two, i.e. half as many wavefronts per
+//     barrier (BP 50.3 -> 44.2 ms per 65 536 shots); 512-thread windows on 256 lanes, windows of <= 128 checks on 128;
+//   * windows it cannot take -- more checks than a workgroup has lanes, or rows of 65..96 faults (three sign words) -- on 512 lanes x 3
+//     checks (or 704 / 1024 x 2): the windows of BASELINE configs[4] (QLP [[1020,136]], W = 3: 1350 checks of up to 78 faults, 18 900 faults).
 //
 // Replaces ldpc.BpOsdDecoder.decode -> BpDecoder::bp_decode_parallel (MINIMUM_SUM, ms_scaling_factor 1) as the reference calls it at
-// quits/decoder/sliding_window.py:171,182 on the windows of BASELINE configs[4] (QLP [[1020,136]], W = 3: 1326 checks of up to 78
-// faults, 18 900 faults).  Same arithmetic, same certificate and the same outputs as qd_bp_scatter_kernel and qd_bp_minsum_kernel, bit for
-// bit; oracle: oracle/bp_core.inc bp_parallel_edge in double on the same LLR grid.
+// quits/decoder/sliding_window.py:171,182.  Same arithmetic, same certificate and the same outputs as qd_bp_scatter_kernel and
+// qd_bp_minsum_kernel, bit for bit; oracle: oracle/bp_core.inc bp_parallel_edge in double on the same LLR grid.
 //
-// Why.  qd_bp_minsum_kernel keeps 16 bytes of packed state per check plus sign words plus a float posterior per fault in LDS: 112 KB
-// per QLP shot, ONE workgroup of 1024 threads per CU, four wavefronts per SIMD.  In the scatter form the LDS holds one int32 accumulator
-// per fault (76 KB), so TWO shots share a CU; a workgroup of 704 threads (11 wavefronts) gives every lane two checks, whose state
-// (two minima, argmin position, three sign words, twice: what was sent and what the gather pass just found) stays in registers.
-// Check slots are sorted by degree; a wavefront's 64 checks of one round are 64 consecutive slots (sg.wave_map), so the trip count stays
-// wave-uniform, and the rounds are dealt out so that the wavefronts of a workgroup walk equally many edges between two barriers.
+// Why for the QLP windows.  qd_bp_minsum_kernel keeps 16 bytes of packed state per check plus sign words plus a float posterior per
+// fault in LDS: 112 KB per QLP shot, ONE workgroup of 1024 threads per CU, four wavefronts per SIMD.  In the scatter form the LDS holds
+// one int32 accumulator per fault (76 KB), so TWO shots share a CU (BP 36.8 -> 19.0 ms per 8192-shot window launch).
 //
-// One iteration = [gather pass of check 0, then of check 1] barrier [converged? | scatter pass of check 0, then of check 1] barrier,
-// in place as in bp_scatter.hip (every gather of the iteration precedes every add).
+// A lane's checks keep their state in registers (two minima, argmin position, the sign words, twice: what was sent and what the gather
+// pass just found).  Check slots are sorted by degree; a wavefront's 64 checks of one round are 64 consecutive slots (sg.wave_map), so
+// the trip count stays wave-uniform, and the rounds are dealt out so that the wavefronts of a workgroup walk equally many edges between
+// two barriers.
+//
+// One iteration = [gather pass of check 0 .. CPL-1] barrier [converged? | scatter pass of check 0 .. CPL-1] barrier, in place as in
+// bp_scatter.hip (every gather of the iteration precedes every add).
 #include "qd_internal.h"
 #include "../../include/quits_amd.h"
 #include "bp_scatter_edge.h"
