@@ -21,7 +21,10 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
 int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg);
 hipError_t qd_launch_bp_ps_lds(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
-                          int blocks_full, hipStream_t s);
+                          int blocks_full, hipStream_t s, bool handed_over = false);
+int qd_osd_sr_layout(int m, int m_pad, int n, int out_words, int *off13, int *threads, int *rpt);
+hipError_t qd_launch_osd0_sr(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s);
+size_t qd_osd_sr_ws_words(int m_pad, int mw, int threads, int rpt);
 hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks,
                           int lsd_w, int lsd_order, const uint32_t *wfix, hipStream_t s);
 size_t qd_lsd_ws_bytes(int m, int n, int blocks, int lsd_w);
@@ -97,8 +100,10 @@ struct qd_decoder {
     int32_t *fail_list = nullptr, *fail_count = nullptr;
     uint16_t *order_ws = nullptr;
     uint64_t *q_spill = nullptr, *q_spill_fast = nullptr, *mt_ws = nullptr;
+    uint64_t *q_spill_sr = nullptr;
     int32_t *hard_list = nullptr, *hard_list2 = nullptr;
     int osd_blocks_fast = 0;
+    int osd_blocks_sr = 0;      // > 0: OSD-0 runs in qd_osd0_sr_kernel (osd_sr.hip), the mirrored kernel only takes the shots it hands over
     int osd_w = 0;
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
     int lds_edge = 0;           // ... its LDS-resident form (flooding product-sum on a window whose messages fit LDS): no HBM message workspace
@@ -684,6 +689,23 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             }
         }
     }
+    // OSD-0 with simultaneous singleton pivots (osd_sr.hip): columns in ELL form (one load per entry, no pointer chase), its own
+    // LDS layout; taken whenever the mirrored register kernel exists too (it decodes the shots the new kernel hands over)
+    od.s_lds_bytes = 0; od.s_per_cu = 0; od.csc_ell = nullptr; od.ell_log2 = 0;
+    if (od.f_lds_bytes > 0 && m < 65535) {
+        int dl = 1;
+        while ((1 << dl) < max_cdeg) ++dl;
+        std::vector<uint16_t> ell((size_t)n << dl, (uint16_t)0xFFFFu);
+        for (int j = 0; j < n; ++j)
+            for (int e = cp[j]; e < cp[j + 1]; ++e) ell[((size_t)j << dl) + (e - cp[j])] = (uint16_t)ri[e];
+        if (g->mem.upload(ell, &od.csc_ell)) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation/upload failed"); }
+        od.ell_log2 = dl;
+        const int lds = qd_osd_sr_layout(m, m_pad, n, bp.out_words, od.s_off, &od.s_threads, &od.s_rpt);
+        if (lds > 0 && lds <= QD_LDS_BYTES) {
+            od.s_lds_bytes = lds;
+            od.s_per_cu = std::max(1, std::min(QD_LDS_BYTES / lds, QD_SR_WPS * 256 / od.s_threads));   // QD_SR_WPS wavefronts per SIMD: the kernel's register budget
+        }
+    }
     // the full kernel sorts all n columns in LDS; windows too large for that rely on the register kernel alone
     if (od.lds_bytes == 0 && od.f_lds_bytes == 0) od.threads = 0;
     if (bp.lds_bytes > QD_LDS_BYTES) {
@@ -850,6 +872,8 @@ static void free_ws(qd_decoder *d)
     if (d->q_spill) (void)hipFree(d->q_spill);
     if (d->q_spill_fast) (void)hipFree(d->q_spill_fast);
     d->q_spill_fast = nullptr;
+    if (d->q_spill_sr) (void)hipFree(d->q_spill_sr);
+    d->q_spill_sr = nullptr;
     if (d->mt_ws) (void)hipFree(d->mt_ws);
     d->mt_ws = nullptr;
     if (d->gws.b2c) (void)hipFree(d->gws.b2c);
@@ -920,6 +944,17 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
             d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
             d->lsd_ws = nullptr;
             HIP_TRY(hipMalloc((void **)&d->lsd_ws, qd_lsd_ws_bytes(g->m, g->n, d->lsd_blocks, d->lsd_w)));   // Q planes + work counter (+ debug timers) + pivot columns (+ sweep scratch)
+        }
+        d->osd_blocks_sr = 0;
+        {
+            const char *ev = std::getenv("QD_NO_OSD_SR");
+            if (!d->osd_w && !d->lsd && g->osd.s_lds_bytes > 0 && !(ev && std::atoi(ev) == 1)) {
+                int per = g->osd.s_per_cu;
+                if (const char *e2 = std::getenv("QD_OSD_SR_PER_CU")) { const int v = std::atoi(e2); if (v > 0) per = std::min(v, QD_LDS_BYTES / g->osd.s_lds_bytes); }
+                d->osd_blocks_sr = ncu * per;
+                HIP_TRY(hipMalloc((void **)&d->q_spill_sr, sizeof(uint64_t) * (size_t)d->osd_blocks_sr *
+                                                           qd_osd_sr_ws_words(g->osd.m_pad, g->osd.mw, g->osd.s_threads, g->osd.s_rpt)));
+            }
         }
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
         if (g->osd.f_lds_bytes > 0 && spill_fast > 0)
@@ -1026,7 +1061,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
     a.max_iter = d->prm.max_iter; a.ms_scale = (float)d->prm.ms_scaling_factor; a.want_llr = osd ? 1 : 0;
     a.err_bits = d_err_bits; a.status = d_status;
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
-    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.mt_ws = d->mt_ws;
+    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.q_spill_sr = d->q_spill_sr; a.mt_ws = d->mt_ws;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;   // bytes 16..143 of the counter block
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
@@ -1081,6 +1116,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         } else
             HIP_TRY(qd_launch_bp(d->g->bp, a, B, s));
         if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
+        if (std::getenv("QD_DEBUG_SYNC")) { std::fprintf(stderr, "[qd] BP stage queued (B = %lld)\n", (long long)B); HIP_TRY(hipStreamSynchronize(s)); std::fprintf(stderr, "[qd] BP stage done\n"); }
     }
     if ((stage & 2) && osd) {
         hipEvent_t t0 = nullptr;
@@ -1088,10 +1124,17 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         if (d->lsd)
             HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), d->lsd_w,
                                    d->prm.osd_order, d->g->osd.wfix, s));
-        else
+        else if (d->osd_blocks_sr > 0) {
+            // OSD-0: many pivots per round (osd_sr.hip); shots whose syndrome is outside the column space come back on the hard list
+            // and are decoded by the one-pivot-per-round kernel, whose lowest-row rule defines their answer
+            HIP_TRY(qd_launch_osd0_sr(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_sr), s));
+            HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
+                                   (int)std::min<int64_t>(B, d->osd_blocks), s, true));
+        } else
             HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                    (int)std::min<int64_t>(B, d->osd_blocks), s));
         if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
+        if (std::getenv("QD_DEBUG_SYNC")) { std::fprintf(stderr, "[qd] post-processing stage queued (B = %lld)\n", (long long)B); HIP_TRY(hipStreamSynchronize(s)); std::fprintf(stderr, "[qd] post-processing stage done\n"); }
     }
     return QD_OK;
 }
@@ -1133,7 +1176,7 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     a.max_iter = d->prm.max_iter; a.ms_scale = (float)d->prm.ms_scaling_factor; a.want_llr = 1;
     a.err_bits = d_err_bits; a.status = d_status;
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
-    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.mt_ws = d->mt_ws;
+    a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.q_spill_sr = d->q_spill_sr; a.mt_ws = d->mt_ws;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
     a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
@@ -1143,7 +1186,11 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     if (lsd_only)
         HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), d->lsd_w,
                                    d->prm.osd_order, d->g->osd.wfix, s));
-    else
+    else if (d->osd_blocks_sr > 0) {
+        HIP_TRY(qd_launch_osd0_sr(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_sr), s));
+        HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
+                               (int)std::min<int64_t>(B, d->osd_blocks), s, true));
+    } else
         HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),
                                (int)std::min<int64_t>(B, d->osd_blocks), s));
     return QD_OK;

@@ -7,6 +7,17 @@
 #define QD_MAX_COL_DEG 16      // bit-side sign copy is a uint16 per fault
 #define QD_MAX_ROW_DEG 255     // edge position inside a check is a byte
 #define QD_LDS_BYTES (160 * 1024)
+#ifndef QD_SR_KWR_OF
+#define QD_SR_KWR_OF(rpt) ((rpt) <= 2 ? 4 : 2)
+#endif
+#ifndef QD_SR_WPS
+#define QD_SR_WPS 6            // wavefronts per SIMD its register budget is cut for
+#endif
+#ifndef QD_SR_TSMALL
+#define QD_SR_TSMALL 512       // its workgroup size for windows of <= 1024 detectors
+#endif
+//      QD_SR_KWR_OF(rpt)       // Q planes (64 pivots each) the many-pivots-per-round OSD-0 kernel keeps in registers at rpt rows per thread (osd_sr.hip)
+#define QD_SR_KWR_MAX 4
 
 // One window's Tanner graph as the BP kernel wants it.
 //   check slots: checks sorted by degree (descending); bit slots: faults sorted by degree (descending), so that a
@@ -124,6 +135,11 @@ struct OsdGraphDev {
     int c_off[10], c_off_sort, c_off_order, c_off_pivmask, c_off_npl, c_lds_bytes, c_cpt, c_per_cu;
     const uint32_t *wfix;       // [n] integer candidate costs round(log(1/p) * 2^18) for OSD-CS / OSD-E
     int threads;
+    // OSD-0 with simultaneous singleton pivots (osd_sr.hip, qd_osd0_sr_kernel): its LDS layout (s_lds_bytes = 0: not taken),
+    // instantiation and the columns in ELL form
+    int s_off[13], s_lds_bytes, s_threads, s_rpt, s_per_cu;
+    const uint16_t *csc_ell;    // [n][1 << ell_log2] detector indices of a fault, ascending, 0xFFFF beyond its weight
+    int ell_log2;
 };
 
 struct DecodeArgs {
@@ -144,6 +160,7 @@ struct DecodeArgs {
     uint16_t *order_ws;         // [blocks][n]   sorted column order (full OSD kernel)
     uint64_t *q_spill;          // [blocks][(mw - kw_lds)][m_pad]
     uint64_t *q_spill_fast;     // [blocks_fast][(mw - f_kw)][m_pad]   register kernel
+    uint64_t *q_spill_sr;       // [blocks_sr][...] spilled Q planes and parked state of qd_osd0_sr_kernel (osd_sr.hip, qd_osd_sr_ws_words)
     uint64_t *mt_ws;            // [blocks_fast][mw * m_pad + 2048]    higher-order OSD: transposed Q + candidate vectors
     int32_t *hard_list;         // [cap]         fail-list slots the first fast OSD pass could not finish
     int32_t *hard_list2;        // [cap]         ... and the second
