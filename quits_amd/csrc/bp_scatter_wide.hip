@@ -211,6 +211,20 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
         __builtin_amdgcn_s_setprio(QS_PRIO);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
+#ifdef QSW_STATS
+            {
+                bool same = A1[j] == S1[j] && A2[j] == S2[j] && (KST[j] == KOLD[j] || A1[j] == A2[j]);
+#pragma unroll
+                for (int w = 0; w < NSW; ++w) same = same && Q[j][w] == O[j][w];
+                const unsigned long long ba = __ballot(act[j]), bs = __ballot(act[j] && same);
+                if ((tid & 63) == 0 && ba) {
+                    const int bk = min(t / 10, 4);
+                    atomicAdd(&a.dbg[0], 1ull); atomicAdd(&a.dbg[2 + bk], 1ull);
+                    if (bs == ba) { atomicAdd(&a.dbg[1], 1ull); atomicAdd(&a.dbg[7 + bk], 1ull); }
+                    atomicAdd(&a.dbg[12], (unsigned long long)__popcll(bs)); atomicAdd(&a.dbg[13], (unsigned long long)__popcll(ba));
+                }
+            }
+#endif
             if (act[j]) {
                 const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
                 const int adj_voff = cs[j] * 16;

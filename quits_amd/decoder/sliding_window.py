@@ -26,6 +26,14 @@ _CHUNK_EDGE = 5 << 14   # ... when BP runs in the one-message-per-edge kernel: f
                         # time is per-workgroup latency (81 920 vs 65 536 shots per launch: +8 % shots/s, 98 304 -18 %; profiles/r03o)
 
 
+def _env_int(name, default):
+    import os
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
 def _progress(it, on):
     if on:
         try:
@@ -119,8 +127,10 @@ class DeviceWindowPlan:
         # QD_NO_PIPELINE=1 or plan.pipeline = False keeps everything on the caller's stream.  Not the default where BP runs in the
         # per-edge kernel: HBM-bound, it loses more to the co-running post-processor than the overlap returns (W = 5 / F = 3
         # windows with the reference's settings 219 k -> 209 k shots/s, profiles/r03x_pipelined_driver_multiwindow_ab.txt)
-        self.pipeline = not os.environ.get("QD_NO_PIPELINE") and not any(d.info()["edge_kernel"] for d in decs)
+        self.pipeline = _env_int("QD_NO_PIPELINE", 0) == 0 and not any(d.info()["edge_kernel"] for d in decs)
         self._side = None
+        self._stage = None
+        self.host_piece = int(os.environ.get("QD_HOST_PIECE_SHOTS", str(4 * self.chunk)))   # shots per staged piece (>= 2 chunks: the pipelined driver)
 
     def window_matrices(self):
         """Host copies of the window check matrices, in window order (bench.py derives its work model from them)."""
@@ -164,6 +174,61 @@ class DeviceWindowPlan:
     def _decode_pipelined(self, det, stats=None):
         return _decode_pipelined_impl(self, det, stats)
 
+    def decode_host(self, zcheck_samples):
+        """The reference call's data path: host samples [N, ndet] (bool / uint8 / any integer numpy array, or a torch tensor)
+        -> int64 numpy [N, nobs] (reference sliding_window.py:160,186).  Host arrays are streamed: pieces of `self.host_piece`
+        shots go through two pinned staging buffers and a copy stream, so that the host-side copy and the PCIe transfer of one
+        piece run beside the decoding of the previous one, and the predictions come back through a pinned buffer.  Tensors that
+        already live on the GPU skip the staging."""
+        import torch
+        if isinstance(zcheck_samples, torch.Tensor) and zcheck_samples.is_cuda:
+            return self.decode(_to_device_samples(zcheck_samples)).cpu().numpy().astype(np.int64)
+        a = zcheck_samples.cpu().numpy() if isinstance(zcheck_samples, torch.Tensor) else np.asarray(zcheck_samples)
+        if a.ndim != 2:
+            raise ValueError("zcheck_samples must be a [shots, detectors] array")
+        N, ndet = a.shape
+        if N == 0:
+            return np.zeros((0, self.nobs), dtype=np.int64)
+        as_u8 = (lambda x: x.view(np.uint8)) if a.dtype == np.bool_ else ((lambda x: x) if a.dtype == np.uint8 else (lambda x: (x % 2).astype(np.uint8)))
+        piece = max(self.chunk, int(self.host_piece) // self.chunk * self.chunk)
+        if N <= self.chunk:
+            piece = N
+        st = self._stage
+        if st is None or st["ndet"] != ndet or st["piece"] < min(piece, N):
+            rows = min(piece, N)
+            st = {"ndet": ndet, "piece": rows,
+                  "pin": [torch.empty((rows, ndet), dtype=torch.uint8, pin_memory=True) for _ in range(2)],
+                  "dev": [torch.empty((rows, ndet), dtype=torch.uint8, device="cuda") for _ in range(2)],
+                  "copy": torch.cuda.Stream(), "out": None}
+            self._stage = st
+        if st["out"] is None or st["out"].shape[0] < N:
+            st["out"] = torch.empty((N, self.nobs), dtype=torch.uint8, pin_memory=True)
+        out = st["out"]
+        cur = torch.cuda.current_stream()
+        h2d_done, dec_done = [None, None], [None, None]
+        try:
+            for i, lo in enumerate(range(0, N, st["piece"])):
+                hi = min(N, lo + st["piece"])
+                b = i & 1
+                if h2d_done[b] is not None:
+                    h2d_done[b].synchronize()                      # the staging buffer has left for the GPU
+                np.copyto(st["pin"][b][:hi - lo].numpy(), as_u8(a[lo:hi]))
+                if dec_done[b] is not None:
+                    st["copy"].wait_event(dec_done[b])             # the device buffer has been decoded
+                with torch.cuda.stream(st["copy"]):
+                    st["dev"][b][:hi - lo].copy_(st["pin"][b][:hi - lo], non_blocking=True)
+                    h2d_done[b] = torch.cuda.Event()
+                    h2d_done[b].record(st["copy"])
+                cur.wait_event(h2d_done[b])
+                pred = self.decode(st["dev"][b][:hi - lo])
+                out[lo:hi].copy_(pred, non_blocking=True)
+                dec_done[b] = torch.cuda.Event()
+                dec_done[b].record(cur)
+        finally:
+            cur.synchronize()
+            st["copy"].synchronize()
+        return out[:N].numpy().astype(np.int64)
+
 
 def _decode_pipelined_impl(plan, det, stats):
     """Calls of two or more chunks: the BP stages run on one side stream, the post-processing (OSD / LSD over the shots BP
@@ -194,9 +259,11 @@ def _decode_pipelined_impl(plan, det, stats):
             for d in both:
                 d.set_workspace_limit(max(1 << 28, int(budget / len(both))))
         # (a high-priority post-processing stream, QD_POST_STREAM_PRIORITY=-1, measured no different: profiles/r03x_post_stream_priority_ab.txt)
-        import os as _os
-        plan._side = (torch.cuda.Stream(), torch.cuda.Stream(priority=int(_os.environ.get("QD_POST_STREAM_PRIORITY", "0"))))
-    s_bp, s_post = plan._side
+        plan._side = {}
+    if det.device not in plan._side:              # (streams live on the device of the data, one pair per device)
+        plan._side[det.device] = (torch.cuda.Stream(device=det.device),
+                                  torch.cuda.Stream(device=det.device, priority=_env_int("QD_POST_STREAM_PRIORITY", 0)))
+    s_bp, s_post = plan._side[det.device]
     N, C, nwin = det.shape[0], plan.chunk, len(plan.windows)
     dev = det.device
     cur = torch.cuda.current_stream()
@@ -210,50 +277,67 @@ def _decode_pipelined_impl(plan, det, stats):
     s_bp.wait_event(start)
     s_post.wait_event(start)
     post_done = [None, None]
-    for p0 in range(0, N, 2 * C):
-        lanes = [(lane, c0) for lane, c0 in enumerate((p0, p0 + C)) if c0 < N]
-        for k, w in enumerate(plan.windows):
-            for lane, c0 in lanes:
-                d = w["dec"] if lane == 0 else w["dec2"]
-                chunk, acc = det[c0:c0 + C], pred[c0:c0 + C]
-                B = chunk.shape[0]
-                err = err_l[lane][:B * w["graph"].words].view(B, w["graph"].words)
-                st = st_all[k, c0:c0 + B] if stats is not None else st_all[0, lane * C:lane * C + B]
-                upd = upd_l[lane][:B] if k > 0 else None
-                if post_done[lane] is not None:
-                    s_bp.wait_event(post_done[lane])
-                d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=1, stream=s_bp)
-                bp_done = torch.cuda.Event()
-                bp_done.record(s_bp)
-                s_post.wait_event(bp_done)
-                d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=2, stream=s_post)
-                w["L"].xor_apply(err, acc, accumulate=True, stream=s_post)
-                if w["U"] is not None:
-                    w["U"].xor_apply(err, upd_l[lane][:B], accumulate=False, stream=s_post)
-                e = torch.cuda.Event()
-                e.record(s_post)
-                post_done[lane] = e
-                if stats is not None:
-                    stats.append((k, st))
-    last = [e for e in post_done if e is not None]
-    for e in last:
-        cur.wait_event(e)
+    try:
+        for p0 in range(0, N, 2 * C):
+            lanes = [(lane, c0) for lane, c0 in enumerate((p0, p0 + C)) if c0 < N]
+            for k, w in enumerate(plan.windows):
+                for lane, c0 in lanes:
+                    d = w["dec"] if lane == 0 else w["dec2"]
+                    chunk, acc = det[c0:c0 + C], pred[c0:c0 + C]
+                    B = chunk.shape[0]
+                    err = err_l[lane][:B * w["graph"].words].view(B, w["graph"].words)
+                    st = st_all[k, c0:c0 + B] if stats is not None else st_all[0, lane * C:lane * C + B]
+                    upd = upd_l[lane][:B] if k > 0 else None
+                    if post_done[lane] is not None:
+                        s_bp.wait_event(post_done[lane])
+                    d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=1, stream=s_bp)
+                    bp_done = torch.cuda.Event()
+                    bp_done.record(s_bp)
+                    s_post.wait_event(bp_done)
+                    d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=2, stream=s_post)
+                    w["L"].xor_apply(err, acc, accumulate=True, stream=s_post)
+                    if w["U"] is not None:
+                        w["U"].xor_apply(err, upd_l[lane][:B], accumulate=False, stream=s_post)
+                    e = torch.cuda.Event()
+                    e.record(s_post)
+                    post_done[lane] = e
+                    if stats is not None:
+                        stats.append((k, st))
+    except BaseException:
+        # the buffers above were allocated on the caller's stream and are in use on the side streams: nothing may be handed back
+        # to the allocator while queued kernels still write to them
+        s_bp.synchronize()
+        s_post.synchronize()
+        raise
+    for e in post_done:
+        if e is not None:
+            cur.wait_event(e)
     return pred
 
 
 def _kwargs_for_device(d, cls):
     """Keyword arguments of plug-in class `cls` -> BatchDecoder options.  The post-processor follows the CLASS, as it does in
-    ldpc: a BpLsdDecoder runs LSD whether or not the dict names `lsd_method` / `lsd_order` (ldpc's defaults 'lsd_0', 0), and
-    each class refuses the other's keywords with TypeError, as the real classes do -- never a silent change of algorithm."""
+    ldpc: a BpLsdDecoder runs LSD whether or not the dict names `lsd_method` / `lsd_order` (ldpc's defaults 'lsd_0', 0).
+    Keywords that do not change the algorithm here are dropped (`omp_thread_count`; `input_vector_type` 'syndrome' / 'auto';
+    `random_schedule_seed` 0 / None and `serial_schedule_order` None = the natural serial order, which is what this build
+    runs); legal ldpc keywords the device path does not implement raise NotImplementedError; the other class's post-processor
+    options and unknown names raise TypeError naming the device path (ldpc's own classes take **kwargs and may ignore them:
+    refusing is the safe side of "never a silent change of algorithm")."""
     from .bplsd import BpLsdDecoder, lsd_to_device_method
     common = ("bp_method", "schedule", "max_iter", "ms_scaling_factor")
     rates = ("error_rate", "channel_probs", "error_channel")
     d = dict(d)
     is_lsd = isinstance(cls, type) and issubclass(cls, BpLsdDecoder)
     own = ("lsd_method", "lsd_order", "bits_per_step") if is_lsd else ("osd_method", "osd_order")
+    d.pop("omp_thread_count", None)
+    if str(d.pop("input_vector_type", "syndrome")).lower() not in ("syndrome", "auto"):
+        raise NotImplementedError("the device path decodes syndromes only (input_vector_type='syndrome')")
+    if d.pop("random_schedule_seed", 0) not in (0, None) or d.pop("serial_schedule_order", None) is not None:
+        raise NotImplementedError("the device path runs the serial schedule in natural fault order only (ldpc's default: "
+                                  "random_schedule_seed=0, serial_schedule_order=None)")
     extra = [k for k in d if k not in common + rates + own]
     if extra:
-        raise TypeError("%s() got unexpected keyword argument(s): %s" % (cls.__name__, ", ".join(sorted(extra))))
+        raise TypeError("%s on the device path does not take the keyword argument(s): %s" % (cls.__name__, ", ".join(sorted(extra))))
     out = {k: d[k] for k in d if k in common}
     if is_lsd:
         out["osd_method"], out["osd_order"] = lsd_to_device_method(d.get("lsd_method", "lsd_0"), d.get("lsd_order", 0),
@@ -261,6 +345,102 @@ def _kwargs_for_device(d, cls):
     else:
         out.update({k: d[k] for k in d if k in own})
     return out
+
+
+# ---- plan cache ---------------------------------------------------------------------------------------------------------------
+# The reference entry points are called once per experiment point with host arrays (bposd.py:54-86; doc/06B_end_to_end_demo_bb.ipynb
+# cell 5 loops over p), and every call used to rebuild everything: DEM extraction + spacetime() + one qd_graph_create per window
+# (0.4 s for the headline window, 15 s for the QLP [[1020,136]] circuit).  Plans are kept, least recently used first out, keyed on
+# everything they depend on: the circuit (hash of its text), hz, W, F, the number of rounds, both plug-in classes and both option
+# dicts.  QD_PLAN_CACHE = number of plans kept (default 8, 0 = off).
+_PLAN_CACHE = None
+_PLAN_STATS = {"hits": 0, "misses": 0}
+
+
+def _freeze(v):
+    """Hashable fingerprint of an option value: arrays by content, floats by repr."""
+    import hashlib
+    if isinstance(v, dict):
+        return tuple(sorted((str(k), _freeze(x)) for k, x in v.items()))
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(x) for x in v)
+    if isinstance(v, np.ndarray) or hasattr(v, "__array__"):
+        a = np.ascontiguousarray(np.asarray(v))
+        return ("ndarray", a.dtype.str, a.shape, hashlib.sha1(a.tobytes()).hexdigest())
+    if isinstance(v, float):
+        return ("float", repr(float(v)))
+    return (type(v).__name__, repr(v))
+
+
+def _circuit_fingerprint(circuit):
+    """sha1 of the circuit text (stim.Circuit, quits_amd.dem.Circuit and plain text all print as Stim text); an object that is
+    already a detector error model goes by its printed form as well."""
+    import hashlib
+    return hashlib.sha1(str(circuit).encode()).hexdigest()
+
+
+def _matrix_fingerprint(mat):
+    import hashlib
+    if hasattr(mat, "tocsr"):
+        c = mat.tocsr()
+        c.sort_indices()
+        h = hashlib.sha1(np.asarray(c.indptr, np.int64).tobytes())
+        h.update(np.asarray(c.indices, np.int64).tobytes())
+        h.update((np.asarray(c.data) % 2).astype(np.uint8).tobytes())
+        return ("sparse", c.shape, h.hexdigest())
+    a = np.ascontiguousarray(np.asarray(mat) % 2).astype(np.uint8)
+    return ("dense", a.shape, hashlib.sha1(a.tobytes()).hexdigest())
+
+
+def plan_key(kind, circuit, hz, lz, W, F, num_rounds, decoder1, decoder2, dict1, dict2):
+    """Everything a DeviceWindowPlan depends on.  kind: 'circuit' (circuit is the circuit) or 'phenom' (circuit is None; lz enters
+    because the phenomenological commit matrices are built from it)."""
+    return (kind, None if circuit is None else _circuit_fingerprint(circuit), _matrix_fingerprint(hz),
+            None if lz is None else _matrix_fingerprint(lz), int(W), int(F), int(num_rounds),
+            getattr(decoder1, "__qualname__", repr(decoder1)), getattr(decoder2, "__qualname__", repr(decoder2)),
+            _freeze(dict1), _freeze(dict2))
+
+
+def _plan_cache_size():
+    import os
+    try:
+        return max(0, int(os.environ.get("QD_PLAN_CACHE", "8")))
+    except ValueError:
+        return 8
+
+
+def cached_plan(key, build):
+    """The plan stored under `key`, built with build() on a miss."""
+    global _PLAN_CACHE
+    from collections import OrderedDict
+    cap = _plan_cache_size()
+    if cap == 0:
+        _PLAN_STATS["misses"] += 1
+        return build()
+    if _PLAN_CACHE is None:
+        _PLAN_CACHE = OrderedDict()
+    plan = _PLAN_CACHE.get(key)
+    if plan is not None:
+        _PLAN_CACHE.move_to_end(key)
+        _PLAN_STATS["hits"] += 1
+        return plan
+    _PLAN_STATS["misses"] += 1
+    plan = build()
+    _PLAN_CACHE[key] = plan
+    while len(_PLAN_CACHE) > cap:
+        _PLAN_CACHE.popitem(last=False)
+    return plan
+
+
+def plan_cache_info():
+    return {"size": 0 if _PLAN_CACHE is None else len(_PLAN_CACHE), "capacity": _plan_cache_size(), **_PLAN_STATS}
+
+
+def plan_cache_clear():
+    global _PLAN_CACHE
+    _PLAN_CACHE = None
+    _PLAN_STATS["hits"] = 0
+    _PLAN_STATS["misses"] = 0
 
 
 def build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2, decoder1=None, decoder2=None):
@@ -319,9 +499,9 @@ def sliding_window_phenom_mem(zcheck_samples, hz, lz, W, F, decoder1, decoder2, 
         warnings.warn("Window size larger than the syndrome extraction rounds: Doing whole history correction")
 
     if _is_device_decoder(decoder1) and _is_device_decoder(decoder2) and function_name1 == function_name2 == "decode":
-        plan = build_phenom_plan(hz, lz, W, F, num_rounds, dict1, dict2, decoder1, decoder2)
-        pred = plan.decode(_to_device_samples(zcheck_samples))
-        return pred.cpu().numpy().astype(np.int64)
+        plan = cached_plan(plan_key("phenom", None, hz, lz, W, F, num_rounds, decoder1, decoder2, dict1, dict2),
+                           lambda: build_phenom_plan(hz, lz, W, F, num_rounds, dict1, dict2, decoder1, decoder2))
+        return plan.decode_host(zcheck_samples)
 
     h_mid, h_last = phenom_window_matrices(hz, W, F, W_last)
     dec_mid = decoder1(h_mid, **dict1)
@@ -365,9 +545,9 @@ def sliding_window_circuit_mem(zcheck_samples, circuit, hz, lz, W, F, decoder1, 
         warnings.warn("Window size larger than the syndrome extraction rounds: Doing whole history correction")
 
     if _is_device_decoder(decoder1) and _is_device_decoder(decoder2) and function_name1 == function_name2 == "decode":
-        plan = build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2, decoder1, decoder2)
-        pred = plan.decode(_to_device_samples(zcheck_samples))
-        return pred.cpu().numpy().astype(np.int64)
+        plan = cached_plan(plan_key("circuit", circuit, hz, None, W, F, num_rounds, decoder1, decoder2, dict1, dict2),
+                           lambda: build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2, decoder1, decoder2))
+        return plan.decode_host(zcheck_samples)
 
     checks, commits, priors, updates = spacetime(circuit, hz, W, F, num_cor_rounds)
     decoders = []
@@ -396,4 +576,4 @@ def sliding_window_circuit_mem(zcheck_samples, circuit, hz, lz, W, F, decoder1, 
     return out
 
 
-__all__ = ["sliding_window_phenom_mem", "sliding_window_circuit_mem"]
+__all__ = ["sliding_window_phenom_mem", "sliding_window_circuit_mem", "plan_cache_info", "plan_cache_clear"]

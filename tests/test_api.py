@@ -117,6 +117,45 @@ def test_device_options_follow_the_decoder_class():
     class MyLsd(BpLsdDecoder):
         pass
     assert _kwargs_for_device(base, MyLsd)["osd_method"] == "lsd_0"
+    # legal ldpc keywords that change nothing here are dropped, the ones the device path lacks say so
+    kw = _kwargs_for_device(dict(base, omp_thread_count=4, input_vector_type="syndrome", random_schedule_seed=None,
+                                 serial_schedule_order=None), BpOsdDecoder)
+    assert set(kw) == {"bp_method", "max_iter", "schedule"}
+    with pytest.raises(NotImplementedError, match="natural fault order"):
+        _kwargs_for_device(dict(base, random_schedule_seed=7), BpOsdDecoder)
+    with pytest.raises(NotImplementedError, match="syndromes only"):
+        _kwargs_for_device(dict(base, input_vector_type="received_vector"), BpLsdDecoder)
+
+
+def test_plan_cache_key_and_lru(monkeypatch):
+    """plans are cached on everything they depend on -- circuit text, hz, W, F, rounds, plug-in classes, option
+    dicts (arrays by content) -- and evicted least recently used first."""
+    from quits_amd.decoder import BpLsdDecoder, BpOsdDecoder
+    from quits_amd.decoder import sliding_window as sw
+    hz = np.eye(3, dtype=int)
+    d = {"bp_method": "minimum_sum", "max_iter": 5, "channel_probs": np.array([0.1, 0.2])}
+    k0 = sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, d)
+    assert k0 == sw.plan_key("circuit", "H 0\nM 0\n", hz.copy(), None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, dict(d), {**d, "channel_probs": np.array([0.1, 0.2])})
+    hash(k0)
+    others = [sw.plan_key("circuit", "H 0\nM 1\n", hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, d),
+              sw.plan_key("circuit", "H 0\nM 0\n", 1 - hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, d),
+              sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 5, 3, 6, BpOsdDecoder, BpOsdDecoder, d, d),
+              sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 7, BpOsdDecoder, BpOsdDecoder, d, d),
+              sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 6, BpOsdDecoder, BpLsdDecoder, d, d),
+              sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, {**d, "max_iter": 6}),
+              sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, {**d, "channel_probs": np.array([0.1, 0.3])}),
+              sw.plan_key("phenom", None, hz, hz, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, d)]
+    assert len(set(others + [k0])) == len(others) + 1
+    sw.plan_cache_clear()
+    monkeypatch.setenv("QD_PLAN_CACHE", "2")
+    built = []
+    for key in ("a", "b", "a", "c", "b"):
+        sw.cached_plan(key, lambda key=key: built.append(key) or key.upper())
+    assert built == ["a", "b", "c", "b"]                 # 'a' hit once; 'b' was evicted when 'c' came in
+    assert sw.plan_cache_info() == {"size": 2, "capacity": 2, "hits": 1, "misses": 4}
+    monkeypatch.setenv("QD_PLAN_CACHE", "0")
+    assert sw.cached_plan("a", lambda: "fresh") == "fresh"
+    sw.plan_cache_clear()
 
 
 def test_dict_helpers():

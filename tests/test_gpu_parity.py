@@ -510,10 +510,57 @@ def test_pipelined_chunks_equal_single_stream(gpu, W, F, opts):
         assert 0.005 < frac_post < 0.98, frac_post          # the post-processor is exercised
 
 
-@pytest.mark.parametrize("p,shots", [(0.001, 400), (0.006, 200)])
+def test_public_call_plan_cache_and_streamed_host_samples(gpu, monkeypatch):
+    """the drop-in call sliding_window_bposd_circuit_mem(host ndarray, circuit, ...) keeps its plan (DEM, windows,
+    graphs, workspaces) between calls -- the reference is called once per experiment point -- and streams the host samples through
+    pinned pieces.  A cached plan returns what a fresh one returns; another circuit or another option misses the cache; pieces
+    smaller than the batch (three of them, the last ragged) and bool / uint8 / int64 / torch inputs all give the same int64 array,
+    equal to the device-resident plan's."""
+    import torch
+    from quits_amd.decoder import sliding_window_bposd_circuit_mem
+    from quits_amd.decoder import sliding_window as sw
+    from quits_amd.decoder.device import DemSampler
+    from quits_amd.dem import Circuit
+    name, R = "bb72_custom_r6_p0.003", 6
+    circ, (H, L, pri) = _circuit_dem(name)
+    cd = helpers.code("bb72")
+    hz, lz = cd["hz"], cd["lz"]
+    kw = dict(max_iter=20, osd_order=0, bp_method="minimum_sum", schedule="parallel", osd_method="osd_0")
+    det, obs = DemSampler(H, L, pri).sample(3000, seed=5)
+    det_h = det.cpu().numpy()
+    sw.plan_cache_clear()
+    monkeypatch.setenv("QD_PLAN_CACHE", "4")
+    ref = sw.build_circuit_plan(circ, hz, 3, 1, R, dict(kw), dict(kw)).decode(det).cpu().numpy().astype(np.int64)
+    a = sliding_window_bposd_circuit_mem(det_h.astype(np.bool_), circ, hz, lz, 3, 1, **kw)
+    assert a.dtype == np.int64 and np.array_equal(a, ref)
+    assert sw.plan_cache_info()["misses"] == 1 and sw.plan_cache_info()["hits"] == 0
+    # same arguments (the circuit as fresh text, hz as a copy): the cached plan, same answer; every input type
+    for samples in (det_h, det_h.astype(np.int64), det_h.astype(np.bool_), torch.from_numpy(det_h), det):
+        b = sliding_window_bposd_circuit_mem(samples, Circuit(str(circ)), hz.copy(), lz, 3, 1, **kw)
+        assert b.dtype == np.int64 and np.array_equal(b, ref)
+    info = sw.plan_cache_info()
+    assert info["misses"] == 1 and info["hits"] == 5 and info["size"] == 1
+    # pieces of 1024 shots through the staging buffers (3000 = 1024 + 1024 + 952)
+    plan = next(iter(sw._PLAN_CACHE.values()))
+    plan.chunk, plan.host_piece, plan._stage = 1024, 1024, None
+    assert np.array_equal(plan.decode_host(det_h.astype(np.bool_)), ref)
+    assert np.array_equal(plan.decode_host(det_h[:10]), ref[:10]) and plan.decode_host(det_h[:0]).shape == (0, ref.shape[1])
+    # another option / another window shape / another circuit: misses
+    sliding_window_bposd_circuit_mem(det_h, circ, hz, lz, 3, 1, **dict(kw, max_iter=21))
+    sliding_window_bposd_circuit_mem(det_h, circ, hz, lz, 5, 3, **kw)
+    other = helpers.circuit_text_at_p(name, 0.003, 0.002)
+    c2 = sliding_window_bposd_circuit_mem(det_h, Circuit(other), hz, lz, 3, 1, **kw)
+    info = sw.plan_cache_info()
+    assert info["misses"] == 4 and info["size"] == 4
+    assert not np.array_equal(c2, ref)                     # other priors: a different decoder, not the cached one
+    sw.plan_cache_clear()
+
+
+@pytest.mark.parametrize("p,shots", [(0.001, 400), (0.002, 300), (0.004, 200), (0.005, 200), (0.006, 200)])
 def test_config3_p_sweep_points_bit_exact(gpu, p, shots):
-    """configs[3]: the [[144,12,12]] single window at the two ends of the p-sweep (p = 1e-3: BP converges on ~98 % of the shots;
-    p = 6e-3: practically every shot goes through OSD), device against the oracle's double-precision ldpc-order decoder."""
+    """configs[3]: the [[144,12,12]] single window at every point of the p-sweep but the headline's (p = 1e-3: BP converges on
+    ~98 % of the shots; p = 6e-3: practically every shot goes through OSD), device against the oracle's double-precision
+    ldpc-order decoder."""
     circ, (H, L, pri) = _circuit_dem("bb144_custom_r12_p%g" % p)
     synd, obs, _ = orc.sample_dem(H, L, pri, seed=606, shot0=0, B=shots)
     err, status, dec = _gpu_decode(H, pri, synd, 50, osd="osd_0")
@@ -524,7 +571,7 @@ def test_config3_p_sweep_points_bit_exact(gpu, p, shots):
     assert np.array_equal((status >> 20) & 0xFFF, np.minimum(flags[:, 2], 4095)), "pivot counts differ"
     assert np.array_equal(err, ref)
     conv = flags[:, 0].mean()
-    assert (conv > 0.9) if p == 0.001 else (conv < 0.05), conv
+    assert (conv > 0.9) if p == 0.001 else (conv < 0.05 if p == 0.006 else 0.0 <= conv <= 1.0), conv
 
 
 @pytest.mark.parametrize("osd,order,shots,max_iter", [("osd_0", 0, 128, 30), ("osd_cs", 1, 64, 30)])
