@@ -83,13 +83,23 @@ def cpu_baseline(args, circ, hz, R, W, F, batch, plan, gpu_value):
     cpu_fail = int((ref != obs_h[:len(ref)]).any(axis=1).sum())
     gpu_pred = plan.decode(batch[0][:len(ref)]).cpu().numpy()
     gpu_fail = int((gpu_pred != obs_h[:len(ref)]).any(axis=1).sum())
+    # paired comparison on the common shots: discordant counts and McNemar's z -- "within 1 sigma" is read off these
+    cf = (ref != obs_h[:len(ref)]).any(axis=1)
+    gf = (gpu_pred != obs_h[:len(ref)]).any(axis=1)
+    only_cpu, only_gpu = int((cf & ~gf).sum()), int((gf & ~cf).sum())
+    pooled = (cpu_fail + gpu_fail) / (2.0 * len(ref))
+    paired = {"fail_cpu_only": only_cpu, "fail_gpu_only": only_gpu,
+              "mcnemar_z": (only_gpu - only_cpu) / float(np.sqrt(max(1, only_cpu + only_gpu))),
+              "delta_ler_in_sigma_unpaired": (gpu_fail - cpu_fail) / float(np.sqrt(max(1e-30, 2.0 * pooled * (1.0 - pooled) * len(ref)))),
+              "note": "same syndromes through both decoders; the CPU column computes in double on the exact channel LLRs, the device on "
+                      "LLRs rounded once to the grid (non-converged min-sum is chaotic: discordant shots are expected in both directions)"}
     sample = ("first %d shots of the first timed batch, same window plan and parameters; oracle/qd_oracle.c (double precision, ldpc's "
               "update order, exact LLRs)")
     res["cpu_baseline"] = {
         "value": len(ref) / cpua_s, "unit": "shots/s", "cores": ncpu, "kind": "port",
         "sample": sample % len(ref) + ", %d processes over shot slices" % ncpu,
         "ler": cpu_fail / len(ref), "gpu_ler_same_sample": gpu_fail / len(ref),
-        "shots_with_identical_prediction": float((ref == gpu_pred).all(axis=1).mean()),
+        "shots_with_identical_prediction": float((ref == gpu_pred).all(axis=1).mean()), "paired": paired,
         "speedup_vs_all_cores": gpu_value / (len(ref) / cpua_s)}
     res["cpu_baseline_1core"] = {"value": ns1 / cpu1_s, "unit": "shots/s", "cores": 1, "kind": "port", "sample": sample % ns1 + ", one thread",
                                  "speedup_vs_cpu_core": gpu_value / (ns1 / cpu1_s)}
@@ -440,6 +450,44 @@ def main():
                                                 "layout in HBM would have to move in the same time (not bytes that cross HBM here)"},
         }
     roofline["osd_kernel_ms_per_launch"] = prof["osd_ms"] / max(1, prof["osd_launches"])
+    # ---- the post-processing stage ("give the OSD kernels a roofline").  OSD-0 reads a shot's posteriors (4 n_pad bytes,
+    # L2-resident after BP wrote them: a few passes per tier), its syndrome and writes the packed correction; the elimination itself
+    # is GF(2) row work in registers / LDS.  Neither HBM nor the vector ALU bounds it: a shot is a chain of dependent barrier rounds
+    # (tools/osd_timing.py counts them), so the object reports the chain beside the two hardware ceilings.
+    if not args.osd_method.startswith("lsd") and args.osd_method != "osd_off":
+        osd_mask = ((st >> 17) & 1) == 1
+        n_osd = int(osd_mask.sum().item())
+        piv = ((st >> 20) & 0xFFF)[osd_mask].to(torch.float64)
+        mean_piv = float(piv.mean().item()) if n_osd else 0.0
+        osd_s = prof["osd_ms"] / 1e3
+        rec0 = per_dec[id(plan.windows[0]["dec"])]
+        n_pad0, m0 = (rec0["n"] + 63) // 64 * 64, rec0["m"]
+        osd_bytes = n_osd * (4 * n_pad0 + m0 + 4 * ((rec0["n"] + 31) // 32) + 8)
+        mw0 = (m0 + 63) // 64
+        # 64-bit word operations of a Gauss-Jordan elimination in T-form that stops after `piv` pivots: every pivot adds the pivot row's
+        # Q words (ceil(k / 64) of them so far) and the batch word to, on average, half of the m rows -- an upper estimate of the useful work
+        words = float((piv * (m0 / 2.0) * (1.0 + (piv / 64.0 + 1.0) / 2.0)).sum().item()) if n_osd else 0.0
+        osd_pm = None
+        try:
+            osd_pm = json.load(open(pmc_path)).get("osd_" + key)
+        except Exception:
+            pass
+        kern = "qd_osd0_sr_kernel" if (args.osd_method == "osd_0" and os.environ.get("QD_NO_OSD_SR") != "1") else ("qd_osd0_reg_kernel" if args.osd_method == "osd_0" else "qd_osdw_col_kernel")
+        roofline["osd"] = {
+            "kernel": kern, "avg_launch_ms": prof["osd_ms"] / max(1, prof["osd_launches"]), "shots_per_launch": n_osd / max(1, prof["osd_launches"]),
+            "mean_pivots": mean_piv, "us_per_shot": 1e6 * osd_s / max(1, n_osd),
+            "bound": "latency (dependent barrier rounds per shot); neither ceiling below is approached",
+            "hbm": {"algorithmic_bytes_per_launch": osd_bytes / max(1, prof["osd_launches"]), "achieved": osd_bytes / osd_s / 1e9 if osd_s > 0 else 0.0,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": osd_bytes / osd_s / 1e9 / HBM_PEAK_GBS if osd_s > 0 else 0.0,
+                    "traffic": (osd_pm or {}).get("bytes_per_launch"), "traffic_source": (osd_pm or {}).get("source")},
+            "gf2_words": {"per_launch": words / max(1, prof["osd_launches"]), "achieved": words / osd_s / 1e9 if osd_s > 0 else 0.0,
+                          "peak": NUM_CU * 64 * 2.0 * CLOCK_HZ / 1e9 / 2.0, "unit": "G 64-bit word-XORs/s",
+                          "frac": (words / osd_s / 1e9) / (NUM_CU * 64 * 2.0 * CLOCK_HZ / 1e9 / 2.0) if osd_s > 0 else 0.0,
+                          "note": "pivots x rows/2 x (Q words + batch word) per shot (an upper estimate of the row additions) against 2 wave-"
+                                  "instructions per CU-clock x 64 lanes / 2 instructions per 64-bit XOR"},
+            "sq_counters": (osd_pm or {}).get("sq_counters"),
+            "chain": (osd_pm or {}).get("chain"),
+        }
 
     value = n_shots / elapsed
     pl = n_err / n_shots

@@ -312,6 +312,7 @@ __global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const
 #pragma unroll
                 for (int q = 0; q < RW; ++q) cur[q] = __builtin_amdgcn_readlane(pf, q);
                 const uint32_t head = cur[0];
+                static_assert(QD_MAX_COL_DEG <= 31, "the record's weight field is decoded with & 31");
                 const int deg = (int)((head >> 24) & 31u);
                 float P[D], X[D], cv[D], pr[D];
                 pf = rb[(size_t)(st + 1 < g.nstep ? st + 1 : st) * (G * RW)];

@@ -351,7 +351,7 @@ __global__ void __launch_bounds__(T, QD_SR_WPS) qd_osd0_sr_kernel(OsdSrArgs a)
 int qd_osd_sr_layout(int m, int m_pad, int n, int out_words, int *off13, int *threads, int *rpt)
 {
     if (m > 2048 || n > 49152) return 0;              // rows per thread <= 4 at 512 threads; ppos holds 10 bits of batch number
-    const int T = m <= 4 * QD_SR_TSMALL ? QD_SR_TSMALL : 512;
+    const int T = m <= 256 ? 256 : (m <= 4 * QD_SR_TSMALL ? QD_SR_TSMALL : 512);     // windows of <= 256 checks: one row per thread on four wavefronts
     *threads = T; *rpt = (m + T - 1) / T;
     auto al = [](int x) { return (x + 15) & ~15; };
     int o = 0;

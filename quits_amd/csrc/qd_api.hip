@@ -387,6 +387,8 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             rcg |= g->mem.upload(ell, &gg.ell);
         }
         {
+            // the records below pack the fault index into 24 bits of their first word: refuse before building anything
+            if (n >= (1 << 24)) { g->mem.release(); delete g; return fail(QD_EINVAL, "more than 2^24 faults"); }
             std::vector<int32_t> last(m, 0), lev(n, 0);
             int nlev = 0;
             for (int j = 0; j < n; ++j) {
@@ -448,7 +450,6 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
                     }
             }
             gg.nlev = nlev; gg.nstep = (int)nstep; gg.srec_w = RW;
-            if (n >= (1 << 24)) { g->mem.release(); delete g; return fail(QD_EINVAL, "more than 2^24 faults"); }
             rcg |= g->mem.upload(srec, &gg.srec);
         }
         if (rcg) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while building the graph"); }
@@ -513,7 +514,18 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         sc.lds_bytes = sc.off_misc + 256;
         const int by_threads = 2048 / bp.threads;
         const int res_old = std::min(by_threads, QD_LDS_BYTES / std::max(1, bp.lds_bytes));
-        const int res_new = std::min(2048 / (scatter_wide ? wide_threads_ : bp.threads), QD_LDS_BYTES / sc.lds_bytes);
+        // the shape that will really be launched (the residency test used to look at a shape that never ran): several
+        // checks per lane -- see below for the measurements behind each case
+        int shape_threads = bp.threads, shape_cpl = 1;
+        if (scatter_wide) {
+            shape_threads = wide_threads_; shape_cpl = 2;
+            if (m <= 1536 && !std::getenv("QD_SCATTER_WIDE_T704")) { shape_threads = 512; shape_cpl = 3; }    // 19.8 -> 19.3 ms per QLP launch
+        } else if (!std::getenv("QD_SCATTER_CPL1")) {
+            if (bp.threads == 1024 && 4 * sc.lds_bytes <= QD_LDS_BYTES) { shape_threads = 512; shape_cpl = 2; }
+            else if (bp.threads == 512 && 8 * sc.lds_bytes <= QD_LDS_BYTES && !std::getenv("QD_SCATTER_NO_CPL2_256")) { shape_threads = 256; shape_cpl = 2; }
+            else if (bp.threads == 256 && 16 * sc.lds_bytes <= QD_LDS_BYTES) { shape_threads = 128; shape_cpl = 2; }    // (<= 128 checks, or QD_SCATTER_SMALL)
+        }
+        const int res_new = std::min(2048 / shape_threads, QD_LDS_BYTES / sc.lds_bytes);
         if (scatter_shape && min_rdeg >= 2 && bp.lds_bytes <= QD_LDS_BYTES && res_new >= 1 && res_new >= res_old) {
             const int rows = max_rdeg_pad / 4 + 2;            // two spare group rows: the kernel loads up to two groups ahead unconditionally
             std::vector<uint32_t> adjA((size_t)rows * m_pad * 4, (uint32_t)(sc.offA + n_pad * 4));
@@ -541,17 +553,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             // 65 536 shots, same bits (profiles/r03x_scatter_cpl2_ab.txt); taken when the LDS holds twice the workgroups.
             // QD_SCATTER_CPL1=1 keeps one check per lane.  Measured and not kept (profiles/r03x_scatter_shapes2_ab.txt): four checks per
             // lane on a quarter of the lanes (headline 46.2 -> 50.9 ms), 384 lanes x 4 checks for the QLP windows (19.2 -> 24.4 ms).
-            sc.wide_threads = 0; sc.wide_cpl = 0;
-            if (scatter_wide) {
-                sc.wide_threads = wide_threads_; sc.wide_cpl = 2;
-                if (m <= 1536 && !std::getenv("QD_SCATTER_WIDE_T704")) { sc.wide_threads = 512; sc.wide_cpl = 3; }    // 19.8 -> 19.3 ms per QLP launch
-            } else if (!std::getenv("QD_SCATTER_CPL1")) {
-                if (bp.threads == 1024 && 4 * sc.lds_bytes <= QD_LDS_BYTES) {
-                    sc.wide_threads = 512; sc.wide_cpl = 2;
-                }
-                else if (bp.threads == 512 && 8 * sc.lds_bytes <= QD_LDS_BYTES && !std::getenv("QD_SCATTER_NO_CPL2_256")) { sc.wide_threads = 256; sc.wide_cpl = 2; }
-                else if (bp.threads == 256 && 16 * sc.lds_bytes <= QD_LDS_BYTES) { sc.wide_threads = 128; sc.wide_cpl = 2; }    // (<= 128 checks, or QD_SCATTER_SMALL)
-            }
+            sc.wide_threads = shape_cpl > 1 ? shape_threads : 0; sc.wide_cpl = shape_cpl > 1 ? shape_cpl : 0;
             if (sc.wide_threads) {
                 // deal the slot-waves (64 consecutive check slots, heaviest first) to the workgroup's wavefronts so that the largest
                 // number of edges a wavefront walks between two barriers is small: each goes to the wavefront with the fewest edges so
