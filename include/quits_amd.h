@@ -112,6 +112,10 @@ int qd_decoder_reserve(qd_decoder *d, int64_t max_batch);
  * batches are decoded in equal chunks that fit.  A sliding-window plan holds one decoder per window: the host divides
  * the budget among them.  No reference counterpart (memory management). */
 int qd_decoder_set_workspace_limit(qd_decoder *d, int64_t bytes);
+/* Hand the device workspace back (posteriors, fail lists, message planes, elimination scratch); the decoder stays usable and
+ * sizes it again at the next decode.  The host keeps sliding-window plans between calls (the reference is called once per
+ * experiment point, bposd.py:54-86) and only the plan in use keeps its workspace.  No reference counterpart (memory management). */
+int qd_decoder_release_workspace(qd_decoder *d);
 
 /* ---- decode: replaces the per-shot `decoder.decode(syndrome)` calls (sliding_window.py:85,95,171,182) for a
  *      whole batch of shots, including the syndrome preparation in front of them (:168-169,179-180):

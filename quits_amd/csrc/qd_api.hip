@@ -1015,6 +1015,15 @@ extern "C" int qd_decoder_set_workspace_limit(qd_decoder *d, int64_t bytes)
     return QD_OK;
 }
 
+extern "C" int qd_decoder_release_workspace(qd_decoder *d)
+{
+    if (!d) return fail(QD_EINVAL, "null decoder");
+    HIP_TRY(hipSetDevice(d->g->device));
+    HIP_TRY(hipDeviceSynchronize());
+    free_ws(d);
+    return QD_OK;
+}
+
 extern "C" int qd_decoder_set_profiling(qd_decoder *d, int32_t enable)
 {
     if (!d) return fail(QD_EINVAL, "null decoder");

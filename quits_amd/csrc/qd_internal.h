@@ -207,6 +207,16 @@ __device__ __forceinline__ uint32_t qd_wave_umin(uint32_t v)
     v = min(v, QD_DPP(v, 0xFFFFFFFFu, 0x143, 0xc));   // row_bcast:31 into rows 2 and 3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ uint32_t qd_wave_or(uint32_t v)
+{
+    v |= QD_DPP(v, 0u, 0x111, 0xf);
+    v |= QD_DPP(v, 0u, 0x112, 0xf);
+    v |= QD_DPP(v, 0u, 0x114, 0xf);
+    v |= QD_DPP(v, 0u, 0x118, 0xf);
+    v |= QD_DPP(v, 0u, 0x142, 0xa);
+    v |= QD_DPP(v, 0u, 0x143, 0xc);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t qd_wave_add(uint32_t v)
 {
     v += QD_DPP(v, 0u, 0x111, 0xf);

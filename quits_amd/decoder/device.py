@@ -96,6 +96,10 @@ class BatchDecoder:
         """Cap the HBM message workspace of the one-message-per-edge BP kernel (product_sum / serial); no effect on the LDS kernel."""
         _lib.check(self._L.qd_decoder_set_workspace_limit(self._h, int(nbytes)))
 
+    def release_workspace(self):
+        """Give the device workspace back; the next decode sizes it again."""
+        _lib.check(self._L.qd_decoder_release_workspace(self._h))
+
     def reserve(self, max_batch: int):
         _lib.check(self._L.qd_decoder_reserve(self._h, int(max_batch)))
 

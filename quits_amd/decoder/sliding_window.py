@@ -132,6 +132,15 @@ class DeviceWindowPlan:
         self._stage = None
         self.host_piece = int(os.environ.get("QD_HOST_PIECE_SHOTS", str(4 * self.chunk)))   # shots per staged piece (>= 2 chunks: the pipelined driver)
 
+    def release_workspaces(self):
+        """Hand the decoders' device workspaces and the staging buffers back (the plan itself -- graphs, decoders, matrices --
+        stays): cached plans that are not the one in use hold no large allocations."""
+        for w in self.windows:
+            for key in ("dec", "dec2"):
+                if key in w:
+                    w[key].release_workspace()
+        self._stage = None
+
     def window_matrices(self):
         """Host copies of the window check matrices, in window order (bench.py derives its work model from them)."""
         return [w["H"] for w in self.windows]
@@ -420,15 +429,25 @@ def cached_plan(key, build):
     if _PLAN_CACHE is None:
         _PLAN_CACHE = OrderedDict()
     plan = _PLAN_CACHE.get(key)
+    # only the plan in use keeps device workspaces (the per-edge BP kernel sizes its message planes for tens of GB): the
+    # others keep their graphs and decoders and size their workspaces again when they are used next
+    for k, other in _PLAN_CACHE.items():
+        if k != key and hasattr(other, "release_workspaces") and getattr(other, "_ws_live", True):
+            other.release_workspaces()
+            other._ws_live = False
     if plan is not None:
         _PLAN_CACHE.move_to_end(key)
         _PLAN_STATS["hits"] += 1
-        return plan
-    _PLAN_STATS["misses"] += 1
-    plan = build()
-    _PLAN_CACHE[key] = plan
-    while len(_PLAN_CACHE) > cap:
-        _PLAN_CACHE.popitem(last=False)
+    else:
+        _PLAN_STATS["misses"] += 1
+        plan = build()
+        _PLAN_CACHE[key] = plan
+        while len(_PLAN_CACHE) > cap:
+            _PLAN_CACHE.popitem(last=False)
+    try:
+        plan._ws_live = True
+    except AttributeError:
+        pass
     return plan
 
 

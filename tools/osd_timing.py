@@ -26,7 +26,8 @@ names = ["tier(select+sort)", "batch-load", "pivots(rest)", "finish", "round: ke
 tot = (sum(c[:8]) + c[10]) or 1
 print("%-10s %6.1f %%   %8.0f ticks/shot" % ("shot init", 100.0 * c[10] / tot, c[10] / max(c[8], 1)))
 
-print("per shot: rounds %.2f tiers %.2f batches %.2f" % (c[11] / max(c[8], 1), c[12] / max(c[8], 1), c[13] / max(c[8], 1)));print( "kernel info", g.info())
+print("per shot: rounds %.2f tiers %.2f batches %.2f" % (c[11] / max(c[8], 1), c[12] / max(c[8], 1), c[13] / max(c[8], 1)));print("column kernel: batches per shot before / after npiv >= m - 64: %.1f / %.1f; ticks per shot in the late batches %.0f" % (c[12] / max(c[8], 1), c[13] / max(c[8], 1), c[14] / max(c[8], 1)))
+print("kernel info", g.info())
 print("osd kernel ms", pr["osd_ms"], "shots", c[8], "mean pivots", c[9] / max(c[8], 1))
 for i, nme in enumerate(names):
     print("%-10s %6.1f %%   %8.0f ticks/shot" % (nme, 100.0 * c[i] / tot, c[i] / max(c[8], 1)))
