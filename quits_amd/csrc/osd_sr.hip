@@ -29,8 +29,13 @@
 //
 // State: a thread owns RPT rows and keeps their batch word, syndrome bit, pivot flag and the first KWR Q planes in REGISTERS; there
 // is no LDS mirror (pivot rows are published per round: 64 x (KWR + 1) words), so a shot needs ~26 KB of LDS at the headline
-// window and six 256-thread workgroups share a CU (the mirrored kernel: 47 KB, three of 512).  Q planes beyond KWR * 64 pivots
-// live in an L2-resident spill, addressed by the owner of the row.
+// window.  Q planes beyond KWR * 64 pivots live in an L2-resident spill, addressed by the owner of the row.
+// Registers: 512 threads x 2 rows at a 128-register budget (two workgroups per CU) -- NO scratch.  At 80 registers (three per CU)
+// the kernel spilled ~50 vector registers next to ~100 scalar registers the compiler parks in vector-register lanes; spill-heavy
+// builds of this and of the column kernel faulted on the GPU until scalar spills were sent to memory instead, which cost 20 % and
+// 0.8 GB of scratch writes per launch.  Same box, 65 536 headline shots / p = 6e-3: 80 registers + scalar spills to memory 5.05 /
+// 66.4 ms, 128 registers 4.40 / 72 ms (profiles/r04_osd_sr_register_budget_ab.txt); tests/test_api.py holds every instantiation
+// to ScratchSize 0.
 #include "osd_shared.h"
 #include <cstdlib>
 #include <algorithm>
@@ -53,7 +58,7 @@ struct OsdSrArgs {
 };
 
 template <int T, int RPT, int KWR>
-__global__ void __launch_bounds__(T, QD_SR_WPS) qd_osd0_sr_kernel(OsdSrArgs a)
+__global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;

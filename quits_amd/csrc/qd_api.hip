@@ -705,7 +705,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         const int lds = qd_osd_sr_layout(m, m_pad, n, bp.out_words, od.s_off, &od.s_threads, &od.s_rpt);
         if (lds > 0 && lds <= QD_LDS_BYTES) {
             od.s_lds_bytes = lds;
-            od.s_per_cu = std::max(1, std::min(QD_LDS_BYTES / lds, QD_SR_WPS * 256 / od.s_threads));   // QD_SR_WPS wavefronts per SIMD: the kernel's register budget
+            od.s_per_cu = std::max(1, std::min(QD_LDS_BYTES / lds, QD_SR_WPS_OF(od.s_rpt) * 256 / od.s_threads));   // the kernel's register budget (wavefronts per SIMD)
         }
     }
     // the full kernel sorts all n columns in LDS; windows too large for that rely on the register kernel alone

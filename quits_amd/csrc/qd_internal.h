@@ -8,10 +8,11 @@
 #define QD_MAX_ROW_DEG 255     // edge position inside a check is a byte
 #define QD_LDS_BYTES (160 * 1024)
 #ifndef QD_SR_KWR_OF
-#define QD_SR_KWR_OF(rpt) ((rpt) <= 2 ? 4 : 2)
+#define QD_SR_KWR_OF(rpt) 4
 #endif
-#ifndef QD_SR_WPS
-#define QD_SR_WPS 6            // wavefronts per SIMD its register budget is cut for
+#ifndef QD_SR_WPS_OF
+#define QD_SR_WPS_OF(rpt) ((rpt) <= 2 ? 4 : 2)   // wavefronts per SIMD its register budget is cut for: 128 / 256 registers -- no instantiation may
+                                                 // spill vector registers (scalar registers it cannot keep live in lanes of vector registers)
 #endif
 #ifndef QD_SR_TSMALL
 #define QD_SR_TSMALL 512       // its workgroup size for windows of <= 1024 detectors

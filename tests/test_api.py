@@ -175,3 +175,21 @@ def test_product_path_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "liboracle" not in txt and "qd_oracle" not in txt.replace("oracle/qd_oracle.c", ""), f
+
+
+def test_osd_sr_kernel_instantiations_use_no_scratch(tmp_path):
+    """qd_osd0_sr_kernel keeps ~100 spilled scalar registers in lanes of vector registers; that is only safe while no vector
+    register is spilled (a spill-heavy build faulted on the GPU): every instantiation must report ScratchSize 0."""
+    import re
+    import subprocess
+    cs = os.path.join(ROOT, "quits_amd", "csrc")
+    mk = open(os.path.join(cs, "Makefile")).read()
+    flags = re.search(r"^FLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    flags = [f for f in flags if f != "-shared"]
+    out = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", "-o",
+                          str(tmp_path / "osd_sr.o"), os.path.join(cs, "osd_sr.hip")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    kern = [(n, sc) for n, sc in zip(names, scratch) if "qd_osd0_sr_kernel" in n]
+    assert len(kern) >= 8 and all(sc == 0 for _, sc in kern), kern

@@ -91,6 +91,12 @@ def test_bench_rank_plumbing_two_processes():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line == {"dry_run": True, "n_gpus": 2, "errors": 3, "shots": 2002, "tmax": 2.0}
+    # BASELINE configs[4] is an 8-GPU configuration: the QLP sliding-window command line takes the same branch
+    qlp = _torchrun(2, [bench, "--gpus", "2", "--dry-run-backend", "gloo", "--code", "qlp1020", "--window", "3", "1", "--shots", "8192",
+                        "--p-override", "0.001", "--osd-method", "osd_cs", "--osd-order", "1"], 29647)
+    assert qlp.returncode == 0, qlp.stderr[-2000:]
+    line = json.loads([ln for ln in qlp.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"dry_run": True, "n_gpus": 2, "errors": 3, "shots": 16384, "tmax": 2.0}
     bad = _torchrun(2, [bench, "--gpus", "1", "--dry-run-backend", "gloo"], 29643)
     assert bad.returncode != 0 and "--gpus 1 but WORLD_SIZE=2" in (bad.stderr + bad.stdout)
     # without --dry-run-backend the next thing bench.py does is ask for a GPU, and says so

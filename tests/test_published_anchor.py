@@ -71,3 +71,30 @@ def test_anchor_settings_device_equals_its_float_mirror(gpu):
     assert np.array_equal(pred, p32.astype(np.int64))
     p64 = pa._oracle_worker((case, synd, orc.FORM_LDPC_F64))
     assert (pred != p64).any(axis=1).sum() <= 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", ["06A_hgp_p2e-3", "05_hgp_phenom_bplsd"])
+def test_anchor_device_vs_double_precision_oracle_paired_8192_shots(gpu, cid):
+    """the two informative anchor points -- 24 / 200 (BP-OSD, circuit level) and 20 / 100 (BP-LSD order 1,
+    phenomenological) -- on 8192 common shots: the device (float product-sum) against the oracle in ldpc's arithmetic (double,
+    exact LLRs), paired.  McNemar's |z| <= 3 on the discordant shots, and both failure rates inside the published interval."""
+    import multiprocessing as mp
+    from quits_amd.decoder.base import detector_error_model_to_matrix
+    from quits_amd.dem import Circuit
+    case = [c for c in pa.CASES if c[0] == cid][0]
+    H, L, pri = detector_error_model_to_matrix(Circuit(pa.circuit_for(case)).detector_error_model())
+    B = 8192
+    synd, obs, _ = orc.sample_dem(H, L, pri, seed=4242, shot0=0, B=B)
+    pred = pa.device_decode(case, synd)
+    nproc = max(1, min(16, len(os.sched_getaffinity(0))))
+    orc.lib()
+    with mp.get_context("fork").Pool(nproc) as pool:                  # children never touch the GPU
+        p64 = pa.oracle_decode(case, synd, orc.FORM_LDPC_F64, pool, nproc)
+    fd = (pred != obs).any(axis=1)
+    fo = (p64 != obs).any(axis=1)
+    only_dev, only_orc = int((fd & ~fo).sum()), int((fo & ~fd).sum())
+    z = (only_dev - only_orc) / max(1.0, float(np.sqrt(only_dev + only_orc)))
+    lo, hi = pa.clopper_pearson(case[10], case[11])
+    assert abs(z) <= 3.0, (cid, only_dev, only_orc, z)
+    assert lo <= fd.mean() <= hi and lo <= fo.mean() <= hi, (cid, float(fd.mean()), float(fo.mean()), lo, hi)
