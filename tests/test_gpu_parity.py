@@ -912,6 +912,45 @@ def test_bplsd_wide_windows(gpu, rows):
     assert big > 128, "no shot reached the Q planes kept in HBM"
 
 
+@pytest.mark.parametrize("rows", [1296, 1708, 2016])
+def test_osd0_many_pivot_kernel_wide_windows(gpu, rows):
+    """qd_osd0_sr_kernel's instantiations with three and four rows per thread (1025..1536 and 1537..2048 checks), OSD-0 alone on
+    block-diagonal matrices assembled from the committed windows: early stops inside a batch (the drain and the sequential pivot count),
+    shots that run deep into the Q planes kept in L2 (more than 256 pivots), ties; vs the oracle, bit for bit."""
+    from scipy.sparse import block_diag, csc_matrix
+    Ha, La, pa = helpers.dem_matrices("bb144_custom_r12_p0.003")
+    if rows == 1296:
+        Hb, Lb, pb = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    elif rows == 1708:
+        Hb, pb = csc_matrix(Ha[:700]), pa
+    else:
+        Hb, pb = Ha, pa
+    H = csc_matrix(block_diag([Ha, Hb], format="csc"))
+    pri = np.concatenate([pa, pb])
+    m, n = H.shape
+    assert m == rows and n <= 49152
+    rng = np.random.default_rng(rows)
+    B = 16
+    e = (rng.random((B, n)) < np.minimum(4 * pri, 0.4)).astype(np.uint8)
+    e[B - 4:] = (rng.random((4, n)) < np.minimum(40 * pri, 0.5)).astype(np.uint8)       # heavy errors: hundreds of pivots
+    synd = np.ascontiguousarray(np.asarray((csc_matrix(e) @ H.T).todense()) % 2, dtype=np.uint8)
+    llr = rng.normal(size=(B, n)).astype(np.float32) + 2.0
+    llr[:3] = np.log((1 - pri) / pri).astype(np.float32)
+    llr[e.astype(bool)] -= 3.0
+    llr[3] = 1.0                                                                           # one key for every fault: order by index
+    err, status = _osd_only(H, pri, synd, llr)
+    g = orc.Graph(H, pri)
+    Hd = np.asarray(H.todense(), dtype=np.int64)
+    big = 0
+    for b in range(B):
+        ref, st = g.osd0(synd[b], llr[b].astype(np.float64), stop_early=True)
+        assert np.array_equal(err[b], ref), b
+        assert ((status[b] >> 20) & 0xFFF) == min(st["pivots"], 4095) and not st["inconsistent"], (b, st)
+        big = max(big, st["pivots"])
+    assert np.array_equal((err.astype(np.int64) @ Hd.T) % 2, synd)
+    assert big > 256, "no shot reached the Q planes kept in L2"
+
+
 def test_bplsd_sliding_window_functions(gpu):
     """sliding_window_bplsd_circuit_mem / _phenom_mem (reference bplsd.py:10,54) on the device against the oracle's loop."""
     from quits_amd.decoder import BpLsdDecoder, sliding_window_bplsd_circuit_mem, sliding_window_bplsd_phenom_mem
