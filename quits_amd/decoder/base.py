@@ -14,7 +14,11 @@ from typing import List, Sequence, Tuple
 import numpy as np
 from scipy.sparse import csc_matrix, csr_matrix
 
+from collections import OrderedDict
+
 from ..dem import as_dem
+
+_MATRIX_CACHE: "OrderedDict[str, tuple]" = OrderedDict()   # circuit structure (dem.structure_key) -> (check, observable, fold order of the priors)
 
 
 def _csc_from_columns(cols: Sequence[Sequence[int]], nrows: int) -> csc_matrix:
@@ -55,10 +59,28 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
       * an error without detectors is printed (base.py:114-115) and still becomes an (all-zero) column.
     """
     dem = as_dem(dem)
+    skey = getattr(dem, "structure_key", None)
+    if skey is not None and skey in _MATRIX_CACHE:
+        # same circuit structure, other probabilities (quits_amd/dem.py): the matrices are the cached ones, the priors are folded again in
+        # the order the loop below folds them -- the same floating-point numbers
+        check, obs, steps = _MATRIX_CACHE[skey]
+        _MATRIX_CACHE.move_to_end(skey)
+        p_err = np.fromiter((e[0] for e in dem.errors), dtype=np.float64, count=len(dem.errors))
+        priors = np.zeros(check.shape[1], dtype=np.float64)
+        for k, (col_idx, err_idx) in enumerate(steps):
+            p = p_err[err_idx]
+            if k == 0:
+                priors[col_idx] = p
+            else:
+                q = priors[col_idx]
+                priors[col_idx] = q * (1 - p) + p * (1 - q)
+        return check, obs, priors
     col_of: dict = {}
     det_sets: List[frozenset] = []
     obs_sets: List[frozenset] = []
     priors: List[float] = []
+    members: List[List[int]] = []           # column -> the error instructions folded into it, in order
+    n_err = 0
     for inst in dem.flattened():
         kind = inst.type
         if kind == "error":
@@ -78,15 +100,28 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
                 det_sets.append(key)
                 obs_sets.append(frozenset(obs))
                 priors.append(p)
+                members.append([n_err])
             else:
                 q = priors[j]
                 priors[j] = q * (1 - p) + p * (1 - q)
+                members[j].append(n_err)
+            n_err += 1
         elif kind in ("detector", "logical_observable"):
             continue
         else:
             raise NotImplementedError()
     check = _csc_from_columns(det_sets, dem.num_detectors)
     obs = _csc_from_columns(obs_sets, dem.num_observables)
+    if skey is not None and n_err == len(getattr(dem, "errors", ())):
+        depth = max((len(c) for c in members), default=0)
+        steps = []
+        for k in range(depth):
+            col_idx = np.fromiter((j for j, c in enumerate(members) if len(c) > k), dtype=np.int64)
+            err_idx = np.fromiter((c[k] for c in members if len(c) > k), dtype=np.int64, count=col_idx.size)
+            steps.append((col_idx, err_idx))
+        _MATRIX_CACHE[skey] = (check, obs, steps)
+        while len(_MATRIX_CACHE) > 4:
+            _MATRIX_CACHE.popitem(last=False)
     return check, obs, np.array(priors)
 
 

@@ -21,8 +21,13 @@ generate tests/golden fixtures) and so can this package's restatement.
 """
 from __future__ import annotations
 
+import hashlib
 import math
+import os
+from collections import OrderedDict
 from typing import Dict, List, Tuple
+
+import numpy as np
 
 from .stim_text import Op, flatten
 
@@ -72,6 +77,7 @@ class DetectorErrorModel:
         self.errors = errors
         self.num_detectors = num_detectors
         self.num_observables = num_observables
+        self.structure_key = None        # set by circuit_to_dem: DEMs of one circuit structure differ in their probabilities only
 
     def flattened(self):
         return [DemInstruction(p, d, o) for (p, d, o) in self.errors]
@@ -93,9 +99,95 @@ def _bits(x: int) -> List[int]:
     return out
 
 
+_NOISE = ("X_ERROR", "Z_ERROR", "DEPOLARIZE1", "DEPOLARIZE2")
+
+# Structure cache.  The reference's notebooks call the decoder once per physical error rate (doc/06B_end_to_end_demo_bb.ipynb cell 5)
+# with circuits that differ in nothing but the noise arguments, and the analysis below is pure Python (11 s for the QLP [[1020,136]]
+# circuit).  What depends on the arguments is only the probability attached to each symptom, so the symptoms, their order and -- per
+# symptom -- the noise instructions that contribute, IN THE ORDER the pass meets them, are kept per circuit structure (everything but
+# the noise arguments); another error rate then only replays  p <- p(1-q) + q(1-p)  in that order, vectorised by position, which gives
+# the same floating-point numbers as the full pass, bit for bit.  QD_DEM_STRUCT_CACHE = structures kept (default 4, 0 = off).
+_STRUCT_CACHE: "OrderedDict[str, dict]" = OrderedDict()
+_STRUCT_STATS = {"hits": 0, "misses": 0}
+
+
+def _struct_cap() -> int:
+    try:
+        return max(0, int(os.environ.get("QD_DEM_STRUCT_CACHE", "4")))
+    except ValueError:
+        return 4
+
+
+def dem_struct_cache_info() -> dict:
+    return {"size": len(_STRUCT_CACHE), "capacity": _struct_cap(), **_STRUCT_STATS}
+
+
+def dem_struct_cache_clear() -> None:
+    _STRUCT_CACHE.clear()
+    _STRUCT_STATS["hits"] = 0
+    _STRUCT_STATS["misses"] = 0
+
+
+def _structure_key(ops, num_meas, num_det, num_obs) -> str:
+    """Everything the analysis depends on except the VALUE of the noise arguments (whether one is zero does change the structure:
+    a zero-probability mechanism is dropped)."""
+    h = hashlib.sha1(("%d %d %d|" % (num_meas, num_det, num_obs)).encode())
+    for op in ops:
+        h.update(op.name.encode())
+        if op.name in _NOISE:
+            h.update(b"+" if op.arg > 0.0 else b"0")
+        else:
+            h.update(repr(op.arg).encode())
+        h.update(np.asarray(op.targets, dtype=np.int64).tobytes())
+        h.update(b";")
+    return h.hexdigest()
+
+
+def _mechanism_probability(op) -> float:
+    """Independent-equivalent probability of ONE component of the noise instruction (see the module docstring)."""
+    if op.name in ("X_ERROR", "Z_ERROR"):
+        return op.arg
+    if op.name == "DEPOLARIZE1":
+        if op.arg > 0.75:
+            raise ValueError("DEPOLARIZE1 probability above 3/4")
+        return 0.5 - 0.5 * math.sqrt(1.0 - 4.0 * op.arg / 3.0)
+    if op.arg > 15.0 / 16.0:
+        raise ValueError("DEPOLARIZE2 probability above 15/16")
+    return 0.5 - 0.5 * (1.0 - 16.0 * op.arg / 15.0) ** 0.125
+
+
+def _replay_probabilities(st: dict, ops) -> np.ndarray:
+    """Probabilities of the cached structure's symptoms for another set of noise arguments: the k-th contribution of every symptom
+    is folded in at step k, i.e. in the order the full pass folds them."""
+    q_of_op = np.zeros(len(ops), dtype=np.float64)
+    for i in st["noise_ops"]:
+        q_of_op[i] = _mechanism_probability(ops[i])
+    prob = np.zeros(st["nsym"], dtype=np.float64)
+    for k, (sym_idx, op_idx) in enumerate(st["steps"]):
+        q = q_of_op[op_idx]
+        if k == 0:
+            prob[sym_idx] = q
+        else:
+            pk = prob[sym_idx]
+            prob[sym_idx] = pk * (1.0 - q) + q * (1.0 - pk)
+    return prob
+
+
 def circuit_to_dem(text: str) -> DetectorErrorModel:
     """Backward Pauli-sensitivity analysis of a QUITS-dialect Stim circuit."""
     ops, num_meas, num_det, num_obs = flatten(text)
+    cap = _struct_cap()
+    skey = _structure_key(ops, num_meas, num_det, num_obs) if cap > 0 else None
+    if skey is not None and skey in _STRUCT_CACHE:
+        st = _STRUCT_CACHE[skey]
+        _STRUCT_CACHE.move_to_end(skey)
+        _STRUCT_STATS["hits"] += 1
+        prob = _replay_probabilities(st, ops)
+        errors = [(float(prob[i]), d, o) for i, (d, o) in enumerate(st["rows"])]
+        dem = DetectorErrorModel(errors, num_det, num_obs)
+        dem.structure_key = skey
+        return dem
+    _STRUCT_STATS["misses"] += 1
     # symptom bitmask layout: bit d for detector d, bit num_det + o for observable o
     meas_sens = [0] * num_meas            # which detectors/observables include measurement k
     nq = 1 + max((max(op.targets) for op in ops if op.name not in ("DETECTOR", "OBSERVABLE_INCLUDE")
@@ -103,15 +195,23 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
     xs = [0] * nq                          # flipped by an X error on q inserted *here*
     zs = [0] * nq
     probs: Dict[int, float] = {}
+    contrib: Dict[int, List[int]] = {}     # symptom -> indices of the noise instructions folded into it, in order
+    cur_op = 0
 
     def add(sym: int, q: float):
         if sym == 0 or q == 0.0:
             return
         p = probs.get(sym)
-        probs[sym] = q if p is None else p * (1.0 - q) + q * (1.0 - p)
+        if p is None:
+            probs[sym] = q
+            contrib[sym] = [cur_op]
+        else:
+            probs[sym] = p * (1.0 - q) + q * (1.0 - p)
+            contrib[sym].append(cur_op)
 
     m = num_meas                           # running "measurements before this point" counter
-    for op in reversed(ops):
+    for cur_op in range(len(ops) - 1, -1, -1):
+        op = ops[cur_op]
         name = op.name
         t = op.targets
         if name == "DETECTOR":
@@ -155,18 +255,14 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
             for q in t:
                 add(zs[q], op.arg)
         elif name == "DEPOLARIZE1":
-            if op.arg > 0.75:
-                raise ValueError("DEPOLARIZE1 probability above 3/4")
-            q1 = 0.5 - 0.5 * math.sqrt(1.0 - 4.0 * op.arg / 3.0)
+            q1 = _mechanism_probability(op)
             for q in t:
                 x, z = xs[q], zs[q]
                 add(x, q1)
                 add(z, q1)
                 add(x ^ z, q1)
         elif name == "DEPOLARIZE2":
-            if op.arg > 15.0 / 16.0:
-                raise ValueError("DEPOLARIZE2 probability above 15/16")
-            q2 = 0.5 - 0.5 * (1.0 - 16.0 * op.arg / 15.0) ** 0.125
+            q2 = _mechanism_probability(op)
             for i in range(0, len(t), 2):
                 a, b = t[i], t[i + 1]
                 pa = (0, xs[a], xs[a] ^ zs[a], zs[a])
@@ -185,11 +281,26 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
     for sym, p in probs.items():
         dets = tuple(_bits(sym & det_mask))
         obs = tuple(_bits(sym >> num_det))
-        rows.append((dets, obs, p))
+        rows.append((dets, obs, p, sym))
     # Stim orders DemTargets with detectors before observables; compare target lists lexicographically
     rows.sort(key=lambda r: tuple(r[0]) + tuple(num_det + o for o in r[1]))
-    errors = [(p, d, o) for (d, o, p) in rows]
-    return DetectorErrorModel(errors, num_det, num_obs)
+    errors = [(p, d, o) for (d, o, p, _) in rows]
+    dem = DetectorErrorModel(errors, num_det, num_obs)
+    if skey is not None:
+        # steps[k] = (symptoms that have a k-th contribution, the noise instruction of that contribution), as index arrays
+        lists = [contrib[r[3]] for r in rows]
+        depth = max((len(c) for c in lists), default=0)
+        steps = []
+        for k in range(depth):
+            sym_idx = np.fromiter((i for i, c in enumerate(lists) if len(c) > k), dtype=np.int64)
+            op_idx = np.fromiter((c[k] for c in lists if len(c) > k), dtype=np.int64, count=sym_idx.size)
+            steps.append((sym_idx, op_idx))
+        _STRUCT_CACHE[skey] = {"rows": [(r[0], r[1]) for r in rows], "nsym": len(rows), "steps": steps,
+                               "noise_ops": [i for i, op in enumerate(ops) if op.name in _NOISE and op.arg > 0.0]}
+        while len(_STRUCT_CACHE) > cap:
+            _STRUCT_CACHE.popitem(last=False)
+        dem.structure_key = skey
+    return dem
 
 
 class Circuit(str):

@@ -232,3 +232,39 @@ def test_all_detectors_circuit_shapes():
     assert dem.num_detectors == 36 * (2 + 2) + 36 * 2, dem.num_detectors
     H, L, pri = detector_error_model_to_matrix(dem)
     assert H.shape[0] == dem.num_detectors and (np.diff(H.tocsc().indptr) > 0).all() and 0 < pri.min() and pri.max() < 0.5
+
+
+@pytest.mark.parametrize("name,p_from,p_to", [("bb72_custom_r6_p0.003", 0.003, 0.0007), ("hgp225_cardinal_r3_p0.01", 0.01, 0.004),
+                                              ("bb72_custom_r2_xbasis_mixed", None, None)])
+def test_structure_cache_replays_the_same_numbers(monkeypatch, name, p_from, p_to):
+    """The reference's notebooks call the decoder once per physical error rate with circuits that differ in the noise arguments
+    only.  quits_amd.dem keeps the symptom structure per circuit structure and replays the probability folding for other
+    arguments; decoder.base does the same for its merge by detector set.  Both must return the numbers of the full pass, bit for
+    bit (same symptoms, same order, identical floats), and a circuit with another structure must not hit the cache."""
+    from quits_amd import dem
+    from quits_amd.decoder import base
+    base_text = helpers.circuit_text(name)
+    other = helpers.circuit_text_at_p(name, p_from, p_to) if p_from else base_text.replace("0.0030000000", "0.0012500000")
+    assert other != base_text
+    monkeypatch.setenv("QD_DEM_STRUCT_CACHE", "0")
+    full = dem.circuit_to_dem(other)
+    Hf, Lf, pf = base.detector_error_model_to_matrix(dem.Circuit(other))
+    assert full.structure_key is None
+    monkeypatch.setenv("QD_DEM_STRUCT_CACHE", "4")
+    dem.dem_struct_cache_clear()
+    base._MATRIX_CACHE.clear()
+    first = dem.circuit_to_dem(base_text)
+    base.detector_error_model_to_matrix(dem.Circuit(base_text))
+    assert dem.dem_struct_cache_info()["misses"] == 1 and first.structure_key is not None
+    replay = dem.circuit_to_dem(other)
+    assert dem.dem_struct_cache_info()["hits"] >= 1 and replay.structure_key == first.structure_key
+    assert replay.errors == full.errors                       # tuples of (float, detectors, observables): exact equality
+    Hr, Lr, pr = base.detector_error_model_to_matrix(dem.Circuit(other))
+    assert np.array_equal(pr, pf) and (Hr != Hf).nnz == 0 and (Lr != Lf).nnz == 0
+    # a noise argument of zero drops mechanisms: another structure
+    zeroed = base_text.replace("%.10f" % (p_from or 0.003), "%.10f" % 0.0)
+    if zeroed != base_text:
+        z = dem.circuit_to_dem(zeroed)
+        assert z.structure_key != first.structure_key
+    dem.dem_struct_cache_clear()
+    base._MATRIX_CACHE.clear()
