@@ -113,12 +113,8 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
     check = _csc_from_columns(det_sets, dem.num_detectors)
     obs = _csc_from_columns(obs_sets, dem.num_observables)
     if skey is not None and n_err == len(getattr(dem, "errors", ())):
-        depth = max((len(c) for c in members), default=0)
-        steps = []
-        for k in range(depth):
-            col_idx = np.fromiter((j for j, c in enumerate(members) if len(c) > k), dtype=np.int64)
-            err_idx = np.fromiter((c[k] for c in members if len(c) > k), dtype=np.int64, count=col_idx.size)
-            steps.append((col_idx, err_idx))
+        from ..dem import fold_steps
+        steps = fold_steps(members)
         _MATRIX_CACHE[skey] = (check, obs, steps)
         while len(_MATRIX_CACHE) > 4:
             _MATRIX_CACHE.popitem(last=False)

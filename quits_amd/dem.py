@@ -156,6 +156,29 @@ def _mechanism_probability(op) -> float:
     return 0.5 - 0.5 * (1.0 - 16.0 * op.arg / 15.0) ** 0.125
 
 
+def fold_steps(lists) -> list:
+    """lists[i] = what is folded into entry i, in order  ->  steps[k] = (entries that have a k-th contribution, that contribution), as
+    index arrays: replaying step 0, 1, 2, ... folds every entry in its own order."""
+    import itertools
+    n = len(lists)
+    lens = np.fromiter((len(c) for c in lists), dtype=np.int64, count=n)
+    total = int(lens.sum())
+    if total == 0:
+        return []
+    owner = np.repeat(np.arange(n, dtype=np.int64), lens)
+    start = np.cumsum(lens) - lens
+    pos = np.arange(total, dtype=np.int64) - np.repeat(start, lens)
+    what = np.fromiter(itertools.chain.from_iterable(lists), dtype=np.int64, count=total)
+    order = np.argsort(pos, kind="stable")                     # (stable: entries stay in ascending order inside a step)
+    cuts = np.cumsum(np.bincount(pos))
+    steps, lo = [], 0
+    for hi in cuts:
+        sel = order[lo:hi]
+        steps.append((owner[sel], what[sel]))
+        lo = int(hi)
+    return steps
+
+
 def _replay_probabilities(st: dict, ops) -> np.ndarray:
     """Probabilities of the cached structure's symptoms for another set of noise arguments: the k-th contribution of every symptom
     is folded in at step k, i.e. in the order the full pass folds them."""
@@ -188,18 +211,21 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
         dem.structure_key = skey
         return dem
     _STRUCT_STATS["misses"] += 1
-    # symptom bitmask layout: bit d for detector d, bit num_det + o for observable o
-    meas_sens = [0] * num_meas            # which detectors/observables include measurement k
+    # A symptom is the frozenset of the detectors (d) and observables (num_det + o) an error flips; XOR is the symmetric difference.
+    # (Sets of a handful of integers hash and combine in ~100 ns; the 10^4-bit integer masks of rounds 1-3 cost a microsecond per
+    # dictionary access on the QLP circuit: 10.4 -> 4-6 s there, the same output on every fixture; small circuits are unchanged.)
+    empty = frozenset()
+    meas_sens = [empty] * num_meas        # which detectors/observables include measurement k
     nq = 1 + max((max(op.targets) for op in ops if op.name not in ("DETECTOR", "OBSERVABLE_INCLUDE")
                   and op.targets), default=0)
-    xs = [0] * nq                          # flipped by an X error on q inserted *here*
-    zs = [0] * nq
-    probs: Dict[int, float] = {}
-    contrib: Dict[int, List[int]] = {}     # symptom -> indices of the noise instructions folded into it, in order
+    xs = [empty] * nq                      # flipped by an X error on q inserted *here*
+    zs = [empty] * nq
+    probs: Dict[frozenset, float] = {}
+    contrib: Dict[frozenset, List[int]] = {}     # symptom -> indices of the noise instructions folded into it, in order
     cur_op = 0
 
-    def add(sym: int, q: float):
-        if sym == 0 or q == 0.0:
+    def add(sym, q: float):
+        if not sym or q == 0.0:
             return
         p = probs.get(sym)
         if p is None:
@@ -215,39 +241,39 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
         name = op.name
         t = op.targets
         if name == "DETECTOR":
-            bit = 1 << int(op.arg)
+            bit = frozenset((int(op.arg),))
             for k in t:
-                meas_sens[k] ^= bit
+                meas_sens[k] = meas_sens[k] ^ bit
         elif name == "OBSERVABLE_INCLUDE":
-            bit = 1 << (num_det + int(op.arg))
+            bit = frozenset((num_det + int(op.arg),))
             for k in t:
-                meas_sens[k] ^= bit
+                meas_sens[k] = meas_sens[k] ^ bit
         elif name == "CX":
             # forward: X_c -> X_c X_t ; Z_t -> Z_c Z_t  (pairs are applied in order; undo in reverse)
             for i in range(len(t) - 2, -1, -2):
                 c, tg = t[i], t[i + 1]
-                xs[c] ^= xs[tg]
-                zs[tg] ^= zs[c]
+                xs[c] = xs[c] ^ xs[tg]
+                zs[tg] = zs[tg] ^ zs[c]
         elif name == "H":
             for q in t:
                 xs[q], zs[q] = zs[q], xs[q]
         elif name == "M":
             for q in reversed(t):
                 m -= 1
-                xs[q] ^= meas_sens[m]
+                xs[q] = xs[q] ^ meas_sens[m]
         elif name == "MX":
             for q in reversed(t):
                 m -= 1
-                zs[q] ^= meas_sens[m]
+                zs[q] = zs[q] ^ meas_sens[m]
         elif name == "MR":
             for q in reversed(t):
                 m -= 1
                 xs[q] = meas_sens[m]       # reset erases later sensitivity, then the Z-measurement
-                zs[q] = 0
+                zs[q] = empty
         elif name in ("R", "RX"):
             for q in t:
-                xs[q] = 0
-                zs[q] = 0
+                xs[q] = empty
+                zs[q] = empty
         elif name == "X_ERROR":
             for q in t:
                 add(xs[q], op.arg)
@@ -265,8 +291,8 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
             q2 = _mechanism_probability(op)
             for i in range(0, len(t), 2):
                 a, b = t[i], t[i + 1]
-                pa = (0, xs[a], xs[a] ^ zs[a], zs[a])
-                pb = (0, xs[b], xs[b] ^ zs[b], zs[b])
+                pa = (empty, xs[a], xs[a] ^ zs[a], zs[a])
+                pb = (empty, xs[b], xs[b] ^ zs[b], zs[b])
                 for ia in range(4):
                     for ib in range(4):
                         if ia or ib:
@@ -276,25 +302,17 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
     if m != 0:
         raise AssertionError("measurement bookkeeping is inconsistent")
 
-    det_mask = (1 << num_det) - 1
     rows = []
     for sym, p in probs.items():
-        dets = tuple(_bits(sym & det_mask))
-        obs = tuple(_bits(sym >> num_det))
+        dets = tuple(sorted(x for x in sym if x < num_det))
+        obs = tuple(sorted(x - num_det for x in sym if x >= num_det))
         rows.append((dets, obs, p, sym))
     # Stim orders DemTargets with detectors before observables; compare target lists lexicographically
     rows.sort(key=lambda r: tuple(r[0]) + tuple(num_det + o for o in r[1]))
     errors = [(p, d, o) for (d, o, p, _) in rows]
     dem = DetectorErrorModel(errors, num_det, num_obs)
     if skey is not None:
-        # steps[k] = (symptoms that have a k-th contribution, the noise instruction of that contribution), as index arrays
-        lists = [contrib[r[3]] for r in rows]
-        depth = max((len(c) for c in lists), default=0)
-        steps = []
-        for k in range(depth):
-            sym_idx = np.fromiter((i for i, c in enumerate(lists) if len(c) > k), dtype=np.int64)
-            op_idx = np.fromiter((c[k] for c in lists if len(c) > k), dtype=np.int64, count=sym_idx.size)
-            steps.append((sym_idx, op_idx))
+        steps = fold_steps([contrib[r[3]] for r in rows])
         _STRUCT_CACHE[skey] = {"rows": [(r[0], r[1]) for r in rows], "nsym": len(rows), "steps": steps,
                                "noise_ops": [i for i, op in enumerate(ops) if op.name in _NOISE and op.arg > 0.0]}
         while len(_STRUCT_CACHE) > cap:
