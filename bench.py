@@ -68,6 +68,7 @@ def cpu_baseline(args, circ, hz, R, W, F, batch, plan, gpu_value):
              "row0": F * k * hz.shape[0]} for k in range(len(checks))]
     _CPU.update(wins=wins, nz=hz.shape[0], det=det_h,
                 prm=orc.make_params(args.bp_method, args.schedule, args.max_iter, args.osd_method, args.osd_order, 1.0, orc.FORM_LDPC_F64))
+    orc.use_native(True)      # this host's own -O3 -march=native build of the port (oracle/_native/, never shipped)
     orc.lib()
     _, ref1, cpu1_s = _cpu_worker((0, ns1))
     res = {}
@@ -97,7 +98,9 @@ def cpu_baseline(args, circ, hz, R, W, F, batch, plan, gpu_value):
               "update order, exact LLRs)")
     res["cpu_baseline"] = {
         "value": len(ref) / cpua_s, "unit": "shots/s", "cores": ncpu, "kind": "port",
-        "sample": sample % len(ref) + ", %d processes over shot slices" % ncpu,
+        "sample": sample % len(ref) + ", %d processes over shot slices" % ncpu, "build": orc.build_info()["flags"],
+        "label": "own C port of ldpc's published algorithm (ldpc itself is absent here and on the GPU box): a readable restatement, "
+                 "not a tuned CPU decoder -- any GPU/CPU ratio quoted from it carries that caveat",
         "ler": cpu_fail / len(ref), "gpu_ler_same_sample": gpu_fail / len(ref),
         "shots_with_identical_prediction": float((ref == gpu_pred).all(axis=1).mean()), "paired": paired,
         "speedup_vs_all_cores": gpu_value / (len(ref) / cpua_s)}
@@ -192,11 +195,13 @@ def main():
     ap.add_argument("--code", default="bb144", choices=["bb144", "bb72", "hgp225", "qlp1020"],
                     help="bb144 = the headline (BASELINE configs[2]); bb72 = configs[1]; hgp225 = configs[0] (their circuits at their p)")
     ap.add_argument("--window", type=int, nargs=2, default=None, metavar=("W", "F"))
-    ap.add_argument("--cpu-shots", type=int, default=2000, help="bounded CPU-baseline sample (rank 0, N=1 only)")
+    ap.add_argument("--cpu-shots", type=int, default=6500, help="bounded CPU-baseline sample PER CORE (rank 0, N=1 only): 16 cores x 6500 = 104 000 paired shots, ~20 s")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-api", action="store_true", help="skip the drop-in call measurement (through_api)")
     ap.add_argument("--api-shots", type=int, default=1000000, help="shots of the through_api call (host bool array; capped at 1 GiB)")
     ap.add_argument("--dry-run-backend", default=None, help=argparse.SUPPRESS)   # tests: rank plumbing + collectives on CPU (gloo), no decoding
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the `other_configs` array (the other BASELINE configs and window shapes, each timed for two short steps)")
     args = ap.parse_args()
 
     from quits_amd import parallel
@@ -221,6 +226,78 @@ def main():
     torch.cuda.set_device(local_rank)
     dist = parallel.init_distributed("nccl")      # "nccl" is RCCL on ROCm; None for a single process
 
+    out = run(args, rank, world, dist, full=True)
+    if rank == 0 and world == 1 and not args.no_other_configs and args.code == "bb144" and args.window is None \
+            and args.osd_method == "osd_0" and not (args.bp_method != "minimum_sum" or args.schedule != "parallel"):
+        out["other_configs"] = other_configs(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+# The other BASELINE.json configurations and the window shapes / options the reference's users run, each timed by the same code as
+# the headline for a few short steps ("make every BASELINE config driver-timed").  N = 1 only; the headline line is
+# measured first and is not affected.
+OTHER_CONFIGS = [
+    # name, overrides
+    ("configs[1] bb72 single window", dict(code="bb72", shots=262144, steps=3, warmup=1)),
+    ("configs[1] bb72 W=3 F=1", dict(code="bb72", window=[3, 1], shots=262144, steps=3, warmup=1)),
+    ("configs[2] bb144 W=3 F=1", dict(window=[3, 1], shots=262144, steps=3, warmup=1)),
+    ("configs[2] bb144 W=5 F=3", dict(window=[5, 3], shots=262144, steps=3, warmup=1)),
+    ("configs[3] bb144 p=1e-3", dict(p=0.001, shots=262144, steps=3, warmup=1)),
+    ("configs[3] bb144 p=6e-3", dict(p=0.006, shots=262144, steps=3, warmup=1)),
+    ("configs[2] bb144 headline window, osd_cs(1)", dict(osd_method="osd_cs", osd_order=1, shots=131072, steps=2, warmup=1)),
+    ("configs[2] bb144 headline window, bp-lsd lsd_cs(1)", dict(osd_method="lsd_cs", osd_order=1, shots=262144, steps=2, warmup=1)),
+    ("configs[4] qlp1020 W=3 F=1 p=1e-3 osd_0", dict(code="qlp1020", window=[3, 1], p_override=0.001, shots=8192, steps=2, warmup=1)),
+    ("configs[4] qlp1020 W=3 F=1 p=1e-3 osd_cs(1)", dict(code="qlp1020", window=[3, 1], p_override=0.001, osd_method="osd_cs", osd_order=1,
+                                                        shots=8192, steps=2, warmup=1)),
+    ("configs[4] qlp1020 W=3 F=1 p=3e-3 (fixture p) osd_0", dict(code="qlp1020", window=[3, 1], shots=8192, steps=2, warmup=1)),
+    ("reference settings (bposd.py:54 defaults + max_iter=10, osd_order=1) bb144 W=5 F=3",
+     dict(window=[5, 3], bp_method="product_sum", schedule="serial", max_iter=10, osd_method="osd_cs", osd_order=1,
+          shots=163840, steps=2, warmup=1)),
+    ("configs[0] hgp225 R=3 p=0.01 W=3 F=1, reference settings", dict(code="hgp225", window=[3, 1], bp_method="product_sum", schedule="serial",
+                                                                     max_iter=10, osd_method="osd_cs", osd_order=1, shots=65536, steps=2, warmup=1)),
+]
+
+
+def other_configs(args):
+    import copy
+    import gc
+    res = []
+    only = os.environ.get("QD_BENCH_OTHER_ONLY")            # substring filter (development)
+    for name, ov in OTHER_CONFIGS:
+        if only and only not in name:
+            continue
+        a = copy.copy(args)
+        for k, v in ov.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            o = run(a, 0, 1, None, full=False)
+            rf = o["roofline"]
+            rec = {"name": name, "workload": o["config"]["workload"], "value": o["value"], "unit": "shots/s", "ms_per_step": o["ms_per_step"],
+                   "shots_per_step": a.shots, "steps": a.steps, "logical_error_rate": o["logical_error_rate"], "ler_sigma": o["ler_sigma"],
+                   "bp_converged_frac": o["bp_converged_frac"], "mean_bp_iters": o["mean_bp_iters"],
+                   "bp_kernel": rf.get("kernel"), "bp_ms_per_launch": rf.get("avg_launch_ms"),
+                   "post_ms_per_launch": rf.get("osd_kernel_ms_per_launch"),
+                   "roofline": {"bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"]},
+                   "wall_s": None}
+            if "kernel_model" in rf:
+                rec["roofline"]["kernel_model_frac"] = rf["kernel_model"]["frac"]
+            if "osd" in rf:
+                rec["post_kernel"] = rf["osd"]["kernel"]
+                rec["post_us_per_shot"] = rf["osd"]["us_per_shot"]
+        except Exception as exc:           # one configuration failing must not take the headline line with it
+            rec = {"name": name, "error": "%s: %s" % (type(exc).__name__, exc)}
+        rec["wall_s"] = time.perf_counter() - t0
+        res.append(rec)
+        gc.collect()
+        torch.cuda.empty_cache()
+    return res
+
+
+def run(args, rank, world, dist, full=True):
     import helpers
     from quits_amd.decoder.base import detector_error_model_to_matrix
     from quits_amd.decoder.device import DemSampler, count_mismatch
@@ -450,8 +527,9 @@ def main():
             # the same instructions priced by class: two-operand add/sub/logic/shift/fma issue in 2 clk per wavefront per SIMD,
             # compares / cndmask / min / max / med3 / three-operand logic / 64-bit shifts in 4 (profiles/r01f_valu_issue_rates.txt)
             "frac_priced_by_class": issue_clk / (bp_s * NUM_CU * 4 * CLOCK_HZ) if bp_s > 0 else 0.0,
-            # the same fraction from the hardware counters of the committed PMC pass (all VALU instructions, overhead included)
-            "frac_from_sq_counters": (sq_counters or {}).get("frac_of_2_per_cu_clk"), "sq_counters": sq_counters,
+            # the same fraction from the hardware counters of the COMMITTED PMC pass (profiles/pmc_traffic.json <- tools/profile_bench.sh; all
+            # VALU instructions, overhead included) -- read from that file, NOT measured in this run (rocprofv3 cannot run inside this process)
+            "frac_from_committed_profile_sq_counters": (sq_counters or {}).get("frac_of_2_per_cu_clk"), "sq_counters_committed_profile": sq_counters,
             "lds": {"achieved": lds_bytes / bp_s / 1e9 if bp_s > 0 else 0.0, "peak": NUM_CU * 256 * CLOCK_HZ / 1e9, "unit": "GB/s",
                     "frac_of_conflict_free_cycles": lds_clk / (bp_s * NUM_CU * CLOCK_HZ) if bp_s > 0 else 0.0,
                     "note": ("4 B gathered and 4 B added (ds_add_u32) per edge and iteration; LDS-array cycles at ds_read_b32 2 clk "
@@ -538,14 +616,12 @@ def main():
         "roofline": roofline,
     }
 
-    if rank == 0 and world == 1 and not args.no_api and args.osd_method.startswith("osd"):
+    if full and rank == 0 and world == 1 and not args.no_api and args.osd_method.startswith("osd"):
         out["through_api"] = through_api(args, circ, hz, lz, W, F, sampler, value)
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if full and rank == 0 and world == 1 and not args.no_cpu:
         out.update(cpu_baseline(args, circ, hz, R, W, F, batches[args.warmup], plan, value))
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    plan.release_workspaces()
+    return out
 
 
 if __name__ == "__main__":

@@ -35,10 +35,46 @@ def build(force: bool = False) -> str:
     return so
 
 
+_NATIVE = {"want": False, "used": False, "flags": "-O3"}
+
+
+def use_native(on: bool = True) -> None:
+    """bench.py's cpu_baseline leg only (the CPU denominator is built `-O3 -march=native`): compile the same sources
+    for THIS host's CPU into oracle/_native/ (never shipped: a -march=native object built in the build container could die with
+    SIGILL on the GPU box's host) and load that.  Must be called before the first lib().  -ffp-contract=off stays, so the results
+    are the portable build's bit for bit (tests/test_oracle.py::test_native_build_matches_portable)."""
+    _NATIVE["want"] = bool(on)
+
+
+def build_native() -> str:
+    out_dir = os.path.join(_HERE, "_native")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "liboracle_native.so")
+    srcs = [os.path.join(_HERE, f) for f in ("qd_oracle.c", "bp_core.inc", "oq_math.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in srcs):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-fno-fast-math", "-ffp-contract=off", "-shared",
+                               "-o", so, os.path.join(_HERE, "qd_oracle.c"), "-lm"])
+    return so
+
+
+def build_info() -> dict:
+    return {"native": _NATIVE["used"], "flags": _NATIVE["flags"]}
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
+        path = None
+        if _NATIVE["want"]:
+            try:
+                path = build_native()
+                _NATIVE["used"], _NATIVE["flags"] = True, "-O3 -march=native -ffp-contract=off"
+            except (OSError, subprocess.CalledProcessError):
+                path = None
+        if path is None:
+            path = build()
+            _NATIVE["flags"] = "-O3 -ffp-contract=off (portable build)"
+        L = C.CDLL(path)
         i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
         u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
         f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")

@@ -50,6 +50,24 @@
                                  * product-sum product is taken as prefix * suffix there (bp_core.inc, bp_serial_ps_presuf) */
 #define OQ_MAX_COL_DEG 64
 
+/* Workspace of the BP forms: a few per-thread buffers that grow to the largest request and are kept between calls, so that the
+ * CPU baseline bench.py times does not pay a malloc/free pair per array and decode (VERDICT r4 #8a; SURVEY.md 8d "workspace once
+ * per worker": bench.py's workers are processes, each owns its slots).  `zero` clears the requested bytes (calloc's contract). */
+#define OQ_WS_SLOTS 8
+static __thread void *oq_ws_buf[OQ_WS_SLOTS];
+static __thread size_t oq_ws_cap[OQ_WS_SLOTS];
+static void *oq_ws(int slot, size_t bytes, int zero)
+{
+    if (bytes == 0) bytes = 1;
+    if (oq_ws_cap[slot] < bytes) {
+        free(oq_ws_buf[slot]);
+        oq_ws_buf[slot] = malloc(bytes);
+        oq_ws_cap[slot] = oq_ws_buf[slot] ? bytes : 0;
+    }
+    if (zero && oq_ws_buf[slot]) memset(oq_ws_buf[slot], 0, bytes);
+    return oq_ws_buf[slot];
+}
+
 typedef struct {
     int bp_method;           /* OQ_PRODUCT_SUM | OQ_MINIMUM_SUM                                   */
     int schedule;            /* OQ_PARALLEL | OQ_SERIAL                                           */

@@ -321,9 +321,11 @@ __global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrA
             if (r < m && !((my_piv >> i) & 1u)) resid |= (my_sp >> i) & 1u;
             if (draining && ((my_bp >> i) & 1u) && (int)(ppos[rowpiv[r]] & 63u) >= cmaxp1) ++over;    // pivots beyond the sequential stop
         }
-        const uint32_t tot = qd_block_sum<T>(resid | (over << 8), sumbuf, sphase);
-        const int inconsistent = (tot & 0xFFu) != 0u;
-        const int npiv_rep = npiv - (int)(tot >> 8);
+        // `over` totals at most 64 (one batch), the residual flags at most T <= 1024: the flags go in the high half so that neither
+        // field can carry into -- or wrap inside -- the other (256 residual rows used to read as "consistent")
+        const uint32_t tot = qd_block_sum<T>(over | (resid << 16), sumbuf, sphase);
+        const int inconsistent = (tot >> 16) != 0u;
+        const int npiv_rep = npiv - (int)(tot & 0xFFFFu);
         if (inconsistent) {
             // defined by the lowest-row rule (oracle): the mirrored kernel decodes the shot again
             if (tid == 0) a.hard_list[atomicAdd(a.hard_count, 1)] = slot;

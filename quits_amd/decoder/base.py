@@ -63,8 +63,10 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
     if skey is not None and skey in _MATRIX_CACHE:
         # same circuit structure, other probabilities (quits_amd/dem.py): the matrices are the cached ones, the priors are folded again in
         # the order the loop below folds them -- the same floating-point numbers
-        check, obs, steps = _MATRIX_CACHE[skey]
+        check, obs, steps, no_det = _MATRIX_CACHE[skey]
         _MATRIX_CACHE.move_to_end(skey)
+        for inst in no_det:                 # the reference prints an error without detectors on every call (base.py:114-115)
+            print(inst)
         p_err = np.fromiter((e[0] for e in dem.errors), dtype=np.float64, count=len(dem.errors))
         priors = np.zeros(check.shape[1], dtype=np.float64)
         for k, (col_idx, err_idx) in enumerate(steps):
@@ -74,13 +76,14 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
             else:
                 q = priors[col_idx]
                 priors[col_idx] = q * (1 - p) + p * (1 - q)
-        return check, obs, priors
+        return check.copy(), obs.copy(), priors      # copies: this is a public function, callers may edit the result in place
     col_of: dict = {}
     det_sets: List[frozenset] = []
     obs_sets: List[frozenset] = []
     priors: List[float] = []
     members: List[List[int]] = []           # column -> the error instructions folded into it, in order
     n_err = 0
+    no_det_insts: List[str] = []
     for inst in dem.flattened():
         kind = inst.type
         if kind == "error":
@@ -93,6 +96,7 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
                     obs.append(t.val)
             if not dets:
                 print(inst)
+                no_det_insts.append(str(inst))
             key = frozenset(dets)
             j = col_of.get(key)
             if j is None:
@@ -113,11 +117,13 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
     check = _csc_from_columns(det_sets, dem.num_detectors)
     obs = _csc_from_columns(obs_sets, dem.num_observables)
     if skey is not None and n_err == len(getattr(dem, "errors", ())):
-        from ..dem import fold_steps
-        steps = fold_steps(members)
-        _MATRIX_CACHE[skey] = (check, obs, steps)
-        while len(_MATRIX_CACHE) > 4:
-            _MATRIX_CACHE.popitem(last=False)
+        from ..dem import fold_steps, _struct_cap
+        cap = _struct_cap()                  # QD_DEM_STRUCT_CACHE sizes (and switches off) both structure caches
+        if cap > 0:
+            steps = fold_steps(members)
+            _MATRIX_CACHE[skey] = (check.copy(), obs.copy(), steps, tuple(no_det_insts))
+            while len(_MATRIX_CACHE) > cap:
+                _MATRIX_CACHE.popitem(last=False)
     return check, obs, np.array(priors)
 
 

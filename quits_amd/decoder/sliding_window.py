@@ -34,6 +34,22 @@ def _env_int(name, default):
         return default
 
 
+def _env_flag(name):
+    """True for any non-empty value other than '0' / 'false' / 'no' / 'off' (so QD_NO_PIPELINE=true still means what it says)."""
+    import os
+    v = os.environ.get(name, "").strip().lower()
+    return v not in ("", "0", "false", "no", "off")
+
+
+def _current_device():
+    """Index of the current CUDA device (-1 without a GPU): plans, graphs, decoders and workspaces are bound to it."""
+    try:
+        import torch
+        return int(torch.cuda.current_device()) if torch.cuda.is_available() else -1
+    except Exception:            # pragma: no cover
+        return -1
+
+
 def _progress(it, on):
     if on:
         try:
@@ -127,10 +143,13 @@ class DeviceWindowPlan:
         # QD_NO_PIPELINE=1 or plan.pipeline = False keeps everything on the caller's stream.  Not the default where BP runs in the
         # per-edge kernel: HBM-bound, it loses more to the co-running post-processor than the overlap returns (W = 5 / F = 3
         # windows with the reference's settings 219 k -> 209 k shots/s, profiles/r03x_pipelined_driver_multiwindow_ab.txt)
-        self.pipeline = _env_int("QD_NO_PIPELINE", 0) == 0 and not any(d.info()["edge_kernel"] for d in decs)
+        self.pipeline = not _env_flag("QD_NO_PIPELINE") and not any(d.info()["edge_kernel"] for d in decs)
         self._side = None
         self._stage = None
-        self.host_piece = int(os.environ.get("QD_HOST_PIECE_SHOTS", str(4 * self.chunk)))   # shots per staged piece (>= 2 chunks: the pipelined driver)
+        self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", 4 * self.chunk))   # shots per staged piece (>= 2 chunks: the pipelined driver)
+        self.device = _current_device()      # graphs, decoders and workspaces were created on this device
+        import threading
+        self._lock = threading.Lock()        # one decode_host at a time per plan: staging buffers, side streams and workspaces are per plan
 
     def release_workspaces(self):
         """Hand the decoders' device workspaces and the staging buffers back (the plan itself -- graphs, decoders, matrices --
@@ -190,7 +209,18 @@ class DeviceWindowPlan:
         piece run beside the decoding of the previous one, and the predictions come back through a pinned buffer.  Tensors that
         already live on the GPU skip the staging."""
         import torch
+        if self.device >= 0 and torch.cuda.current_device() != self.device:
+            raise RuntimeError("this plan was built on cuda:%d but the current device is cuda:%d (plans are per device; the plan "
+                               "cache keys on the current device)" % (self.device, torch.cuda.current_device()))
+        with self._lock:
+            return self._decode_host_locked(zcheck_samples)
+
+    def _decode_host_locked(self, zcheck_samples):
+        import torch
+        dev = torch.device("cuda", self.device) if self.device >= 0 else torch.device("cuda")
         if isinstance(zcheck_samples, torch.Tensor) and zcheck_samples.is_cuda:
+            if zcheck_samples.device != dev:
+                raise RuntimeError("samples live on %s, the plan on %s" % (zcheck_samples.device, dev))
             return self.decode(_to_device_samples(zcheck_samples)).cpu().numpy().astype(np.int64)
         a = zcheck_samples.cpu().numpy() if isinstance(zcheck_samples, torch.Tensor) else np.asarray(zcheck_samples)
         if a.ndim != 2:
@@ -207,8 +237,8 @@ class DeviceWindowPlan:
             rows = min(piece, N)
             st = {"ndet": ndet, "piece": rows,
                   "pin": [torch.empty((rows, ndet), dtype=torch.uint8, pin_memory=True) for _ in range(2)],
-                  "dev": [torch.empty((rows, ndet), dtype=torch.uint8, device="cuda") for _ in range(2)],
-                  "copy": torch.cuda.Stream(), "out": None}
+                  "dev": [torch.empty((rows, ndet), dtype=torch.uint8, device=dev) for _ in range(2)],
+                  "copy": torch.cuda.Stream(device=dev), "out": None}
             self._stage = st
         if st["out"] is None or st["out"].shape[0] < N:
             st["out"] = torch.empty((N, self.nobs), dtype=torch.uint8, pin_memory=True)
@@ -361,9 +391,28 @@ def _kwargs_for_device(d, cls):
 # cell 5 loops over p), and every call used to rebuild everything: DEM extraction + spacetime() + one qd_graph_create per window
 # (0.4 s for the headline window, 15 s for the QLP [[1020,136]] circuit).  Plans are kept, least recently used first out, keyed on
 # everything they depend on: the circuit (hash of its text), hz, W, F, the number of rounds, both plug-in classes and both option
-# dicts.  QD_PLAN_CACHE = number of plans kept (default 8, 0 = off).
-_PLAN_CACHE = None
-_PLAN_STATS = {"hits": 0, "misses": 0}
+# dicts -- and the CUDA device that is current, because graphs, decoders and workspaces are bound to the device they were built on.
+# QD_PLAN_CACHE = number of plans kept (default 8, 0 = off).  The cache is PER THREAD: a plan carries mutable state
+# (staging buffers, side streams, decoder workspaces), so two threads never share one; within a thread the plan's own lock orders
+# re-entrant use.  Releasing the idle plans' workspaces therefore only ever touches plans of the calling thread.
+import threading as _threading
+
+_TLS = _threading.local()
+
+
+def _tls_cache(create=False):
+    c = getattr(_TLS, "cache", None)
+    if c is None and create:
+        from collections import OrderedDict
+        c = _TLS.cache = OrderedDict()
+    return c
+
+
+def _tls_stats():
+    st = getattr(_TLS, "stats", None)
+    if st is None:
+        st = _TLS.stats = {"hits": 0, "misses": 0}
+    return st
 
 
 def _freeze(v):
@@ -404,7 +453,7 @@ def _matrix_fingerprint(mat):
 def plan_key(kind, circuit, hz, lz, W, F, num_rounds, decoder1, decoder2, dict1, dict2):
     """Everything a DeviceWindowPlan depends on.  kind: 'circuit' (circuit is the circuit) or 'phenom' (circuit is None; lz enters
     because the phenomenological commit matrices are built from it)."""
-    return (kind, None if circuit is None else _circuit_fingerprint(circuit), _matrix_fingerprint(hz),
+    return (kind, ("device", _current_device()), None if circuit is None else _circuit_fingerprint(circuit), _matrix_fingerprint(hz),
             None if lz is None else _matrix_fingerprint(lz), int(W), int(F), int(num_rounds),
             getattr(decoder1, "__qualname__", repr(decoder1)), getattr(decoder2, "__qualname__", repr(decoder2)),
             _freeze(dict1), _freeze(dict2))
@@ -419,31 +468,29 @@ def _plan_cache_size():
 
 
 def cached_plan(key, build):
-    """The plan stored under `key`, built with build() on a miss."""
-    global _PLAN_CACHE
-    from collections import OrderedDict
+    """The plan stored under `key` in the calling thread's cache, built with build() on a miss."""
     cap = _plan_cache_size()
+    stats = _tls_stats()
     if cap == 0:
-        _PLAN_STATS["misses"] += 1
+        stats["misses"] += 1
         return build()
-    if _PLAN_CACHE is None:
-        _PLAN_CACHE = OrderedDict()
-    plan = _PLAN_CACHE.get(key)
+    cache = _tls_cache(create=True)
+    plan = cache.get(key)
     # only the plan in use keeps device workspaces (the per-edge BP kernel sizes its message planes for tens of GB): the
     # others keep their graphs and decoders and size their workspaces again when they are used next
-    for k, other in _PLAN_CACHE.items():
+    for k, other in cache.items():
         if k != key and hasattr(other, "release_workspaces") and getattr(other, "_ws_live", True):
             other.release_workspaces()
             other._ws_live = False
     if plan is not None:
-        _PLAN_CACHE.move_to_end(key)
-        _PLAN_STATS["hits"] += 1
+        cache.move_to_end(key)
+        stats["hits"] += 1
     else:
-        _PLAN_STATS["misses"] += 1
+        stats["misses"] += 1
         plan = build()
-        _PLAN_CACHE[key] = plan
-        while len(_PLAN_CACHE) > cap:
-            _PLAN_CACHE.popitem(last=False)
+        cache[key] = plan
+        while len(cache) > cap:
+            cache.popitem(last=False)
     try:
         plan._ws_live = True
     except AttributeError:
@@ -452,14 +499,13 @@ def cached_plan(key, build):
 
 
 def plan_cache_info():
-    return {"size": 0 if _PLAN_CACHE is None else len(_PLAN_CACHE), "capacity": _plan_cache_size(), **_PLAN_STATS}
+    c = _tls_cache()
+    return {"size": 0 if c is None else len(c), "capacity": _plan_cache_size(), **_tls_stats()}
 
 
 def plan_cache_clear():
-    global _PLAN_CACHE
-    _PLAN_CACHE = None
-    _PLAN_STATS["hits"] = 0
-    _PLAN_STATS["misses"] = 0
+    _TLS.cache = None
+    _TLS.stats = {"hits": 0, "misses": 0}
 
 
 def build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2, decoder1=None, decoder2=None):

@@ -135,7 +135,9 @@ def _structure_key(ops, num_meas, num_det, num_obs) -> str:
     for op in ops:
         h.update(op.name.encode())
         if op.name in _NOISE:
-            h.update(b"+" if op.arg > 0.0 else b"0")
+            # keyed on the DERIVED probability: the full pass drops a mechanism whose probability is exactly 0.0, which for the
+            # depolarising channels already happens at p ~ 1e-16 (the square / eighth root underflows), not only at p == 0
+            h.update(b"+" if _mechanism_probability(op) > 0.0 else b"0")
         else:
             h.update(repr(op.arg).encode())
         h.update(np.asarray(op.targets, dtype=np.int64).tobytes())

@@ -193,3 +193,43 @@ def test_osd_sr_kernel_instantiations_use_no_scratch(tmp_path):
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
     kern = [(n, sc) for n, sc in zip(names, scratch) if "qd_osd0_sr_kernel" in n]
     assert len(kern) >= 8 and all(sc == 0 for _, sc in kern), kern
+
+
+def test_plan_cache_is_per_thread_and_keyed_on_the_device(monkeypatch):
+    """a cached plan carries mutable state (staging buffers, side streams, decoder workspaces) and is bound to the
+    device it was built on -- so the key holds the current device and every thread has its own cache."""
+    import threading
+    from quits_amd.decoder import BpOsdDecoder
+    from quits_amd.decoder import sliding_window as sw
+    hz = np.eye(3, dtype=int)
+    d = {"bp_method": "minimum_sum", "max_iter": 5}
+    k0 = sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, d)
+    assert ("device", sw._current_device()) in k0
+    monkeypatch.setattr(sw, "_current_device", lambda: 5)
+    k5 = sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, d)
+    assert k5 != k0 and ("device", 5) in k5
+    sw.plan_cache_clear()
+    sw.cached_plan("x", lambda: "main-thread plan")
+    seen = {}
+
+    def other():
+        seen["info_before"] = sw.plan_cache_info()
+        seen["plan"] = sw.cached_plan("x", lambda: "worker plan")
+        seen["info_after"] = sw.plan_cache_info()
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert seen["info_before"]["size"] == 0 and seen["plan"] == "worker plan" and seen["info_after"]["misses"] == 1
+    assert sw.cached_plan("x", lambda: "rebuilt") == "main-thread plan"
+    sw.plan_cache_clear()
+
+
+def test_env_switches_parse_loosely(monkeypatch):
+    """QD_NO_PIPELINE=true / yes still switch the pipelined driver off; a malformed QD_HOST_PIECE_SHOTS falls back."""
+    from quits_amd.decoder import sliding_window as sw
+    for v, want in (("1", True), ("true", True), ("yes", True), ("0", False), ("", False), ("off", False)):
+        monkeypatch.setenv("QD_NO_PIPELINE", v)
+        assert sw._env_flag("QD_NO_PIPELINE") is want, v
+    monkeypatch.setenv("QD_HOST_PIECE_SHOTS", "a lot")
+    assert sw._env_int("QD_HOST_PIECE_SHOTS", 123) == 123

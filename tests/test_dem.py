@@ -268,3 +268,41 @@ def test_structure_cache_replays_the_same_numbers(monkeypatch, name, p_from, p_t
         assert z.structure_key != first.structure_key
     dem.dem_struct_cache_clear()
     base._MATRIX_CACHE.clear()
+
+
+def test_structure_cache_keys_on_the_derived_probability_and_hands_out_copies(monkeypatch):
+    """(1) a depolarising argument so small that the derived mechanism probability underflows to exactly 0.0 drops the
+    mechanisms in the full pass, so such a circuit must not share a cached structure with the same circuit at an ordinary rate (in
+    either direction); (2) detector_error_model_to_matrix is a public function: what it returns on a cache hit must be the caller's
+    own copy; (3) QD_DEM_STRUCT_CACHE=0 switches the matrix cache off as well."""
+    from quits_amd import dem
+    from quits_amd.decoder import base
+    name = "bb72_custom_r6_p0.003"
+    text = helpers.circuit_text(name)
+    tiny = text.replace("DEPOLARIZE1(0.0030000000)", "DEPOLARIZE1(1e-17)").replace("DEPOLARIZE2(0.0030000000)", "DEPOLARIZE2(1e-17)")
+    assert tiny != text
+    monkeypatch.setenv("QD_DEM_STRUCT_CACHE", "0")
+    full_tiny, full_norm = dem.circuit_to_dem(tiny), dem.circuit_to_dem(text)
+    assert len(full_tiny.errors) < len(full_norm.errors)            # the underflowed mechanisms are gone
+    monkeypatch.setenv("QD_DEM_STRUCT_CACHE", "4")
+    for first, second, want in ((tiny, text, full_norm), (text, tiny, full_tiny)):
+        dem.dem_struct_cache_clear()
+        base._MATRIX_CACHE.clear()
+        a = dem.circuit_to_dem(first)
+        b = dem.circuit_to_dem(second)
+        assert a.structure_key != b.structure_key
+        assert b.errors == want.errors
+    # copies on a hit
+    dem.dem_struct_cache_clear()
+    base._MATRIX_CACHE.clear()
+    H0, L0, p0 = base.detector_error_model_to_matrix(dem.Circuit(text))
+    H1, L1, p1 = base.detector_error_model_to_matrix(dem.Circuit(text))
+    assert H1 is not H0 and (H1 != H0).nnz == 0
+    H1.data[:] = 0
+    L1.data[:] = 0
+    H2, L2, p2 = base.detector_error_model_to_matrix(dem.Circuit(text))
+    assert (H2 != H0).nnz == 0 and (L2 != L0).nnz == 0 and np.array_equal(p2, p0)
+    monkeypatch.setenv("QD_DEM_STRUCT_CACHE", "0")
+    base._MATRIX_CACHE.clear()
+    base.detector_error_model_to_matrix(dem.Circuit(text))
+    assert len(base._MATRIX_CACHE) == 0

@@ -389,3 +389,39 @@ def test_higher_order_lsd_small_case_by_brute_force():
     g2 = orc.Graph(H, np.array([0.01, 0.01, 0.2, 0.001, 0.01, 0.01]))
     e2, st2 = g2.lsd(s, llr, "lsd_cs", 1)
     assert e2.tolist() == [0, 0, 1, 0, 0, 0] and st2["replaced"] == 0
+
+
+def test_native_build_matches_portable(tmp_path):
+    """bench.py's cpu_baseline leg times a `-O3 -march=native` build of the port made on the host it runs on (oracle/_native/, never
+    shipped).  With -ffp-contract=off the two builds must agree bit for bit: decode the same shots with both (the native one in a
+    child process, since a process loads one build)."""
+    import subprocess
+    import sys
+    name = "bb72_custom_r6_p0.003"
+    H, L, pri = helpers.dem_matrices(name)
+    rng = np.random.default_rng(5)
+    e = (rng.random((48, H.shape[1])) < pri).astype(np.uint8)
+    synd = np.ascontiguousarray((csr_matrix(H) @ e.T % 2).T.astype(np.uint8))
+    np.save(tmp_path / "synd.npy", synd)
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import helpers, oracle as orc
+native = sys.argv[2] == "1"
+orc.use_native(native)
+H, L, pri = helpers.dem_matrices(%r)
+g = orc.Graph(H, pri)
+out = []
+for bp, sch, osd, order, form in (("minimum_sum", "parallel", "osd_0", 0, orc.FORM_LDPC_F64), ("product_sum", "serial", "osd_cs", 1, orc.FORM_LDPC_F64),
+                                  ("product_sum", "parallel", "osd_0", 0, orc.FORM_LDPC_F32), ("minimum_sum", "serial", "lsd_cs", 1, orc.FORM_LDPC_F32)):
+    dec, st = g.decode_batch(np.load(sys.argv[1]), orc.make_params(bp, sch, 12, osd, order, 1.0, form))
+    out.append(dec)
+assert orc.build_info()["native"] == native, orc.build_info()
+np.save(sys.argv[3], np.stack(out))
+''' % (os.path.dirname(os.path.abspath(orc.__file__)), os.path.dirname(os.path.abspath(helpers.__file__)), name)
+    outs = []
+    for native in ("0", "1"):
+        dst = str(tmp_path / ("out%s.npy" % native))
+        subprocess.check_call([sys.executable, "-c", code, str(tmp_path / "synd.npy"), native, dst])
+        outs.append(np.load(dst))
+    assert np.array_equal(outs[0], outs[1])
