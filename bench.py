@@ -299,6 +299,7 @@ def other_configs(args):
 
 def run(args, rank, world, dist, full=True):
     import helpers
+    from quits_amd import parallel
     from quits_amd.decoder.base import detector_error_model_to_matrix
     from quits_amd.decoder.device import DemSampler, count_mismatch
     from quits_amd.decoder.sliding_window import build_circuit_plan
