@@ -571,7 +571,7 @@ def run(args, rank, world, dist, full=True):
             osd_pm = json.load(open(pmc_path)).get("osd_" + key)
         except Exception:
             pass
-        kern = "qd_osd0_sr_kernel" if (args.osd_method == "osd_0" and os.environ.get("QD_NO_OSD_SR") != "1") else ("qd_osd0_reg_kernel" if args.osd_method == "osd_0" else "qd_osdw_col_kernel")
+        kern = dinfo_post = decs[0].info().get("post_kernel", "?")
         roofline["osd"] = {
             "kernel": kern, "avg_launch_ms": prof["osd_ms"] / max(1, prof["osd_launches"]), "shots_per_launch": n_osd / max(1, prof["osd_launches"]),
             "mean_pivots": mean_piv, "us_per_shot": 1e6 * osd_s / max(1, n_osd),

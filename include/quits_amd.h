@@ -105,6 +105,15 @@ void qd_decoder_destroy(qd_decoder *d);
  * lane for windows of more than 1024 checks or rows of 65..96 faults).
  * No reference counterpart (ldpc computes in double). */
 int qd_decoder_info(const qd_decoder *d, int32_t *info);
+/* Which kernel post-processes the shots BP leaves unconverged (decoder/device.py reports it; bench.py labels its roofline.osd object
+ * with it).  No reference counterpart: ldpc has one OsdDecoder / LsdDecoder. */
+#define QD_POST_NONE 0          /* osd_method = osd_off                                                                          */
+#define QD_POST_OSD0_SR 1       /* OSD-0, many pivots per barrier round: qd_osd0_sr_kernel (osd_sr.hip)                          */
+#define QD_POST_OSD0_REG 2      /* OSD-0, one pivot per round: qd_osd0_reg_kernel (osd_kernels.hip)                              */
+#define QD_POST_OSD_W_OLD 3     /* OSD-CS / OSD-E, rounds 2-4: qd_osdw_col_kernel / the row form (osd_kernels.hip)               */
+#define QD_POST_OSD_CS_PANEL 4  /* OSD-CS / OSD-E, round 5: qd_osdcs_kernel (osd_cs.hip), one panel of 64 sorted columns at a time */
+#define QD_POST_LSD 5           /* BP-LSD: qd_lsd0_kernel (lsd_kernels.hip)                                                      */
+int qd_decoder_postproc_kernel(const qd_decoder *d);
 /* Pre-size the device workspace for batches of up to max_batch shots (otherwise grown on demand, which
  * synchronises). */
 int qd_decoder_reserve(qd_decoder *d, int64_t max_batch);

@@ -41,7 +41,7 @@ _lib = None
 
 EXPORTS = [
     "qd_version", "qd_last_error", "qd_device_count", "qd_graph_create", "qd_graph_destroy", "qd_graph_info",
-    "qd_decoder_create", "qd_decoder_info", "qd_decoder_destroy", "qd_decoder_reserve", "qd_decoder_set_workspace_limit", "qd_decoder_release_workspace", "qd_decode_batch", "qd_decode_stage", "qd_osd0_batch", "qd_decoder_failed_llr",
+    "qd_decoder_create", "qd_decoder_info", "qd_decoder_postproc_kernel", "qd_decoder_destroy", "qd_decoder_reserve", "qd_decoder_set_workspace_limit", "qd_decoder_release_workspace", "qd_decode_batch", "qd_decode_stage", "qd_osd0_batch", "qd_decoder_failed_llr",
     "qd_decoder_set_profiling", "qd_decoder_profile", "qd_decoder_debug_counters", "qd_spmat_create", "qd_spmat_destroy", "qd_gf2_spmv_batch",
     "qd_unpack_bits", "qd_count_mismatch", "qd_sample_dem",
 ]
@@ -74,6 +74,8 @@ def load():
     L.qd_graph_info.argtypes = [vp, vp]
     L.qd_decoder_create.argtypes = [vp, C.POINTER(QdParams), C.POINTER(vp)]
     L.qd_decoder_info.argtypes = [vp, vp]
+    L.qd_decoder_postproc_kernel.argtypes = [vp]
+    L.qd_decoder_postproc_kernel.restype = C.c_int
     L.qd_decoder_destroy.argtypes = [vp]
     L.qd_decoder_destroy.restype = None
     L.qd_decoder_reserve.argtypes = [vp, i64]

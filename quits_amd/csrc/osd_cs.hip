@@ -1,0 +1,667 @@
+// osd_cs.hip -- OSD-CS / OSD-E (ldpc osd.hpp, OsdDecoder::decode with osd_order > 0): the full-rank elimination by column, rebuilt
+// in round 5.  Replaces qd_osdw_col_kernel (osd_kernels.hip) wherever the window fits; same oracle
+// (oracle/qd_oracle.c: osd_w_impl / elim_run), same column order, same pivot rule (first independent column of the order, lowest
+// unpivoted row), hence the same pivots, transformed syndrome, candidate costs and corrections, bit for bit.
+//
+// What changed against qd_osdw_col_kernel, and why:
+//   * The column order is produced ONCE, completely: a sample sort of the (posterior key, fault index) pairs in LDS -- 8 samples per
+//     bucket ranked by counting, one pass that counts, one that scatters into <= 32 buckets, then every wavefront sorts whole buckets
+//     in place with a direction-free bitonic network (no workgroup barrier inside).  The old kernel drew the order in tiers of 1024
+//     by radix selection: three passes over all n posteriors + a 55-stage barrier sort per tier, 13 % of a shot.
+//   * A batch of 64 sorted columns is one PANEL.  The image of a column under the pivots found before the batch is pushed into LDS
+//     by the owners of the Q columns (as before); then ONE wavefront finds the batch's pivots on the panel alone -- liveness of all
+//     64 columns in one sweep, a pivot step = three LDS round trips and no barrier -- and records (pivot row, image) per pivot.
+//     The Q columns in the other wavefronts' registers are brought up to date AFTERWARDS, all pivots of the batch in one go, with the
+//     image of each pivot broadcast through SCALAR registers (one 16-lane LDS read + v_readlane per word instead of a 16-word LDS
+//     read per thread): the old kernel paid two workgroup barriers and 64 KB of LDS reads per pivot.
+//     Three barriers per BATCH (~130 batches per headline shot) instead of two per PIVOT (~1000) plus five per batch.
+//   * The candidate sweep sums the signed pivot weights four rows at a time (a 16-entry table per nibble of rows, built once per
+//     shot) instead of one set bit at a time, and breaks ties on the sorted position instead of re-deriving the key.
+//   * One kernel body, every loop that touches the Q columns unrolled over compile-time bounds: ScratchSize 0 in every instantiation
+//     (tests/test_api.py compiles this file and asserts it).
+#include "osd_shared.h"
+
+#include <cstdlib>
+
+#ifndef QD_CS_NSAMP_PER_BUCKET
+#define QD_CS_NSAMP_PER_BUCKET 8
+#endif
+#define QD_CS_MAX_BUCKETS 32
+
+struct OsdCsArgs {
+    int m, n, n_pad, out_words, upd_rows, ell_log2, rank;
+    int osd_w, osd_order;                 // 1 = combination sweep, 2 = exhaustive
+    // LDS: everything whose size the instantiation fixes sits at compile-time offsets (CsLds below: one scalar register per runtime offset
+    // is what pushed the first build of this kernel into scratch); only the three arrays sized by the window follow at runtime offsets
+    int o_out, o_order, o_sort_aux;       // pivmask at CsLds::o_var, out words, sorted order, splitters / counters of the sort
+    const uint16_t *csc_ell;              // [n][1 << ell_log2] detector indices of a fault, ascending, 0xFFFF beyond its weight
+    const uint32_t *wfix;                 // [n] round(log(1/p_j) * 2^18)
+    const uint32_t *bit_orig;             // [n_pad] fault index of a bit slot (rows of llr_ws are in slot order)
+    const uint8_t *det, *upd;
+    int64_t det_stride, det_offset, upd_stride;
+    const float *llr_ws;
+    const int32_t *fail_list, *fail_count;
+    uint64_t *ws;                         // [blocks][ws_words]: the Q columns where the sweep reads them
+    size_t ws_words;
+    uint32_t *err_bits;
+    int32_t *status;
+    unsigned long long *dbg;
+};
+
+// LDS layout shared by the kernel and the host (bytes).  The sweep's tables overlay the panel and `need` buffers, dead by then.
+template <int T, int CPT, int NWD>
+struct CsLds {
+    static constexpr int PSTR = NWD + 1, NPIV = T * CPT;
+    static constexpr int o_p = 0;                                   // [2][64][PSTR] u64 panel
+    static constexpr int o_need = o_p + 2 * 64 * PSTR * 8;          // [2][NPIV] u64
+    static constexpr int o_tp = o_need + 2 * NPIV * 8;              // [64][NWD] u64
+    static constexpr int o_sv = o_tp + 64 * NWD * 8;                // [NWD] u64
+    static constexpr int o_unp = o_sv + NWD * 8;                    // [NWD] u64
+    static constexpr int o_rowpiv = o_unp + NWD * 8;                // [NWD * 64] i16
+    static constexpr int o_prow = o_rowpiv + NWD * 64 * 2;          // [NPIV] u16
+    static constexpr int o_pcol = o_prow + NPIV * 2;                // [NPIV] u16
+    static constexpr int o_misc = o_pcol + NPIV * 2;                // 2048 bytes
+    static constexpr int o_var = o_misc + 2048;                     // pivmask [out_words], then out, then order (runtime sizes)
+    static constexpr int o_swl = o_p;                               // [NWD * 64] i32
+    static constexpr int o_nib = o_swl + NWD * 64 * 4;              // [NWD * 16][16] i32
+    static constexpr int o_tv = o_nib + NWD * 256 * 4;              // [64][NWD] u64
+    static_assert(o_tv + 64 * NWD * 8 <= o_tp, "the sweep's tables must fit over the panel and need buffers");
+    static_assert((NWD * 8) % 16 == 0 && (o_need % 16) == 0 && (o_tp % 16) == 0 && (o_var % 16) == 0, "16-byte alignment");
+};
+
+struct CsBest { long long delta; uint32_t cls; unsigned long long tie, what; };
+
+__device__ __forceinline__ bool qd_cs_less(long long d1, uint32_t c1, unsigned long long t1, long long d2, uint32_t c2, unsigned long long t2)
+{
+    if (d1 != d2) return d1 < d2;
+    if (c1 != c2) return c1 < c2;
+    return t1 < t2;
+}
+
+// Sorts buf[0 .. len) ascending, in place, by ONE wavefront (all 64 lanes call it with the same arguments).  Direction-free bitonic
+// network: the first step of every merge compares i with its mirror inside the block, the rest are half-cleaners, so every
+// comparator puts the smaller key at the lower index and the elements beyond `len` (virtual +infinity) never move.  A wavefront's
+// LDS operations complete in order, so the stages need no barrier.
+__device__ __forceinline__ void qd_cs_wave_sort(uint64_t *buf, int len, int lane)
+{
+    if (len < 2) return;
+    int P = 2;
+    while (P < len) P <<= 1;
+    const int half = P >> 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        const int kh = k >> 1;
+        for (int i = lane; i < half; i += 64) {
+            const int blk = i / kh, off = i - blk * kh;
+            const int lo = blk * k + off, hi = blk * k + (k - 1 - off);
+            if (hi < len) {
+                const uint64_t x = buf[lo], y = buf[hi];
+                if (x > y) { buf[lo] = y; buf[hi] = x; }
+            }
+        }
+        for (int j = kh >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < half; i += 64) {
+                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo + j;
+                if (hi < len) {
+                    const uint64_t x = buf[lo], y = buf[hi];
+                    if (x > y) { buf[lo] = y; buf[hi] = x; }
+                }
+            }
+        }
+    }
+}
+
+// T threads hold CPT columns of Q each (rank <= T * CPT), NWD words per column (m <= 64 * NWD); WPS = wavefronts per SIMD the
+// register budget is cut for; IPT = sorted items per thread (n <= T * IPT).
+template <int T, int CPT, int NWD, int WPS, int IPT>
+__global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int NW = T / 64;
+    constexpr int LPS = NWD <= 8 ? 8 : (NWD <= 16 ? 16 : 32);     // lanes per panel vector in the single-wavefront phase
+    constexpr int NSLOT = 64 / LPS;
+    constexpr unsigned long long LPSMASK = (LPS == 32) ? 0xFFFFFFFFull : ((1ull << LPS) - 1ull);
+    constexpr int PSTR = NWD + 1;                                  // padded column stride (words): a lane-per-column read of one word spreads over the banks
+    constexpr int NPIV = T * CPT;
+    const int m = a.m, n = a.n, dlog = a.ell_log2, ellw = 1 << dlog;
+
+    using L = CsLds<T, CPT, NWD>;
+    uint64_t *sb = reinterpret_cast<uint64_t *>(smem);                                   // [n] sort buffer (the sort phase owns all of LDS)
+    uint64_t *spl = reinterpret_cast<uint64_t *>(smem + a.o_sort_aux);                   // [32] splitters
+    uint32_t *bcnt = reinterpret_cast<uint32_t *>(smem + a.o_sort_aux + 256);            // [33] bucket starts
+    uint32_t *bcur = bcnt + 40;                                                          // [32] bucket cursors
+    uint16_t *order = reinterpret_cast<uint16_t *>(smem + a.o_order);                    // [n] faults in sorted order
+    uint64_t *Pbuf = reinterpret_cast<uint64_t *>(smem + L::o_p);                        // [2][64][PSTR] panel: images of the batch's columns, by row
+    uint64_t *needb = reinterpret_cast<uint64_t *>(smem + L::o_need);                    // [2][NPIV] pivot order -> batch columns that contain its row
+    uint64_t *Tp = reinterpret_cast<uint64_t *>(smem + L::o_tp);                         // [64][NWD] images of the batch's pivot columns (without the pivot bit)
+    uint64_t *sv = reinterpret_cast<uint64_t *>(smem + L::o_sv);                         // [NWD] transformed syndrome
+    uint64_t *unpm = reinterpret_cast<uint64_t *>(smem + L::o_unp);                      // [NWD] rows that are not pivot rows yet
+    int16_t *rowpiv = reinterpret_cast<int16_t *>(smem + L::o_rowpiv);                   // [NWD * 64] row -> pivot order or -1
+    uint16_t *prow = reinterpret_cast<uint16_t *>(smem + L::o_prow);                     // [NPIV] pivot order -> row
+    uint16_t *pcol = reinterpret_cast<uint16_t *>(smem + L::o_pcol);                     // [NPIV] pivot order -> fault
+    uint32_t *pivmask = reinterpret_cast<uint32_t *>(smem + L::o_var);                   // [out_words] faults that are pivot columns
+    uint32_t *outw = reinterpret_cast<uint32_t *>(smem + a.o_out);                       // [out_words]
+    uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::o_misc);                     // [0] pivots of the batch, [64..127] pivp, [128..] bests, [256..] npl
+    uint32_t *pivp = misc + 64;                                                          // [64] pivot row | batch column << 16
+    int32_t *swl = reinterpret_cast<int32_t *>(smem + L::o_swl);                         // [NWD * 64] signed pivot weight of a row (sweep)
+    int32_t *nib = reinterpret_cast<int32_t *>(smem + L::o_nib);                         // [NWD * 16][16] sums of swl over the rows of a nibble (sweep)
+    uint64_t *tvl = reinterpret_cast<uint64_t *>(smem + L::o_tv);                        // [64][NWD] images of the first non-pivot columns (patterns)
+    uint64_t *mt = a.ws + (size_t)blockIdx.x * a.ws_words;                               // [NPIV][NWD] Q columns, for the sweep (L2-resident)
+
+    const int nfail = *a.fail_count;
+    for (int item = blockIdx.x; item < nfail; item += gridDim.x) {
+        // The thread index is made opaque once per shot: everything derived from it (the IPT item indices of the sort, their bounds
+        // tests and global addresses, ...) is invariant across shots, and the compiler otherwise hoists all of it out of this loop
+        // and keeps it live -- in scratch -- for the whole kernel (the first build: 628 bytes per lane)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int slot = item;
+        const int64_t shot = a.fail_list[slot];
+        const float *llr = a.llr_ws + (int64_t)slot * a.n_pad;
+        const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
+        const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
+#ifdef QD_OSD_TIMING
+        unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long tick_ = wall_clock64();
+#endif
+        // ================================================================== the column order: sample sort of (key, fault) in LDS
+        {
+            const int nbk = min(QD_CS_MAX_BUCKETS, max(1, n >> 8));
+            const int ns = nbk * QD_CS_NSAMP_PER_BUCKET;                     // <= 256 <= T
+            auto key_of = [&](int b) -> uint64_t { return ((uint64_t)qd_mono_key(llr[b]) << 32) | (uint64_t)a.bit_orig[b]; };
+            if (tid < ns) sb[tid] = key_of((int)(((long long)tid * n) / ns));
+            if (tid < 32) spl[tid] = ~0ull;
+            if (tid < 40) { bcnt[tid] = 0u; }
+            __syncthreads();
+            if (nbk > 1 && tid < ns) {
+                // rank by counting (the keys are distinct: the fault index is part of them); every 8th sample is a splitter
+                const uint64_t mine = sb[tid];
+                int rank = 0;
+                for (int u = 0; u < ns; ++u) rank += sb[u] < mine ? 1 : 0;
+                if (rank > 0 && (rank % QD_CS_NSAMP_PER_BUCKET) == 0) spl[rank / QD_CS_NSAMP_PER_BUCKET - 1] = mine;
+            }
+            __syncthreads();
+            // bucket of a key = number of splitters <= key (branch-free binary search over 31 + 1 entries)
+            auto bucket_of = [&](uint64_t x) -> uint32_t {
+                uint32_t lo = 0;
+#pragma unroll
+                for (int step = 16; step >= 1; step >>= 1) lo += (spl[lo + step - 1] <= x) ? step : 0;
+                return lo;
+            };
+            uint32_t bkreg[(IPT + 3) / 4];
+#pragma unroll
+            for (int i = 0; i < (IPT + 3) / 4; ++i) bkreg[i] = 0u;
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int b = tid + i * T;
+                if (b < n) {
+                    const uint32_t bk = nbk > 1 ? bucket_of(key_of(b)) : 0u;
+                    bkreg[i >> 2] |= bk << (8 * (i & 3));
+                    atomicAdd(&bcnt[bk], 1u);
+                }
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // exclusive scan of the <= 32 counts (lanes 32.. carry zeros); bcnt[k] becomes the start of bucket k, bcnt[nbk .. 32] = n
+                const uint32_t c = tid < 32 ? bcnt[tid] : 0u;
+                uint32_t incl = c;
+#pragma unroll
+                for (int d = 1; d < 32; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+                if (tid < 32) { bcnt[tid] = incl - c; bcur[tid] = incl - c; }
+                if (tid == 32) bcnt[32] = (uint32_t)n;
+            }
+            __syncthreads();                                                  // (the samples in sb[0 .. ns) are dead: everybody has its bucket numbers)
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int b = tid + i * T;
+                if (b < n) {
+                    const uint32_t bk = (bkreg[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                    sb[atomicAdd(&bcur[bk], 1u)] = key_of(b);
+                }
+            }
+            __syncthreads();
+            for (int bk = wave; bk < nbk; bk += NW) {
+                const int lo = (int)bcnt[bk], hi = (int)bcnt[bk + 1];
+                qd_cs_wave_sort(sb + lo, hi - lo, lane);
+            }
+            __syncthreads();
+            uint16_t myord[IPT];
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int b = tid + i * T;
+                myord[i] = b < n ? (uint16_t)(sb[b] & 0xFFFFull) : (uint16_t)0;
+            }
+            __syncthreads();                                                  // the sort buffer is dead; everything below lives in the same LDS
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int b = tid + i * T;
+                if (b < n) order[b] = myord[i];
+            }
+        }
+        QD_TICK(0)
+        // ================================================================== elimination state
+        uint64_t mycol[CPT][NWD];
+#pragma unroll
+        for (int i = 0; i < CPT; ++i)
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) mycol[i][w] = 0ull;
+        for (int x = tid; x < 2 * 64 * PSTR; x += T) Pbuf[x] = 0ull;
+        for (int x = tid; x < 2 * NPIV; x += T) needb[x] = 0ull;
+        if (tid < NWD) {
+            sv[tid] = 0ull;
+            const int lo = tid * 64;
+            unpm[tid] = (m - lo >= 64) ? ~0ull : (m > lo ? ((1ull << (m - lo)) - 1ull) : 0ull);
+        }
+        for (int r = tid; r < NWD * 64; r += T) rowpiv[r] = -1;
+        for (int w = tid; w < a.out_words; w += T) { outw[w] = 0u; pivmask[w] = 0u; }
+        if (tid < 64) misc[tid] = 0u;
+        __syncthreads();
+        for (int r = tid; r < m; r += T) {
+            uint32_t sbit = det[r] & 1u;
+            if (upd && r < a.upd_rows) sbit ^= upd[r] & 1u;
+            if (sbit) atomicOr(reinterpret_cast<unsigned long long *>(&sv[r >> 6]), 1ull << (r & 63));
+        }
+        // scatter of batch `b0`: raw columns by row into the panel, and for every pivot the batch columns that contain its row
+        auto scatter = [&](int base, uint64_t *Pc, uint64_t *nd) {
+            const int nb = min(64, n - base);
+            for (int x = tid; x < (64 << dlog); x += T) {
+                const int c = x >> dlog, q = x & (ellw - 1);
+                if (c < nb) {
+                    const uint32_t col = order[base + c];
+                    const uint32_t r = a.csc_ell[((size_t)col << dlog) + q];
+                    if (r != 0xFFFFu) {
+                        atomicXor(reinterpret_cast<unsigned long long *>(&Pc[c * PSTR + (r >> 6)]), 1ull << (r & 63));
+                        const int k = rowpiv[r];
+                        if (k >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&nd[k]), 1ull << c);
+                    }
+                }
+            }
+        };
+        scatter(0, Pbuf, needb);
+        __syncthreads();
+
+        int npiv = 0;
+        for (int base = 0, bi = 0; base < n; base += 64, ++bi) {
+            const int nb = min(64, n - base);
+            uint64_t *Pc = Pbuf + (bi & 1) * 64 * PSTR, *Pn = Pbuf + ((bi & 1) ^ 1) * 64 * PSTR;
+            uint64_t *ndc = needb + (bi & 1) * NPIV, *ndn = needb + ((bi & 1) ^ 1) * NPIV;
+            // ---- [A] images: the owner of Q column k adds it to the batch columns that contain pivot row k; the other buffers are cleared
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int k = tid + i * T;
+                if (k < npiv)
+                    for (uint64_t bits = ndc[k]; bits; bits &= bits - 1ull) {
+                        const int c = (int)__builtin_ctzll(bits);
+#pragma unroll
+                        for (int w = 0; w < NWD; ++w)
+                            atomicXor(reinterpret_cast<unsigned long long *>(&Pc[c * PSTR + w]), (unsigned long long)mycol[i][w]);
+                    }
+            }
+            for (int x = tid; x < 64 * PSTR; x += T) Pn[x] = 0ull;
+            for (int x = tid; x < NPIV; x += T) ndn[x] = 0ull;
+            QD_TICK(1)
+            __syncthreads();
+            QD_TICK(5)
+            // ---- [B] one wavefront: the pivots of the batch, on the panel alone
+            if (wave == 0) {
+                const int w = lane & (LPS - 1), s = lane / LPS;
+                const bool wv = w < NWD;
+                uint64_t unp = wv ? unpm[w] : 0ull;
+                uint64_t live = 0ull;                                  // batch columns with a one on a row that is not a pivot row
+                for (int c0 = 0; c0 < nb; c0 += NSLOT) {
+                    const int c = c0 + s;
+                    const uint64_t x = (wv && c < nb) ? Pc[c * PSTR + w] : 0ull;
+                    const unsigned long long nz = __ballot((x & unp) != 0ull);
+#pragma unroll
+                    for (int q = 0; q < NSLOT; ++q)
+                        if ((nz >> (q * LPS)) & LPSMASK) live |= 1ull << (c0 + q);
+                }
+                int g = 0;
+                const int room = a.rank - npiv;
+                while (live != 0ull && g < room) {
+                    const int j = (int)__builtin_ctzll(live);
+                    live &= live - 1ull;
+                    const uint64_t x = wv ? Pc[j * PSTR + w] : 0ull;   // every slot reads the same column
+                    const uint64_t y = x & unp;
+                    const unsigned long long nz = __ballot(y != 0ull) & LPSMASK;
+                    if (nz == 0ull) continue;                          // the pivots of this batch made it dependent
+                    const int w0 = (int)__builtin_ctzll(nz);
+                    const uint32_t ylo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)y, w0);
+                    const uint32_t yhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(y >> 32), w0);
+                    const int pbit = ylo ? (int)__builtin_ctz(ylo) : 32 + (int)__builtin_ctz(yhi);
+                    const int p = w0 * 64 + pbit;
+                    const uint64_t pb = 1ull << pbit;
+                    const uint64_t tq = x ^ ((w == w0) ? pb : 0ull);   // the image without bit p
+                    if (s == 0 && wv) Tp[g * NWD + w] = tq;
+                    if (w == w0) unp &= ~pb;
+                    const int K = npiv + g;
+                    if (lane == 0) {
+                        const uint32_t pc = order[base + j];
+                        pivp[g] = (uint32_t)p | ((uint32_t)j << 16);
+                        rowpiv[p] = (int16_t)K; prow[K] = (uint16_t)p; pcol[K] = (uint16_t)pc;
+                        pivmask[pc >> 5] |= 1u << (pc & 31u);
+                    }
+                    // who holds row p: the later live columns (one lane per column reads the word of bit p) and the syndrome
+                    const uint64_t hb = ((live >> lane) & 1ull) ? Pc[lane * PSTR + w0] : 0ull;
+                    unsigned long long hits = __ballot((hb & pb) != 0ull);
+                    const uint64_t svw = sv[w0];
+                    if ((svw & pb) != 0ull && s == 0 && wv) sv[w] ^= tq;
+                    while (hits != 0ull) {
+                        int mine = -1;
+#pragma unroll
+                        for (int q = 0; q < NSLOT; ++q)
+                            if (hits != 0ull) {
+                                const int c = (int)__builtin_ctzll(hits);
+                                hits &= hits - 1ull;
+                                if (s == q) mine = c;
+                            }
+                        if (mine >= 0 && wv) Pc[mine * PSTR + w] ^= tq;
+                    }
+                    ++g;
+                }
+                if (s == 0 && wv) unpm[w] = unp;
+                if (lane == 0) misc[0] = (uint32_t)g;
+            }
+            QD_TICK(2)
+            __syncthreads();
+            QD_TICK(6)
+            // ---- [C] every Q column takes the batch's pivots, in order: a column that has bit p set gets the pivot's image added (bit p stays:
+            // the image is stored without it); column K, all zero until now, becomes that image.  The image travels in scalar registers.
+            const int g = (int)misc[0];
+            for (int i = 0; i < g; ++i) {
+                const int K = npiv + i;
+                if (wave * 64 > K) continue;                           // none of this wavefront's columns exists yet (uniform)
+                const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pivp[i]);
+                const int p = (int)(pj & 0xFFFFu), pw = p >> 6;
+                const uint64_t pb = 1ull << (p & 63);
+                const uint64_t tl = lane < NWD ? Tp[i * NWD + lane] : 0ull;
+                const uint32_t tl_lo = (uint32_t)tl, tl_hi = (uint32_t)(tl >> 32);
+                uint64_t sel[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) sel[c] = 0ull;
+                switch (pw) {
+#define QD_X(W) case W: if constexpr (W < NWD) { _Pragma("unroll") for (int c = 0; c < CPT; ++c) sel[c] = mycol[c][W < NWD ? W : 0]; } break;
+                    QD_X(0) QD_X(1) QD_X(2) QD_X(3) QD_X(4) QD_X(5) QD_X(6) QD_X(7) QD_X(8) QD_X(9) QD_X(10) QD_X(11)
+                    QD_X(12) QD_X(13) QD_X(14) QD_X(15) QD_X(16) QD_X(17) QD_X(18) QD_X(19) QD_X(20) QD_X(21) QD_X(22) QD_X(23)
+#undef QD_X
+                    default: break;
+                }
+                bool hit[CPT];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) {
+                    const int k = tid + c * T;
+                    hit[c] = (k < K && (sel[c] & pb) != 0ull) || k == K;
+                }
+                // eight words of the image at a time through scalar registers (16 SGPRs live, not 2 NWD)
+#pragma unroll
+                for (int wb = 0; wb < NWD; wb += 8) {
+                    uint32_t tlo[8], thi[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (wb + u < NWD) {
+                            tlo[u] = (uint32_t)__builtin_amdgcn_readlane((int)tl_lo, wb + u);
+                            thi[u] = (uint32_t)__builtin_amdgcn_readlane((int)tl_hi, wb + u);
+                        }
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c)
+                        if (hit[c]) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u)
+                                if (wb + u < NWD) mycol[c][wb + u] ^= ((uint64_t)thi[u] << 32) | (uint64_t)tlo[u];
+                        }
+                }
+            }
+            npiv += g;
+            const bool done = npiv >= a.rank || base + 64 >= n;
+            if (!done) scatter(base + 64, Pn, ndn);
+            QD_TICK(3)
+            __syncthreads();
+            QD_TICK(7)
+            if (done) break;
+        }
+        // ================================================================== OSD-0 solution, then the candidate sweep
+        // residual on a non-pivot row <=> syndrome outside the column space (the answer is still the oracle's: same pivot rule)
+        if (tid < NWD && (sv[tid] & unpm[tid]) != 0ull) atomicOr(&misc[2], 1u);      // (misc[0..63] was cleared at the head of the shot)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            const int k = tid + c * T;
+            if (k < npiv) {
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) mt[(size_t)k * NWD + w] = mycol[c][w];
+            }
+        }
+        // signed pivot weights by row (a pivot that is on in the OSD-0 solution gets cheaper when flipped), and their sums per nibble
+        for (int r = tid; r < NWD * 64; r += T) {
+            int32_t v = 0;
+            const int k = r < m ? (int)rowpiv[r] : -1;
+            if (k >= 0) { const int32_t wgt = (int32_t)a.wfix[pcol[k]]; v = ((sv[r >> 6] >> (r & 63)) & 1ull) ? -wgt : wgt; }
+            swl[r] = v;
+        }
+        __syncthreads();
+        for (int x = tid; x < NWD * 16 * 16; x += T) {
+            const int nb4 = x >> 4, pat = x & 15;
+            int32_t s = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) s += ((pat >> b) & 1) ? swl[nb4 * 4 + b] : 0;
+            nib[x] = s;
+        }
+        __syncthreads();
+        const int nnp_all = n - npiv;
+        // image of fault `col` under the complete transform, restricted to nothing: t ^= XOR over its pivoted rows r of (Q column of r + e_r)
+        auto add_col = [&](uint32_t col, uint64_t t[NWD]) {
+            for (int q = 0; q < ellw; ++q) {
+                const uint32_t r = a.csc_ell[((size_t)col << dlog) + q];
+                if (r == 0xFFFFu) break;
+                const int k = rowpiv[r];
+                if (k < 0) continue;                                   // a non-pivot row weighs nothing
+                const uint64_t *src = mt + (size_t)k * NWD;
+                const int rw = (int)(r >> 6);
+                const uint64_t rb = 1ull << (r & 63u);
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) t[w] ^= src[w] ^ ((w == rw) ? rb : 0ull);
+            }
+        };
+        auto wsum = [&](const uint64_t t[NWD]) -> long long {
+            long long tot = 0;
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) {
+                const uint32_t lo = (uint32_t)t[w], hi = (uint32_t)(t[w] >> 32);
+                int32_t s = 0;                                         // 16 nibbles x 4 weights below 2^25 each: no overflow (checked by the host)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s += nib[((w * 16 + q) << 4) + ((lo >> (4 * q)) & 15u)];
+                    s += nib[((w * 16 + 8 + q) << 4) + ((hi >> (4 * q)) & 15u)];
+                }
+                tot += (long long)s;
+            }
+            return tot;
+        };
+        CsBest best{0x7FFFFFFFFFFFFFFFll, 3u, ~0ull, 0ull};
+        if (a.osd_w == 1) {
+            // ---- singles: every non-pivot column; ties go to the earlier position of the order (ldpc's enumeration order)
+            for (int i = tid; i < n; i += T) {
+                const uint32_t col = order[i];
+                if ((pivmask[col >> 5] >> (col & 31u)) & 1u) continue;
+                uint64_t t[NWD];
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) t[w] = 0ull;
+                add_col(col, t);
+                const long long d = wsum(t) + (long long)a.wfix[col];
+                if (qd_cs_less(d, 1u, (unsigned long long)i, best.delta, best.cls, best.tie)) best = CsBest{d, 1u, (unsigned long long)i, (unsigned long long)col};
+            }
+        }
+        // ---- patterns over the first lam non-pivot columns of the order: pairs (combination sweep) or all subsets (exhaustive)
+        const int lam = min(min(a.osd_order, nnp_all), 64);
+        uint32_t *npl = misc + 256;                                    // [64] the first lam non-pivot faults of the order
+        if (lam >= (a.osd_w == 1 ? 2 : 1)) {
+            if (wave == 0) {
+                int cnt = 0;
+                for (int b0 = 0; b0 < n && cnt < lam; b0 += 64) {
+                    const int i = b0 + lane;
+                    uint32_t col = 0u;
+                    bool np_ = false;
+                    if (i < n) { col = order[i]; np_ = !((pivmask[col >> 5] >> (col & 31u)) & 1u); }
+                    const unsigned long long bal = __ballot(np_);
+                    const int at = cnt + (int)__popcll(bal & ((1ull << lane) - 1ull));
+                    if (np_ && at < lam) npl[at] = col;
+                    cnt += (int)__popcll(bal);
+                }
+            }
+            __syncthreads();
+            if (tid < lam) {
+                uint64_t t[NWD];
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) t[w] = 0ull;
+                add_col(npl[tid], t);
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) tvl[tid * NWD + w] = t[w];
+            }
+            __syncthreads();
+            const unsigned long long npat = (a.osd_w == 1) ? (unsigned long long)lam * (lam - 1) / 2 : ((1ull << lam) - 1ull);
+            for (unsigned long long ic = tid; ic < npat; ic += T) {
+                unsigned long long pat;
+                if (a.osd_w == 2) pat = ic + 1ull;
+                else {
+                    unsigned long long qq = ic; int x = 0;             // pairs (x, y), x < y < lam, lexicographic
+                    while (qq >= (unsigned long long)(lam - 1 - x)) { qq -= (unsigned long long)(lam - 1 - x); ++x; }
+                    pat = (1ull << x) | (1ull << (x + 1 + (int)qq));
+                }
+                uint64_t t[NWD];
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) t[w] = 0ull;
+                long long d = 0;
+                for (int b = 0; b < lam; ++b)
+                    if ((pat >> b) & 1ull) {
+                        d += (long long)a.wfix[npl[b]];
+#pragma unroll
+                        for (int w = 0; w < NWD; ++w) t[w] ^= tvl[b * NWD + w];
+                    }
+                d += wsum(t);
+                if (qd_cs_less(d, 2u, ic, best.delta, best.cls, best.tie)) best = CsBest{d, 2u, ic, pat};
+            }
+        }
+        // ---- winner: wavefront minimum by shuffles, then the NW partials
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+            CsBest o;
+            o.delta = ((long long)__shfl_xor((int)(best.delta >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)best.delta, sh);
+            o.cls = (uint32_t)__shfl_xor((int)best.cls, sh);
+            o.tie = ((unsigned long long)(uint32_t)__shfl_xor((int)(best.tie >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)best.tie, sh);
+            o.what = ((unsigned long long)(uint32_t)__shfl_xor((int)(best.what >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)best.what, sh);
+            if (qd_cs_less(o.delta, o.cls, o.tie, best.delta, best.cls, best.tie)) best = o;
+        }
+        CsBest *bests = reinterpret_cast<CsBest *>(misc + 128);       // [NW <= 16] x 32 bytes
+        uint64_t *twin = Tp;                                           // [NWD] the winner's image (the panel scratch is idle)
+        if (lane == 0) bests[wave] = best;
+        __syncthreads();
+        CsBest win = bests[0];
+        for (int q = 1; q < NW; ++q) { const CsBest c = bests[q]; if (qd_cs_less(c.delta, c.cls, c.tie, win.delta, win.cls, win.tie)) win = c; }
+        const bool take = win.delta < 0;                               // OSD-0 unless a candidate is strictly cheaper
+        if (tid == 0) {
+            uint64_t t[NWD];
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) t[w] = 0ull;
+            if (take) {
+                if (win.cls == 1u) add_col((uint32_t)win.what, t);
+                else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) add_col(npl[b], t);
+            }
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) twin[w] = t[w];
+        }
+        __syncthreads();
+        for (int k = tid; k < npiv; k += T) {
+            const int r = (int)prow[k];
+            if ((((sv[r >> 6] ^ twin[r >> 6]) >> (r & 63)) & 1ull) != 0ull) {
+                const uint32_t j = pcol[k];
+                atomicOr(&outw[j >> 5], 1u << (j & 31u));
+            }
+        }
+        if (tid == 0 && take) {
+            if (win.cls == 1u) atomicOr(&outw[(uint32_t)win.what >> 5], 1u << ((uint32_t)win.what & 31u));
+            else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) atomicOr(&outw[npl[b] >> 5], 1u << (npl[b] & 31u));
+        }
+        __syncthreads();
+        for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = outw[w];
+        if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (misc[2] ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
+        QD_TICK(4)
+#ifdef QD_OSD_TIMING
+        if (tid == 0) {
+            for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc_[i]);
+            atomicAdd(&a.dbg[8], 1ull); atomicAdd(&a.dbg[9], (unsigned long long)npiv);
+        }
+#endif
+        __syncthreads();   // LDS is recycled by the next shot
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+// Instantiations: variant 1: m <= 512 (256 threads x 2 columns x 8 words), 2: m <= 1024 (512 x 2 x 16), 3: m <= 1408 (512 x 3 x 22).
+struct CsShape { int T, CPT, NWD, WPS, IPT; };
+static CsShape cs_shape(int variant)
+{
+    switch (variant) {
+    case 1: return CsShape{256, 2, 8, 6, 16};
+    case 2: return CsShape{512, 2, 16, 4, 20};
+    default: return CsShape{512, 3, 22, 2, 40};
+    }
+}
+
+// LDS layout for a window of m detectors, n faults; returns the bytes (0: this kernel does not take the window), the instantiation
+// and how many workgroups share a CU.  off[0..2] = the runtime offsets of OsdCsArgs (out, order, sort_aux).
+int qd_osdcs_layout(int m, int n, int out_words, uint32_t max_wfix, int *off, int *variant, int *per_cu)
+{
+    const int var = m <= 512 ? 1 : (m <= 1024 ? 2 : (m <= 1408 ? 3 : 0));
+    if (var == 0 || n >= 65535) return 0;
+    const CsShape sh = cs_shape(var);
+    if (n > sh.T * sh.IPT) return 0;
+    if ((uint64_t)max_wfix * 64ull >= 0x7FFFFFFFull) return 0;        // the sweep adds 64 weights in 32 bits
+    auto al = [](int x) { return (x + 15) & ~15; };
+    const int o_var = var == 1 ? CsLds<256, 2, 8>::o_var : (var == 2 ? CsLds<512, 2, 16>::o_var : CsLds<512, 3, 22>::o_var);
+    int o = o_var + al(out_words * 4);                // pivmask
+    off[0] = o; o += al(out_words * 4);               // out
+    off[1] = o; o += al(n * 2);                       // order
+    // the sort phase owns everything: n keys of 8 bytes, then splitters / counters
+    off[2] = al(n * 8);
+    const int sort_end = off[2] + 1024;
+    const int total = std::max(o, sort_end);
+    const int by_regs = sh.WPS * 256 / sh.T;          // workgroups per CU the register budget allows
+    const int by_lds = QD_LDS_BYTES / total;
+    if (by_lds < 1) return 0;
+    *variant = var;
+    *per_cu = std::max(1, std::min(by_regs, by_lds));
+    return total;
+}
+
+size_t qd_osdcs_ws_words(int variant)
+{
+    const CsShape sh = cs_shape(variant);
+    return (size_t)sh.T * sh.CPT * sh.NWD + 64;
+}
+
+hipError_t qd_launch_osdcs(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const int *off, int variant, int lds,
+                           uint64_t *ws, int blocks, hipStream_t s)
+{
+    OsdCsArgs r{};
+    r.m = g.m; r.n = g.n; r.n_pad = bg.n_pad; r.out_words = bg.out_words; r.upd_rows = a.upd_rows; r.ell_log2 = g.ell_log2; r.rank = a.rank;
+    r.osd_w = a.osd_w; r.osd_order = a.osd_order;
+    r.o_out = off[0]; r.o_order = off[1]; r.o_sort_aux = off[2];
+    r.csc_ell = g.csc_ell; r.wfix = g.wfix; r.bit_orig = bg.bit_orig;
+    r.det = a.det; r.upd = a.upd; r.det_stride = a.det_stride; r.det_offset = a.det_offset; r.upd_stride = a.upd_stride;
+    r.llr_ws = a.llr_ws; r.fail_list = a.fail_list; r.fail_count = a.fail_count;
+    r.ws = ws; r.ws_words = qd_osdcs_ws_words(variant);
+    r.err_bits = a.err_bits; r.status = a.status; r.dbg = a.dbg;
+#define QD_CS_CASE(TT, CC, WW, SS, II)                                                                                            \
+    {                                                                                                                             \
+        auto k = qd_osdcs_kernel<TT, CC, WW, SS, II>;                                                                             \
+        hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);                     \
+        if (e != hipSuccess) return e;                                                                                            \
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TT), lds, s, r);                                                       \
+        return hipGetLastError();                                                                                                 \
+    }
+    switch (variant) {
+    case 1: QD_CS_CASE(256, 2, 8, 6, 16)
+    case 2: QD_CS_CASE(512, 2, 16, 4, 20)
+    default: QD_CS_CASE(512, 3, 22, 2, 40)
+    }
+#undef QD_CS_CASE
+}

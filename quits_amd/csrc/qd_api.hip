@@ -24,6 +24,11 @@ hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const Deco
                           int blocks_full, hipStream_t s, bool handed_over = false);
 int qd_osd_sr_layout(int m, int m_pad, int n, int out_words, int *off13, int *threads, int *rpt);
 hipError_t qd_launch_osd0_sr(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s);
+// osd_cs.hip: OSD-CS / OSD-E, the rebuilt column-form kernel
+int qd_osdcs_layout(int m, int n, int out_words, uint32_t max_wfix, int *off, int *variant, int *per_cu);
+size_t qd_osdcs_ws_words(int variant);
+hipError_t qd_launch_osdcs(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const int *off, int variant, int lds,
+                           uint64_t *ws, int blocks, hipStream_t s);
 size_t qd_osd_sr_ws_words(int m_pad, int mw, int threads, int rpt);
 hipError_t qd_launch_lsd0(const GenGraphDev &gg, const BpGraphDev &bg, const DecodeArgs &d, uint64_t *q_ws, int blocks_alloc, int blocks,
                           int lsd_w, int lsd_order, const uint32_t *wfix, hipStream_t s);
@@ -104,6 +109,9 @@ struct qd_decoder {
     int32_t *hard_list = nullptr, *hard_list2 = nullptr;
     int osd_blocks_fast = 0;
     int osd_blocks_sr = 0;      // > 0: OSD-0 runs in qd_osd0_sr_kernel (osd_sr.hip), the mirrored kernel only takes the shots it hands over
+    int osd_blocks_cs = 0;      // > 0: OSD-CS / OSD-E run in qd_osdcs_kernel (osd_cs.hip)
+    int cs_off[16] = {0}, cs_variant = 0, cs_lds = 0;
+    uint64_t *cs_ws = nullptr;  // [osd_blocks_cs][qd_osdcs_ws_words] Q columns for the candidate sweep
     int osd_w = 0;
     int general = 0;            // 1: the one-message-per-edge kernel (bp_general.hip) runs BP
     int lds_edge = 0;           // ... its LDS-resident form (flooding product-sum on a window whose messages fit LDS): no HBM message workspace
@@ -481,6 +489,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         for (int j = 0; j < n; ++j) {
             double w = std::log(1.0 / priors[j]) * 262144.0;
             wfix[j] = (uint32_t)std::llround(std::min(std::max(w, 0.0), 4294967295.0));
+            g->osd.max_wfix = std::max(g->osd.max_wfix, wfix[j]);
         }
         rc |= g->mem.upload(slot_of, &bp.bit_slot_of);
         rc |= g->mem.upload(wfix, &g->osd.wfix);
@@ -865,6 +874,24 @@ extern "C" int qd_decoder_info(const qd_decoder *d, int32_t *info)
     return QD_OK;
 }
 
+extern "C" int qd_decoder_postproc_kernel(const qd_decoder *d)
+{
+    if (!d) return -1;
+    if (d->prm.osd_method == QD_OSD_OFF) return QD_POST_NONE;
+    if (d->lsd) return QD_POST_LSD;
+    if (d->osd_w) {
+        // (the same decision qd_decoder_reserve takes when it sizes the workspace)
+        const char *ev = std::getenv("QD_OSDCS_OLD");
+        int off[16], var = 0, per = 0;
+        if (d->g->osd.csc_ell && !(ev && std::atoi(ev) == 1) &&
+            qd_osdcs_layout(d->g->m, d->g->n, d->g->bp.out_words, d->g->osd.max_wfix, off, &var, &per) > 0) return QD_POST_OSD_CS_PANEL;
+        return QD_POST_OSD_W_OLD;
+    }
+    const char *ev = std::getenv("QD_NO_OSD_SR");
+    if (d->g->osd.s_lds_bytes > 0 && !(ev && std::atoi(ev) == 1)) return QD_POST_OSD0_SR;
+    return QD_POST_OSD0_REG;
+}
+
 static void free_ws(qd_decoder *d)
 {
     if (d->llr_ws) (void)hipFree(d->llr_ws);
@@ -878,6 +905,8 @@ static void free_ws(qd_decoder *d)
     d->q_spill_sr = nullptr;
     if (d->mt_ws) (void)hipFree(d->mt_ws);
     d->mt_ws = nullptr;
+    if (d->cs_ws) (void)hipFree(d->cs_ws);
+    d->cs_ws = nullptr; d->osd_blocks_cs = 0;
     if (d->gws.b2c) (void)hipFree(d->gws.b2c);
     if (d->gws.c2b) (void)hipFree(d->gws.c2b);
     if (d->gws.th) (void)hipFree(d->gws.th);
@@ -956,6 +985,21 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
                 d->osd_blocks_sr = ncu * per;
                 HIP_TRY(hipMalloc((void **)&d->q_spill_sr, sizeof(uint64_t) * (size_t)d->osd_blocks_sr *
                                                            qd_osd_sr_ws_words(g->osd.m_pad, g->osd.mw, g->osd.s_threads, g->osd.s_rpt)));
+            }
+        }
+        d->osd_blocks_cs = 0;
+        {
+            // higher-order OSD: the rebuilt column-form kernel (osd_cs.hip) wherever its layout takes the window; QD_OSDCS_OLD=1 keeps
+            // qd_osdw_col_kernel / the row form for A/B runs
+            const char *ev = std::getenv("QD_OSDCS_OLD");
+            if (d->osd_w && !d->lsd && g->osd.csc_ell && !(ev && std::atoi(ev) == 1)) {
+                int per = 0;
+                d->cs_lds = qd_osdcs_layout(g->m, g->n, g->bp.out_words, g->osd.max_wfix, d->cs_off, &d->cs_variant, &per);
+                if (d->cs_lds > 0) {
+                    if (const char *e2 = std::getenv("QD_OSDCS_PER_CU")) { const int v = std::atoi(e2); if (v > 0) per = std::min(v, QD_LDS_BYTES / d->cs_lds); }
+                    d->osd_blocks_cs = ncu * per;
+                    HIP_TRY(hipMalloc((void **)&d->cs_ws, sizeof(uint64_t) * (size_t)d->osd_blocks_cs * qd_osdcs_ws_words(d->cs_variant)));
+                }
             }
         }
         const int spill_fast = g->osd.mw - (d->osd_w ? g->osd.w_kw : g->osd.f_kw);
@@ -1135,6 +1179,9 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         if (d->lsd)
             HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), d->lsd_w,
                                    d->prm.osd_order, d->g->osd.wfix, s));
+        else if (d->osd_blocks_cs > 0)
+            HIP_TRY(qd_launch_osdcs(d->g->osd, d->g->bp, a, d->cs_off, d->cs_variant, d->cs_lds, d->cs_ws,
+                                    (int)std::min<int64_t>(B, d->osd_blocks_cs), s));
         else if (d->osd_blocks_sr > 0) {
             // OSD-0: many pivots per round (osd_sr.hip); shots whose syndrome is outside the column space come back on the hard list
             // and are decoded by the one-pivot-per-round kernel, whose lowest-row rule defines their answer
@@ -1197,6 +1244,9 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     if (lsd_only)
         HIP_TRY(qd_launch_lsd0(d->g->gen, d->g->bp, a, d->lsd_ws, d->lsd_blocks, (int)std::min<int64_t>(B, d->lsd_blocks), d->lsd_w,
                                    d->prm.osd_order, d->g->osd.wfix, s));
+    else if (d->osd_blocks_cs > 0)
+        HIP_TRY(qd_launch_osdcs(d->g->osd, d->g->bp, a, d->cs_off, d->cs_variant, d->cs_lds, d->cs_ws,
+                                (int)std::min<int64_t>(B, d->osd_blocks_cs), s));
     else if (d->osd_blocks_sr > 0) {
         HIP_TRY(qd_launch_osd0_sr(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_sr), s));
         HIP_TRY(qd_launch_osd0(d->g->osd, d->g->bp, a, (int)std::min<int64_t>(B, d->osd_blocks_fast),

@@ -135,6 +135,7 @@ struct OsdGraphDev {
     // higher-order OSD by column (qd_osdw_col_kernel): its own, smaller layout -- the Q region only holds the elimination's scratch
     int c_off[10], c_off_sort, c_off_order, c_off_pivmask, c_off_npl, c_lds_bytes, c_cpt, c_per_cu;
     const uint32_t *wfix;       // [n] integer candidate costs round(log(1/p) * 2^18) for OSD-CS / OSD-E
+    uint32_t max_wfix;          // largest of them (the rebuilt OSD-CS / OSD-E kernel adds 64 of them in 32 bits)
     int threads;
     // OSD-0 with simultaneous singleton pivots (osd_sr.hip, qd_osd0_sr_kernel): its LDS layout (s_lds_bytes = 0: not taken),
     // instantiation and the columns in ELL form
