@@ -161,7 +161,8 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
         const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
 #ifdef QD_OSD_TIMING
-        unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long acc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long sub_ = 0;
         unsigned long long tick_ = wall_clock64();
 #endif
         // ================================================================== the column order: sample sort of (key, fault) in LDS
@@ -299,68 +300,123 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             }
             for (int x = tid; x < 64 * PSTR; x += T) Pn[x] = 0ull;
             for (int x = tid; x < NPIV; x += T) ndn[x] = 0ull;
+#ifdef QD_OSD_TIMING
+            ++acc_[10];
+#endif
             QD_TICK(1)
             __syncthreads();
             QD_TICK(5)
-            // ---- [B] one wavefront: the pivots of the batch, on the panel alone
+            // ---- [B] one wavefront: the pivots of the batch, on the panel alone.  Lane w holds word w of whatever vector is being looked
+            // at (the lanes beyond NWD idle; the LPS-lane slots only matter to the liveness sweep).  Live columns are taken CH at a time
+            // into registers -- one LDS round trip per chunk, none per pivot: bit p of a register-held vector is read with v_readlane
+            // from the lane of its word --, the syndrome and the unpivoted-row mask stay in registers for the whole batch, and a chunk
+            // loaded later first takes the batch's earlier pivots (only the columns that hold one of their rows at all).
             if (wave == 0) {
+                __builtin_amdgcn_s_setprio(3);                         // the one wavefront everybody waits for
                 const int w = lane & (LPS - 1), s = lane / LPS;
                 const bool wv = w < NWD;
                 uint64_t unp = wv ? unpm[w] : 0ull;
-                uint64_t live = 0ull;                                  // batch columns with a one on a row that is not a pivot row
-                for (int c0 = 0; c0 < nb; c0 += NSLOT) {
-                    const int c = c0 + s;
-                    const uint64_t x = (wv && c < nb) ? Pc[c * PSTR + w] : 0ull;
-                    const unsigned long long nz = __ballot((x & unp) != 0ull);
+                uint64_t svr = wv ? sv[w] : 0ull;
+                uint64_t bm = 0ull;                                    // rows that became pivot rows in this batch
+                // liveness, one lane per column: OR over the words of (column & unpivoted rows); the padded column stride keeps the 64
+                // lanes' reads of one word on different banks
+                uint64_t live;                                         // batch columns with a one on a row that is not a pivot row
+                {
+                    uint64_t acc = 0ull;
 #pragma unroll
-                    for (int q = 0; q < NSLOT; ++q)
-                        if ((nz >> (q * LPS)) & LPSMASK) live |= 1ull << (c0 + q);
+                    for (int ww = 0; ww < NWD; ++ww) acc |= Pc[lane * PSTR + ww] & unpm[ww];
+                    live = __ballot(acc != 0ull && lane < nb);
                 }
+#ifdef QD_OSD_TIMING
+#define QD_SUB(slot) { const unsigned long long n2_ = wall_clock64(); acc_[slot] += n2_ - sub_; sub_ = n2_; }
+                sub_ = tick_;
+#else
+#define QD_SUB(slot)
+#endif
+                QD_SUB(11)
+                // rank -> column table of the live columns (chunks are consecutive rank ranges; a pivot's record keeps the rank)
+                uint32_t *tab = misc + 192;                            // [64]
+                const int nlive = (int)__popcll(live);
+                if ((live >> lane) & 1ull) tab[__popcll(live & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+                // A chunk = NR registers x NSLOT slots: the column of rank c0 + r * NSLOT + q has word w in lane (q * LPS + w) of x[r].  A pivot's
+                // image goes through Tp (it has to be stored there anyway) back into every slot; whether a register's columns hold the
+                // pivot row is one ballot per register: the bit sits in lane (slot * LPS + w0).
+                constexpr int NR = NWD <= 8 ? 4 : 8, CHC = NR * NSLOT;
                 int g = 0;
                 const int room = a.rank - npiv;
-                while (live != 0ull && g < room) {
-                    const int j = (int)__builtin_ctzll(live);
-                    live &= live - 1ull;
-                    const uint64_t x = wv ? Pc[j * PSTR + w] : 0ull;   // every slot reads the same column
-                    const uint64_t y = x & unp;
-                    const unsigned long long nz = __ballot(y != 0ull) & LPSMASK;
-                    if (nz == 0ull) continue;                          // the pivots of this batch made it dependent
-                    const int w0 = (int)__builtin_ctzll(nz);
-                    const uint32_t ylo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)y, w0);
-                    const uint32_t yhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(y >> 32), w0);
-                    const int pbit = ylo ? (int)__builtin_ctz(ylo) : 32 + (int)__builtin_ctz(yhi);
-                    const int p = w0 * 64 + pbit;
-                    const uint64_t pb = 1ull << pbit;
-                    const uint64_t tq = x ^ ((w == w0) ? pb : 0ull);   // the image without bit p
-                    if (s == 0 && wv) Tp[g * NWD + w] = tq;
-                    if (w == w0) unp &= ~pb;
-                    const int K = npiv + g;
-                    if (lane == 0) {
-                        const uint32_t pc = order[base + j];
-                        pivp[g] = (uint32_t)p | ((uint32_t)j << 16);
-                        rowpiv[p] = (int16_t)K; prow[K] = (uint16_t)p; pcol[K] = (uint16_t)pc;
-                        pivmask[pc >> 5] |= 1u << (pc & 31u);
-                    }
-                    // who holds row p: the later live columns (one lane per column reads the word of bit p) and the syndrome
-                    const uint64_t hb = ((live >> lane) & 1ull) ? Pc[lane * PSTR + w0] : 0ull;
-                    unsigned long long hits = __ballot((hb & pb) != 0ull);
-                    const uint64_t svw = sv[w0];
-                    if ((svw & pb) != 0ull && s == 0 && wv) sv[w] ^= tq;
-                    while (hits != 0ull) {
-                        int mine = -1;
+                for (int c0 = 0; c0 < nlive && g < room; c0 += CHC) {
+                    uint64_t x[NR];
 #pragma unroll
-                        for (int q = 0; q < NSLOT; ++q)
-                            if (hits != 0ull) {
-                                const int c = (int)__builtin_ctzll(hits);
-                                hits &= hits - 1ull;
-                                if (s == q) mine = c;
-                            }
-                        if (mine >= 0 && wv) Pc[mine * PSTR + w] ^= tq;
+                    for (int r = 0; r < NR; ++r) {
+                        const int rank = c0 + r * NSLOT + s;
+                        const bool ok = wv && rank < nlive;
+                        const uint32_t c = ok ? tab[rank] : 0u;
+                        x[r] = ok ? Pc[c * PSTR + w] : 0ull;
                     }
-                    ++g;
+                    // adds `tq` to the columns of `v` that hold row (64 w0 + pbit); sh = w0 + LPS * slot, isw = (w == w0)
+                    auto apply_row = [&](uint64_t &v, uint64_t tq, int pbit, int sh, bool isw) {
+                        const uint32_t half = (pbit & 32) ? (uint32_t)(v >> 32) : (uint32_t)v;
+                        const unsigned long long bal = __ballot(isw && ((half >> (pbit & 31)) & 1u) != 0u);
+                        if ((bal >> sh) & 1ull) v ^= tq;
+                    };
+                    if (g > 0) {
+                        uint32_t flag = 0u;
+#pragma unroll
+                        for (int r = 0; r < NR; ++r)
+                            if (__ballot((x[r] & bm) != 0ull) != 0ull) flag |= 1u << r;
+                        if (flag != 0u)
+                            for (int i = 0; i < g; ++i) {
+                                const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pivp[i]);
+                                const int p = (int)(pj & 0xFFFFu), w0 = p >> 6, pbit = p & 63;
+                                const uint64_t tq = wv ? Tp[i * NWD + w] : 0ull;
+                                const int sh = w0 + LPS * s;
+                                const bool isw = w == w0;
+#pragma unroll
+                                for (int r = 0; r < NR; ++r)
+                                    if ((flag >> r) & 1u) apply_row(x[r], tq, pbit, sh, isw);
+                            }
+                    }
+                    QD_SUB(12)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) {
+                        for (int q = 0; q < NSLOT; ++q) {
+                            if (c0 + r * NSLOT + q >= nlive || g >= room) break;
+                            const uint64_t y = x[r] & unp;
+                            const unsigned long long nz = (__ballot(y != 0ull) >> (q * LPS)) & LPSMASK;
+                            if (nz == 0ull) continue;                  // the pivots of this batch made it dependent
+                            const int w0 = (int)__builtin_ctzll(nz), src = q * LPS + w0;
+                            const uint32_t ylo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)y, src);
+                            const uint32_t yhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(y >> 32), src);
+                            const int pbit = ylo ? (int)__builtin_ctz(ylo) : 32 + (int)__builtin_ctz(yhi);
+                            const int p = w0 * 64 + pbit;
+                            const uint64_t pb = 1ull << pbit;
+                            const bool isw = w == w0;
+                            if (s == q && wv) Tp[g * NWD + w] = x[r] ^ (isw ? pb : 0ull);      // the image without bit p
+                            if (lane == 0) pivp[g] = (uint32_t)p | ((uint32_t)(c0 + r * NSLOT + q) << 16);
+                            if (isw) { unp &= ~pb; bm |= pb; }
+                            const uint64_t tq = wv ? Tp[g * NWD + w] : 0ull;                   // ... back into every slot
+                            const int sh = w0 + LPS * s;
+                            apply_row(svr, tq, pbit, sh, isw);
+#pragma unroll
+                            for (int r2 = r; r2 < NR; ++r2) apply_row(x[r2], tq, pbit, sh, isw);   // (columns already passed are dead: harmless)
+                            ++g;
+                        }
+                    }
+                    QD_SUB(13)
                 }
-                if (s == 0 && wv) unpm[w] = unp;
+                if (s == 0 && wv) { unpm[w] = unp; sv[w] = svr; }
                 if (lane == 0) misc[0] = (uint32_t)g;
+                if (lane < g) {                                        // the pivots' records, one lane each (pivp: same wavefront, LDS in order)
+                    const uint32_t pj = pivp[lane];
+                    const int p = (int)(pj & 0xFFFFu), K = npiv + lane;
+                    const uint32_t cb = tab[pj >> 16];                 // rank among the live columns -> column of the batch
+                    pivp[lane] = (uint32_t)p | (cb << 16);
+                    const uint32_t pc = order[base + (int)cb];
+                    rowpiv[p] = (int16_t)K; prow[K] = (uint16_t)p; pcol[K] = (uint16_t)pc;
+                    atomicOr(&pivmask[pc >> 5], 1u << (pc & 31u));
+                }
+                QD_SUB(14)
+                __builtin_amdgcn_s_setprio(0);
             }
             QD_TICK(2)
             __syncthreads();
@@ -368,13 +424,19 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             // ---- [C] every Q column takes the batch's pivots, in order: a column that has bit p set gets the pivot's image added (bit p stays:
             // the image is stored without it); column K, all zero until now, becomes that image.  The image travels in scalar registers.
             const int g = (int)misc[0];
+            uint32_t pj_n = g > 0 ? pivp[0] : 0u;
+            uint64_t tl_n = (g > 0 && lane < NWD) ? Tp[lane] : 0ull;
             for (int i = 0; i < g; ++i) {
                 const int K = npiv + i;
+                const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pj_n);
+                const uint64_t tl = tl_n;
+                if (i + 1 < g) {                                       // the next pivot's record and image are on their way while this one is applied
+                    pj_n = pivp[i + 1];
+                    tl_n = lane < NWD ? Tp[(i + 1) * NWD + lane] : 0ull;
+                }
                 if (wave * 64 > K) continue;                           // none of this wavefront's columns exists yet (uniform)
-                const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pivp[i]);
                 const int p = (int)(pj & 0xFFFFu), pw = p >> 6;
                 const uint64_t pb = 1ull << (p & 63);
-                const uint64_t tl = lane < NWD ? Tp[i * NWD + lane] : 0ull;
                 const uint32_t tl_lo = (uint32_t)tl, tl_hi = (uint32_t)(tl >> 32);
                 uint64_t sel[CPT];
 #pragma unroll
@@ -587,7 +649,8 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
 #ifdef QD_OSD_TIMING
         if (tid == 0) {
             for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc_[i]);
-            atomicAdd(&a.dbg[8], 1ull); atomicAdd(&a.dbg[9], (unsigned long long)npiv);
+            atomicAdd(&a.dbg[8], 1ull); atomicAdd(&a.dbg[9], (unsigned long long)npiv); atomicAdd(&a.dbg[10], acc_[10]);
+            for (int i = 11; i < 15; ++i) atomicAdd(&a.dbg[i], acc_[i]);
         }
 #endif
         __syncthreads();   // LDS is recycled by the next shot
@@ -600,7 +663,7 @@ struct CsShape { int T, CPT, NWD, WPS, IPT; };
 static CsShape cs_shape(int variant)
 {
     switch (variant) {
-    case 1: return CsShape{256, 2, 8, 6, 16};
+    case 1: return CsShape{256, 2, 8, 5, 16};
     case 2: return CsShape{512, 2, 16, 4, 20};
     default: return CsShape{512, 3, 22, 2, 40};
     }
@@ -659,7 +722,7 @@ hipError_t qd_launch_osdcs(const OsdGraphDev &g, const BpGraphDev &bg, const Dec
         return hipGetLastError();                                                                                                 \
     }
     switch (variant) {
-    case 1: QD_CS_CASE(256, 2, 8, 6, 16)
+    case 1: QD_CS_CASE(256, 2, 8, 5, 16)
     case 2: QD_CS_CASE(512, 2, 16, 4, 20)
     default: QD_CS_CASE(512, 3, 22, 2, 40)
     }
