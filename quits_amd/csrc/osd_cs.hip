@@ -28,6 +28,23 @@
 #endif
 #define QD_CS_MAX_BUCKETS 32
 
+// sub-phase timers of a -DQD_OSD_TIMING build: -DQD_CS_SUB=1 (default) panel phase, 2 the sort, 3 the sweep (tools/osdcs_timing.py)
+#ifndef QD_CS_SUB
+#define QD_CS_SUB 1
+#endif
+#ifdef QD_OSD_TIMING
+#define QD_SUBT(mode, slot) if constexpr (QD_CS_SUB == mode) { const unsigned long long n2_ = wall_clock64(); acc_[slot] += n2_ - sub_; sub_ = n2_; }
+#define QD_SUBT0(mode) if constexpr (QD_CS_SUB == mode) { sub_ = wall_clock64(); }
+#else
+#define QD_SUBT(mode, slot)
+#define QD_SUBT0(mode)
+#endif
+
+// Lanes of ONE wavefront exchanging data through LDS: the hardware runs them in lockstep and completes a wavefront's LDS operations in
+// order, but the compiler reasons per thread -- it may forward a lane's own store to its later load and hoist the other lanes' load
+// above the (to them absent) store.  A wavefront-scope fence costs no instruction and forbids that.
+#define QD_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
 struct OsdCsArgs {
     int m, n, n_pad, out_words, upd_rows, ell_log2, rank;
     int osd_w, osd_order;                 // 1 = combination sweep, 2 = exhaustive
@@ -88,25 +105,32 @@ __device__ __forceinline__ void qd_cs_wave_sort(uint64_t *buf, int len, int lane
     int P = 2;
     while (P < len) P <<= 1;
     const int half = P >> 1;
-    for (int k = 2; k <= P; k <<= 1) {
+    // one pass of the network: comparator i of `half`; four comparators per lane are loaded before the first is decided (the pairs of
+    // a pass are disjoint), so a pass costs one LDS round trip per 256 comparators instead of one per 64
+    auto pass = [&](int k, int j) {                                    // j == 0: the flip step of merge size k; else half-cleaner of distance j
         const int kh = k >> 1;
-        for (int i = lane; i < half; i += 64) {
-            const int blk = i / kh, off = i - blk * kh;
-            const int lo = blk * k + off, hi = blk * k + (k - 1 - off);
-            if (hi < len) {
-                const uint64_t x = buf[lo], y = buf[hi];
-                if (x > y) { buf[lo] = y; buf[hi] = x; }
+        for (int i0 = lane; i0 < half; i0 += 256) {
+            int lo[4], hi[4];
+            uint64_t x[4], y[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u;
+                if (j == 0) { const int blk = i / kh, off = i - blk * kh; lo[u] = blk * k + off; hi[u] = blk * k + (k - 1 - off); }
+                else { lo[u] = ((i & ~(j - 1)) << 1) | (i & (j - 1)); hi[u] = lo[u] + j; }
+                ok[u] = i < half && hi[u] < len;
+                x[u] = ok[u] ? buf[lo[u]] : 0ull;
+                y[u] = ok[u] ? buf[hi[u]] : 0ull;
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ok[u] && x[u] > y[u]) { buf[lo[u]] = y[u]; buf[hi[u]] = x[u]; }
         }
-        for (int j = kh >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < half; i += 64) {
-                const int lo = ((i & ~(j - 1)) << 1) | (i & (j - 1)), hi = lo + j;
-                if (hi < len) {
-                    const uint64_t x = buf[lo], y = buf[hi];
-                    if (x > y) { buf[lo] = y; buf[hi] = x; }
-                }
-            }
-        }
+        QD_WAVE_SYNC();
+    };
+    for (int k = 2; k <= P; k <<= 1) {
+        pass(k, 0);
+        for (int j = k >> 2; j > 0; j >>= 1) pass(k, j);
     }
 }
 
@@ -167,6 +191,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
 #endif
         // ================================================================== the column order: sample sort of (key, fault) in LDS
         {
+            QD_SUBT0(2)
             const int nbk = min(QD_CS_MAX_BUCKETS, max(1, n >> 8));
             const int ns = nbk * QD_CS_NSAMP_PER_BUCKET;                     // <= 256 <= T
             auto key_of = [&](int b) -> uint64_t { return ((uint64_t)qd_mono_key(llr[b]) << 32) | (uint64_t)a.bit_orig[b]; };
@@ -189,6 +214,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 for (int step = 16; step >= 1; step >>= 1) lo += (spl[lo + step - 1] <= x) ? step : 0;
                 return lo;
             };
+            QD_SUBT(2, 11)
             uint32_t bkreg[(IPT + 3) / 4];
 #pragma unroll
             for (int i = 0; i < (IPT + 3) / 4; ++i) bkreg[i] = 0u;
@@ -202,6 +228,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 }
             }
             __syncthreads();
+            QD_SUBT(2, 12)
             if (tid < 64) {
                 // exclusive scan of the <= 32 counts (lanes 32.. carry zeros); bcnt[k] becomes the start of bucket k, bcnt[nbk .. 32] = n
                 const uint32_t c = tid < 32 ? bcnt[tid] : 0u;
@@ -212,20 +239,27 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 if (tid == 32) bcnt[32] = (uint32_t)n;
             }
             __syncthreads();                                                  // (the samples in sb[0 .. ns) are dead: everybody has its bucket numbers)
+            {
+                uint32_t pos[IPT];                                    // all the cursor bumps first, then the stores: one round trip, not IPT
 #pragma unroll
-            for (int i = 0; i < IPT; ++i) {
-                const int b = tid + i * T;
-                if (b < n) {
-                    const uint32_t bk = (bkreg[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                    sb[atomicAdd(&bcur[bk], 1u)] = key_of(b);
+                for (int i = 0; i < IPT; ++i) {
+                    const int b = tid + i * T;
+                    pos[i] = b < n ? atomicAdd(&bcur[(bkreg[i >> 2] >> (8 * (i & 3))) & 0xFFu], 1u) : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < IPT; ++i) {
+                    const int b = tid + i * T;
+                    if (b < n) sb[pos[i]] = key_of(b);
                 }
             }
             __syncthreads();
+            QD_SUBT(2, 13)
             for (int bk = wave; bk < nbk; bk += NW) {
                 const int lo = (int)bcnt[bk], hi = (int)bcnt[bk + 1];
                 qd_cs_wave_sort(sb + lo, hi - lo, lane);
             }
             __syncthreads();
+            QD_SUBT(2, 14)
             uint16_t myord[IPT];
 #pragma unroll
             for (int i = 0; i < IPT; ++i) {
@@ -320,6 +354,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 uint64_t bm = 0ull;                                    // rows that became pivot rows in this batch
                 // liveness, one lane per column: OR over the words of (column & unpivoted rows); the padded column stride keeps the 64
                 // lanes' reads of one word on different banks
+                QD_SUBT0(1)
                 uint64_t live;                                         // batch columns with a one on a row that is not a pivot row
                 {
                     uint64_t acc = 0ull;
@@ -327,17 +362,12 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     for (int ww = 0; ww < NWD; ++ww) acc |= Pc[lane * PSTR + ww] & unpm[ww];
                     live = __ballot(acc != 0ull && lane < nb);
                 }
-#ifdef QD_OSD_TIMING
-#define QD_SUB(slot) { const unsigned long long n2_ = wall_clock64(); acc_[slot] += n2_ - sub_; sub_ = n2_; }
-                sub_ = tick_;
-#else
-#define QD_SUB(slot)
-#endif
-                QD_SUB(11)
+                QD_SUBT(1, 11)
                 // rank -> column table of the live columns (chunks are consecutive rank ranges; a pivot's record keeps the rank)
                 uint32_t *tab = misc + 192;                            // [64]
                 const int nlive = (int)__popcll(live);
                 if ((live >> lane) & 1ull) tab[__popcll(live & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+                QD_WAVE_SYNC();
                 // A chunk = NR registers x NSLOT slots: the column of rank c0 + r * NSLOT + q has word w in lane (q * LPS + w) of x[r].  A pivot's
                 // image goes through Tp (it has to be stored there anyway) back into every slot; whether a register's columns hold the
                 // pivot row is one ballot per register: the bit sits in lane (slot * LPS + w0).
@@ -360,6 +390,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                         if ((bal >> sh) & 1ull) v ^= tq;
                     };
                     if (g > 0) {
+                        QD_WAVE_SYNC();
                         uint32_t flag = 0u;
 #pragma unroll
                         for (int r = 0; r < NR; ++r)
@@ -376,7 +407,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                                     if ((flag >> r) & 1u) apply_row(x[r], tq, pbit, sh, isw);
                             }
                     }
-                    QD_SUB(12)
+                    QD_SUBT(1, 12)
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
                         for (int q = 0; q < NSLOT; ++q) {
@@ -391,21 +422,41 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                             const int p = w0 * 64 + pbit;
                             const uint64_t pb = 1ull << pbit;
                             const bool isw = w == w0;
-                            if (s == q && wv) Tp[g * NWD + w] = x[r] ^ (isw ? pb : 0ull);      // the image without bit p
+                            // the image without bit p: stored for phase [C], and copied from slot q into every slot -- by two lane-swap
+                            // instructions per half (rows of 16 lanes, halves of 32), no LDS round trip; 8-lane slots go through LDS
+                            uint64_t tq = x[r] ^ (isw ? pb : 0ull);
+                            if (s == q && wv) Tp[g * NWD + w] = tq;
+                            if constexpr (LPS == 8) { QD_WAVE_SYNC(); tq = wv ? Tp[g * NWD + w] : 0ull; }
+                            else {
+                                uint32_t lo = (uint32_t)tq, hi = (uint32_t)(tq >> 32);
+                                if constexpr (LPS == 16) {
+                                    const auto a1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+                                    const auto a2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+                                    lo = (q & 1) ? a1[1] : a1[0];
+                                    hi = (q & 1) ? a2[1] : a2[0];
+                                }
+                                const int qh = LPS == 16 ? (q >> 1) : q;
+                                const auto b1 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+                                const auto b2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+                                lo = qh ? b1[1] : b1[0];
+                                hi = qh ? b2[1] : b2[0];
+                                tq = ((uint64_t)hi << 32) | (uint64_t)lo;
+                            }
                             if (lane == 0) pivp[g] = (uint32_t)p | ((uint32_t)(c0 + r * NSLOT + q) << 16);
                             if (isw) { unp &= ~pb; bm |= pb; }
-                            const uint64_t tq = wv ? Tp[g * NWD + w] : 0ull;                   // ... back into every slot
                             const int sh = w0 + LPS * s;
                             apply_row(svr, tq, pbit, sh, isw);
 #pragma unroll
-                            for (int r2 = r; r2 < NR; ++r2) apply_row(x[r2], tq, pbit, sh, isw);   // (columns already passed are dead: harmless)
+                            for (int r2 = r; r2 < NR; ++r2)
+                                if (c0 + r2 * NSLOT < nlive) apply_row(x[r2], tq, pbit, sh, isw);  // (columns already passed are dead: harmless)
                             ++g;
                         }
                     }
-                    QD_SUB(13)
+                    QD_SUBT(1, 13)
                 }
                 if (s == 0 && wv) { unpm[w] = unp; sv[w] = svr; }
                 if (lane == 0) misc[0] = (uint32_t)g;
+                QD_WAVE_SYNC();
                 if (lane < g) {                                        // the pivots' records, one lane each (pivp: same wavefront, LDS in order)
                     const uint32_t pj = pivp[lane];
                     const int p = (int)(pj & 0xFFFFu), K = npiv + lane;
@@ -415,7 +466,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     rowpiv[p] = (int16_t)K; prow[K] = (uint16_t)p; pcol[K] = (uint16_t)pc;
                     atomicOr(&pivmask[pc >> 5], 1u << (pc & 31u));
                 }
-                QD_SUB(14)
+                QD_SUBT(1, 14)
                 __builtin_amdgcn_s_setprio(0);
             }
             QD_TICK(2)
@@ -424,20 +475,12 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             // ---- [C] every Q column takes the batch's pivots, in order: a column that has bit p set gets the pivot's image added (bit p stays:
             // the image is stored without it); column K, all zero until now, becomes that image.  The image travels in scalar registers.
             const int g = (int)misc[0];
-            uint32_t pj_n = g > 0 ? pivp[0] : 0u;
-            uint64_t tl_n = (g > 0 && lane < NWD) ? Tp[lane] : 0ull;
             for (int i = 0; i < g; ++i) {
                 const int K = npiv + i;
-                const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pj_n);
-                const uint64_t tl = tl_n;
-                if (i + 1 < g) {                                       // the next pivot's record and image are on their way while this one is applied
-                    pj_n = pivp[i + 1];
-                    tl_n = lane < NWD ? Tp[(i + 1) * NWD + lane] : 0ull;
-                }
                 if (wave * 64 > K) continue;                           // none of this wavefront's columns exists yet (uniform)
+                const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pivp[i]);
                 const int p = (int)(pj & 0xFFFFu), pw = p >> 6;
                 const uint64_t pb = 1ull << (p & 63);
-                const uint32_t tl_lo = (uint32_t)tl, tl_hi = (uint32_t)(tl >> 32);
                 uint64_t sel[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) sel[c] = 0ull;
@@ -454,22 +497,21 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     const int k = tid + c * T;
                     hit[c] = (k < K && (sel[c] & pb) != 0ull) || k == K;
                 }
-                // eight words of the image at a time through scalar registers (16 SGPRs live, not 2 NWD)
+                // the image comes as broadcast LDS reads (every lane the same address): the LDS pipe is idle in this phase, the vector ALU
+                // is what bounds it (the first form moved the words through v_readlane: a quarter of this loop's instructions)
+                const uint64_t *tq = Tp + i * NWD;
 #pragma unroll
                 for (int wb = 0; wb < NWD; wb += 8) {
-                    uint32_t tlo[8], thi[8];
+                    uint64_t tv_[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
-                        if (wb + u < NWD) {
-                            tlo[u] = (uint32_t)__builtin_amdgcn_readlane((int)tl_lo, wb + u);
-                            thi[u] = (uint32_t)__builtin_amdgcn_readlane((int)tl_hi, wb + u);
-                        }
+                        if (wb + u < NWD) tv_[u] = tq[wb + u];
 #pragma unroll
                     for (int c = 0; c < CPT; ++c)
                         if (hit[c]) {
 #pragma unroll
                             for (int u = 0; u < 8; ++u)
-                                if (wb + u < NWD) mycol[c][wb + u] ^= ((uint64_t)thi[u] << 32) | (uint64_t)tlo[u];
+                                if (wb + u < NWD) mycol[c][wb + u] ^= tv_[u];
                         }
                 }
             }
@@ -483,6 +525,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         }
         // ================================================================== OSD-0 solution, then the candidate sweep
         // residual on a non-pivot row <=> syndrome outside the column space (the answer is still the oracle's: same pivot rule)
+        QD_SUBT0(3)
         if (tid < NWD && (sv[tid] & unpm[tid]) != 0ull) atomicOr(&misc[2], 1u);      // (misc[0..63] was cleared at the head of the shot)
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
@@ -508,8 +551,11 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             nib[x] = s;
         }
         __syncthreads();
+        QD_SUBT(3, 11)
         const int nnp_all = n - npiv;
         // image of fault `col` under the complete transform, restricted to nothing: t ^= XOR over its pivoted rows r of (Q column of r + e_r)
+        // image of fault `col` under the complete transform: t ^= XOR over its pivoted rows r of (Q column of r + e_r).  One thread, whole
+        // vector: the patterns' base vectors and the winner only (the single-column candidates use the four-lane form below)
         auto add_col = [&](uint32_t col, uint64_t t[NWD]) {
             for (int q = 0; q < ellw; ++q) {
                 const uint32_t r = a.csc_ell[((size_t)col << dlog) + q];
@@ -520,7 +566,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 const int rw = (int)(r >> 6);
                 const uint64_t rb = 1ull << (r & 63u);
 #pragma unroll
-                for (int w = 0; w < NWD; ++w) t[w] ^= src[w] ^ ((w == rw) ? rb : 0ull);
+                for (int ww = 0; ww < NWD; ++ww) t[ww] ^= src[ww] ^ ((ww == rw) ? rb : 0ull);
             }
         };
         auto wsum = [&](const uint64_t t[NWD]) -> long long {
@@ -540,18 +586,77 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         };
         CsBest best{0x7FFFFFFFFFFFFFFFll, 3u, ~0ull, 0ull};
         if (a.osd_w == 1) {
-            // ---- singles: every non-pivot column; ties go to the earlier position of the order (ldpc's enumeration order)
-            for (int i = tid; i < n; i += T) {
-                const uint32_t col = order[i];
-                if ((pivmask[col >> 5] >> (col & 31u)) & 1u) continue;
-                uint64_t t[NWD];
+            // ---- singles: every non-pivot column; ties go to the earlier position of the order (ldpc's enumeration order).  FOUR lanes per
+            // candidate, WPL words of the image each: a lane reads 16-byte pieces of the Q columns' lines, so one load instruction touches
+            // 16 lines instead of 64 (the L1 looks up one line per clock: with a lane per candidate that lookup rate, not bandwidth, was
+            // 13 % of a shot); the four partial sums meet by two lane exchanges.
+            constexpr int WPL = (NWD + 3) / 4;
+            const int sub = lane & 3, wbase = sub * WPL;
+            for (int i0 = 0; i0 < n; i0 += T / 4) {
+                const int i = i0 + (tid >> 2);
+                uint32_t col = 0u;
+                bool cand = false;
+                if (i < n) { col = order[i]; cand = !((pivmask[col >> 5] >> (col & 31u)) & 1u); }
+                if (__ballot(cand) == 0ull) continue;
+                uint64_t t[WPL];
 #pragma unroll
-                for (int w = 0; w < NWD; ++w) t[w] = 0ull;
-                add_col(col, t);
-                const long long d = wsum(t) + (long long)a.wfix[col];
-                if (qd_cs_less(d, 1u, (unsigned long long)i, best.delta, best.cls, best.tie)) best = CsBest{d, 1u, (unsigned long long)i, (unsigned long long)col};
+                for (int u = 0; u < WPL; ++u) t[u] = 0ull;
+                if (cand) {
+                    uint32_t wds[8];
+                    if (dlog >= 3) {
+                        const uint4 *e4 = reinterpret_cast<const uint4 *>(a.csc_ell + ((size_t)col << dlog));
+                        const uint4 v0 = e4[0];
+                        uint4 v1 = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                        if (dlog == 4) v1 = e4[1];
+                        wds[0] = v0.x; wds[1] = v0.y; wds[2] = v0.z; wds[3] = v0.w; wds[4] = v1.x; wds[5] = v1.y; wds[6] = v1.z; wds[7] = v1.w;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const uint32_t e0 = 2 * q < ellw ? (uint32_t)a.csc_ell[((size_t)col << dlog) + 2 * q] : 0xFFFFu;
+                            const uint32_t e1 = 2 * q + 1 < ellw ? (uint32_t)a.csc_ell[((size_t)col << dlog) + 2 * q + 1] : 0xFFFFu;
+                            wds[q] = e0 | (e1 << 16);
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const uint32_t r = (q & 1) ? (wds[q >> 1] >> 16) : (wds[q >> 1] & 0xFFFFu);
+                        if (q >= ellw || __ballot(r != 0xFFFFu) == 0ull) break;        // (rows ascend: nothing behind the first padding entry)
+                        const int k = r != 0xFFFFu ? (int)rowpiv[r] : -1;                // (a non-pivot row weighs nothing)
+                        if (k >= 0) {
+                            const uint64_t *src = mt + (size_t)k * NWD + wbase;
+                            const int rw = (int)(r >> 6) - wbase;
+                            const uint64_t rb = 1ull << (r & 63u);
+#pragma unroll
+                            for (int u = 0; u < WPL; ++u)
+                                if (NWD % 4 == 0 || wbase + u < NWD) t[u] ^= src[u] ^ ((u == rw) ? rb : 0ull);
+                        }
+                    }
+                }
+                long long part = 0;
+#pragma unroll
+                for (int u = 0; u < WPL; ++u) {
+                    const int ww = wbase + u;
+                    if (NWD % 4 == 0 || ww < NWD) {
+                        const uint32_t lo = (uint32_t)t[u], hi = (uint32_t)(t[u] >> 32);
+                        int32_t sacc = 0;                              // 16 nibbles x 4 weights below 2^25 each: no overflow (checked by the host)
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            sacc += nib[((ww * 16 + q) << 4) + ((lo >> (4 * q)) & 15u)];
+                            sacc += nib[((ww * 16 + 8 + q) << 4) + ((hi >> (4 * q)) & 15u)];
+                        }
+                        part += (long long)sacc;
+                    }
+                }
+#pragma unroll
+                for (int sh = 1; sh <= 2; sh <<= 1)
+                    part += ((long long)__shfl_xor((int)(part >> 32), sh) << 32) | (uint32_t)__shfl_xor((int)part, sh);
+                if (cand && sub == 0) {
+                    const long long d = part + (long long)a.wfix[col];
+                    if (qd_cs_less(d, 1u, (unsigned long long)i, best.delta, best.cls, best.tie)) best = CsBest{d, 1u, (unsigned long long)i, (unsigned long long)col};
+                }
             }
         }
+        QD_SUBT(3, 12)
         // ---- patterns over the first lam non-pivot columns of the order: pairs (combination sweep) or all subsets (exhaustive)
         const int lam = min(min(a.osd_order, nnp_all), 64);
         uint32_t *npl = misc + 256;                                    // [64] the first lam non-pivot faults of the order
@@ -602,6 +707,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 if (qd_cs_less(d, 2u, ic, best.delta, best.cls, best.tie)) best = CsBest{d, 2u, ic, pat};
             }
         }
+        QD_SUBT(3, 13)
         // ---- winner: wavefront minimum by shuffles, then the NW partials
 #pragma unroll
         for (int sh = 32; sh >= 1; sh >>= 1) {
@@ -645,6 +751,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         __syncthreads();
         for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = outw[w];
         if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (misc[2] ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
+        QD_SUBT(3, 14)
         QD_TICK(4)
 #ifdef QD_OSD_TIMING
         if (tid == 0) {

@@ -30,5 +30,8 @@ print("fixture %s  window %s  %d x %d" % (name, os.environ.get("WINDOW", "whole"
 print("osd kernel ms %.2f, shots in OSD %d, mean pivots %.1f, batches per shot %.1f, ticks per shot %.0f (100 MHz)" % (pr["osd_ms"], c[8], c[9] / shots, c[10] / shots, tot / shots))
 for i, nme in enumerate(names):
     print("%-34s %6.1f %%   %8.0f ticks/shot   %7.1f ticks/batch" % (nme, 100.0 * c[i] / tot, c[i] / shots, c[i] / max(c[10], 1)))
-for i, nme in ((11, "[B] liveness sweep"), (12, "[B] chunk load + earlier pivots"), (13, "[B] chunk columns in order"), (14, "[B] write-back + records")):
+SUB = {"1": ((11, "[B] liveness sweep"), (12, "[B] chunk load + earlier pivots"), (13, "[B] chunk columns in order"), (14, "[B] write-back + records")),
+       "2": ((11, "sort: samples + splitters"), (12, "sort: bucket numbers + counts"), (13, "sort: scan + scatter"), (14, "sort: bucket sorts")),
+       "3": ((11, "sweep: residual, Q dump, weight tables"), (12, "sweep: single columns"), (13, "sweep: patterns"), (14, "sweep: winner + output"))}
+for i, nme in SUB[os.environ.get("QD_CS_SUB", "1")]:
     print("%-34s %6.1f %%   %8.0f ticks/shot   %7.1f ticks/batch" % (nme, 100.0 * c[i] / tot, c[i] / shots, c[i] / max(c[10], 1)))
