@@ -81,7 +81,10 @@ struct CsLds {
     static constexpr int o_var = o_misc + 2048;                     // pivmask [out_words], then out, then order (runtime sizes)
     static constexpr int o_swl = o_p;                               // [NWD * 64] i32
     static constexpr int o_nib = o_swl + NWD * 64 * 4;              // [NWD * 16][16] i32
-    static constexpr int o_tv = o_nib + NWD * 256 * 4;              // [64][NWD] u64
+    // the nibble tables of one 64-row word take 256 entries; each word's block is shifted by NIBS entries so that the four lanes of a
+    // candidate (words sub * WPL + u) read four different quarters of the 64 banks: WPL * NIBS = 16 (mod 64)
+    static constexpr int WPL = (NWD + 3) / 4, NIBS = WPL == 6 ? 24 : 16 / WPL, NIBW = 256 + NIBS;
+    static constexpr int o_tv = o_nib + ((NWD * NIBW * 4 + 15) & ~15);   // [64][NWD] u64
     static_assert(o_tv + 64 * NWD * 8 <= o_tp, "the sweep's tables must fit over the panel and need buffers");
     static_assert((NWD * 8) % 16 == 0 && (o_need % 16) == 0 && (o_tp % 16) == 0 && (o_var % 16) == 0, "16-byte alignment");
 };
@@ -150,9 +153,6 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
 
     using L = CsLds<T, CPT, NWD>;
     uint64_t *sb = reinterpret_cast<uint64_t *>(smem);                                   // [n] sort buffer (the sort phase owns all of LDS)
-    uint64_t *spl = reinterpret_cast<uint64_t *>(smem + a.o_sort_aux);                   // [32] splitters
-    uint32_t *bcnt = reinterpret_cast<uint32_t *>(smem + a.o_sort_aux + 256);            // [33] bucket starts
-    uint32_t *bcur = bcnt + 40;                                                          // [32] bucket cursors
     uint16_t *order = reinterpret_cast<uint16_t *>(smem + a.o_order);                    // [n] faults in sorted order
     uint64_t *Pbuf = reinterpret_cast<uint64_t *>(smem + L::o_p);                        // [2][64][PSTR] panel: images of the batch's columns, by row
     uint64_t *needb = reinterpret_cast<uint64_t *>(smem + L::o_need);                    // [2][NPIV] pivot order -> batch columns that contain its row
@@ -163,13 +163,11 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
     uint16_t *prow = reinterpret_cast<uint16_t *>(smem + L::o_prow);                     // [NPIV] pivot order -> row
     uint16_t *pcol = reinterpret_cast<uint16_t *>(smem + L::o_pcol);                     // [NPIV] pivot order -> fault
     uint32_t *pivmask = reinterpret_cast<uint32_t *>(smem + L::o_var);                   // [out_words] faults that are pivot columns
-    uint32_t *outw = reinterpret_cast<uint32_t *>(smem + a.o_out);                       // [out_words]
     uint32_t *misc = reinterpret_cast<uint32_t *>(smem + L::o_misc);                     // [0] pivots of the batch, [64..127] pivp, [128..] bests, [256..] npl
     uint32_t *pivp = misc + 64;                                                          // [64] pivot row | batch column << 16
     int32_t *swl = reinterpret_cast<int32_t *>(smem + L::o_swl);                         // [NWD * 64] signed pivot weight of a row (sweep)
     int32_t *nib = reinterpret_cast<int32_t *>(smem + L::o_nib);                         // [NWD * 16][16] sums of swl over the rows of a nibble (sweep)
     uint64_t *tvl = reinterpret_cast<uint64_t *>(smem + L::o_tv);                        // [64][NWD] images of the first non-pivot columns (patterns)
-    uint64_t *mt = a.ws + (size_t)blockIdx.x * a.ws_words;                               // [NPIV][NWD] Q columns, for the sweep (L2-resident)
 
     const int nfail = *a.fail_count;
     for (int item = blockIdx.x; item < nfail; item += gridDim.x) {
@@ -192,6 +190,9 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         // ================================================================== the column order: sample sort of (key, fault) in LDS
         {
             QD_SUBT0(2)
+            uint64_t *spl = reinterpret_cast<uint64_t *>(smem + a.o_sort_aux);                   // [32] splitters
+            uint32_t *bcnt = reinterpret_cast<uint32_t *>(smem + a.o_sort_aux + 256);            // [33] bucket starts
+            uint32_t *bcur = bcnt + 40;                                                          // [32] bucket cursors
             const int nbk = min(QD_CS_MAX_BUCKETS, max(1, n >> 8));
             const int ns = nbk * QD_CS_NSAMP_PER_BUCKET;                     // <= 256 <= T
             auto key_of = [&](int b) -> uint64_t { return ((uint64_t)qd_mono_key(llr[b]) << 32) | (uint64_t)a.bit_orig[b]; };
@@ -288,7 +289,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             unpm[tid] = (m - lo >= 64) ? ~0ull : (m > lo ? ((1ull << (m - lo)) - 1ull) : 0ull);
         }
         for (int r = tid; r < NWD * 64; r += T) rowpiv[r] = -1;
-        for (int w = tid; w < a.out_words; w += T) { outw[w] = 0u; pivmask[w] = 0u; }
+        for (int w = tid; w < a.out_words; w += T) { reinterpret_cast<uint32_t *>(smem + a.o_out)[w] = 0u; pivmask[w] = 0u; }
         if (tid < 64) misc[tid] = 0u;
         __syncthreads();
         for (int r = tid; r < m; r += T) {
@@ -371,7 +372,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 // A chunk = NR registers x NSLOT slots: the column of rank c0 + r * NSLOT + q has word w in lane (q * LPS + w) of x[r].  A pivot's
                 // image goes through Tp (it has to be stored there anyway) back into every slot; whether a register's columns hold the
                 // pivot row is one ballot per register: the bit sits in lane (slot * LPS + w0).
-                constexpr int NR = NWD <= 8 ? 4 : 8, CHC = NR * NSLOT;
+                constexpr int NR = NWD <= 8 ? 4 : (NWD <= 16 ? 7 : 8), CHC = NR * NSLOT;   // (7, not 8, at 16 words: the eighth row costs the 128-register instantiation its zero scratch)
                 int g = 0;
                 const int room = a.rank - npiv;
                 for (int c0 = 0; c0 < nlive && g < room; c0 += CHC) {
@@ -526,6 +527,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         // ================================================================== OSD-0 solution, then the candidate sweep
         // residual on a non-pivot row <=> syndrome outside the column space (the answer is still the oracle's: same pivot rule)
         QD_SUBT0(3)
+        uint64_t *mt = a.ws + (size_t)blockIdx.x * a.ws_words;                                   // [NPIV][NWD] Q columns, for the sweep (L2-resident)
         if (tid < NWD && (sv[tid] & unpm[tid]) != 0ull) atomicOr(&misc[2], 1u);      // (misc[0..63] was cleared at the head of the shot)
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
@@ -548,7 +550,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             int32_t s = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) s += ((pat >> b) & 1) ? swl[nb4 * 4 + b] : 0;
-            nib[x] = s;
+            nib[(x >> 8) * L::NIBW + (x & 255)] = s;                  // word (x >> 8), nibble position, pattern
         }
         __syncthreads();
         QD_SUBT(3, 11)
@@ -577,8 +579,8 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 int32_t s = 0;                                         // 16 nibbles x 4 weights below 2^25 each: no overflow (checked by the host)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    s += nib[((w * 16 + q) << 4) + ((lo >> (4 * q)) & 15u)];
-                    s += nib[((w * 16 + 8 + q) << 4) + ((hi >> (4 * q)) & 15u)];
+                    s += nib[w * L::NIBW + (q << 4) + ((lo >> (4 * q)) & 15u)];
+                    s += nib[w * L::NIBW + ((8 + q) << 4) + ((hi >> (4 * q)) & 15u)];
                 }
                 tot += (long long)s;
             }
@@ -617,18 +619,30 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                             wds[q] = e0 | (e1 << 16);
                         }
                     }
+                    // four incidences at a time: their pivot orders, then their pieces of the Q columns, all in flight before the first is
+                    // added (one candidate used to be a chain of up to eight dependent L2 round trips)
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const uint32_t r = (q & 1) ? (wds[q >> 1] >> 16) : (wds[q >> 1] & 0xFFFFu);
-                        if (q >= ellw || __ballot(r != 0xFFFFu) == 0ull) break;        // (rows ascend: nothing behind the first padding entry)
-                        const int k = r != 0xFFFFu ? (int)rowpiv[r] : -1;                // (a non-pivot row weighs nothing)
-                        if (k >= 0) {
-                            const uint64_t *src = mt + (size_t)k * NWD + wbase;
-                            const int rw = (int)(r >> 6) - wbase;
-                            const uint64_t rb = 1ull << (r & 63u);
+                    for (int q0 = 0; q0 < 16; q0 += 4) {
+                        uint32_t r4[4];
 #pragma unroll
-                            for (int u = 0; u < WPL; ++u)
-                                if (NWD % 4 == 0 || wbase + u < NWD) t[u] ^= src[u] ^ ((u == rw) ? rb : 0ull);
+                        for (int u4 = 0; u4 < 4; ++u4) { const int q = q0 + u4; r4[u4] = (q & 1) ? (wds[q >> 1] >> 16) : (wds[q >> 1] & 0xFFFFu); }
+                        if (q0 >= ellw || __ballot(r4[0] != 0xFFFFu) == 0ull) break;      // (rows ascend: nothing behind the first padding entry)
+                        int k4[4];
+#pragma unroll
+                        for (int u4 = 0; u4 < 4; ++u4) k4[u4] = r4[u4] != 0xFFFFu ? (int)rowpiv[r4[u4]] : -1;   // (a non-pivot row weighs nothing)
+                        uint64_t v4[4][WPL];
+#pragma unroll
+                        for (int u4 = 0; u4 < 4; ++u4) {
+                            const uint64_t *src = mt + (size_t)(k4[u4] >= 0 ? k4[u4] : 0) * NWD + wbase;
+#pragma unroll
+                            for (int u = 0; u < WPL; ++u) v4[u4][u] = (k4[u4] >= 0 && (NWD % 4 == 0 || wbase + u < NWD)) ? src[u] : 0ull;
+                        }
+#pragma unroll
+                        for (int u4 = 0; u4 < 4; ++u4) {
+                            const int rw = k4[u4] >= 0 ? (int)(r4[u4] >> 6) - wbase : -1;
+                            const uint64_t rb = 1ull << (r4[u4] & 63u);
+#pragma unroll
+                            for (int u = 0; u < WPL; ++u) t[u] ^= v4[u4][u] ^ ((u == rw) ? rb : 0ull);
                         }
                     }
                 }
@@ -641,8 +655,8 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                         int32_t sacc = 0;                              // 16 nibbles x 4 weights below 2^25 each: no overflow (checked by the host)
 #pragma unroll
                         for (int q = 0; q < 8; ++q) {
-                            sacc += nib[((ww * 16 + q) << 4) + ((lo >> (4 * q)) & 15u)];
-                            sacc += nib[((ww * 16 + 8 + q) << 4) + ((hi >> (4 * q)) & 15u)];
+                            sacc += nib[ww * L::NIBW + (q << 4) + ((lo >> (4 * q)) & 15u)];
+                            sacc += nib[ww * L::NIBW + ((8 + q) << 4) + ((hi >> (4 * q)) & 15u)];
                         }
                         part += (long long)sacc;
                     }
@@ -741,15 +755,15 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             const int r = (int)prow[k];
             if ((((sv[r >> 6] ^ twin[r >> 6]) >> (r & 63)) & 1ull) != 0ull) {
                 const uint32_t j = pcol[k];
-                atomicOr(&outw[j >> 5], 1u << (j & 31u));
+                atomicOr(&reinterpret_cast<uint32_t *>(smem + a.o_out)[j >> 5], 1u << (j & 31u));
             }
         }
         if (tid == 0 && take) {
-            if (win.cls == 1u) atomicOr(&outw[(uint32_t)win.what >> 5], 1u << ((uint32_t)win.what & 31u));
-            else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) atomicOr(&outw[npl[b] >> 5], 1u << (npl[b] & 31u));
+            if (win.cls == 1u) atomicOr(&reinterpret_cast<uint32_t *>(smem + a.o_out)[(uint32_t)win.what >> 5], 1u << ((uint32_t)win.what & 31u));
+            else for (int b = 0; b < lam; ++b) if ((win.what >> b) & 1ull) atomicOr(&reinterpret_cast<uint32_t *>(smem + a.o_out)[npl[b] >> 5], 1u << (npl[b] & 31u));
         }
         __syncthreads();
-        for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = outw[w];
+        for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = reinterpret_cast<uint32_t *>(smem + a.o_out)[w];
         if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (misc[2] ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
         QD_SUBT(3, 14)
         QD_TICK(4)

@@ -195,6 +195,25 @@ def test_osd_sr_kernel_instantiations_use_no_scratch(tmp_path):
     assert len(kern) >= 8 and all(sc == 0 for _, sc in kern), kern
 
 
+def test_osdcs_kernel_instantiations_use_no_scratch(tmp_path):
+    """the rebuilt OSD-CS / OSD-E kernel (osd_cs.hip, qd_osdcs_kernel) -- the reference wrapper's default post-processor
+    (bposd.py:54 osd_method='osd_cs') -- reports ScratchSize 0 in all three instantiations (the kernel it replaces spilled 648-684 bytes
+    per lane)."""
+    import re
+    import subprocess
+    cs = os.path.join(ROOT, "quits_amd", "csrc")
+    mk = open(os.path.join(cs, "Makefile")).read()
+    flags = re.search(r"^FLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split()
+    flags = [f for f in flags if f != "-shared"]
+    out = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", "-o",
+                          str(tmp_path / "osd_cs.o"), os.path.join(cs, "osd_cs.hip")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    kern = [(n, sc) for n, sc in zip(names, scratch) if "qd_osdcs_kernel" in n]
+    assert len(kern) == 3 and all(sc == 0 for _, sc in kern), kern
+
+
 def test_plan_cache_is_per_thread_and_keyed_on_the_device(monkeypatch):
     """a cached plan carries mutable state (staging buffers, side streams, decoder workspaces) and is bound to the
     device it was built on -- so the key holds the current device and every thread has its own cache."""
