@@ -110,7 +110,7 @@ int qd_decoder_info(const qd_decoder *d, int32_t *info);
 #define QD_POST_NONE 0          /* osd_method = osd_off                                                                          */
 #define QD_POST_OSD0_SR 1       /* OSD-0, many pivots per barrier round: qd_osd0_sr_kernel (osd_sr.hip)                          */
 #define QD_POST_OSD0_REG 2      /* OSD-0, one pivot per round: qd_osd0_reg_kernel (osd_kernels.hip)                              */
-#define QD_POST_OSD_W_OLD 3     /* OSD-CS / OSD-E, rounds 2-4: qd_osdw_col_kernel / the row form (osd_kernels.hip)               */
+#define QD_POST_OSD_W_OLD 3     /* OSD-CS / OSD-E by row (qd_osd0_reg_kernel<.., true>, osd_kernels.hip): windows the panel kernel does not take */
 #define QD_POST_OSD_CS_PANEL 4  /* OSD-CS / OSD-E, round 5: qd_osdcs_kernel (osd_cs.hip), one panel of 64 sorted columns at a time */
 #define QD_POST_LSD 5           /* BP-LSD: qd_lsd0_kernel (lsd_kernels.hip)                                                      */
 int qd_decoder_postproc_kernel(const qd_decoder *d);

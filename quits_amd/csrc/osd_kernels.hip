@@ -458,10 +458,7 @@ __device__ __noinline__ void qd_osd_sweep(const OsdRegArgs &a, unsigned char *sm
 // reduction per 32 candidates, only one for the winner.  The transpose goes through a global scratch (64 x 64 bit blocks,
 // one per wavefront at a time) and replaces Q in LDS.  Same costs, same tie rule, same result as qd_osd_sweep.
 // SW = pivot-order words a candidate vector may span: 16 (rank <= 1024) or 32 (rank <= 2048)
-// ROWS: the caller (qd_osdw_col_kernel) already holds Q by column, bits indexed by ROW instead of pivot order, and has put
-// column j at mt[j * mw .. + mw) (global scratch, L2-resident: one 128-byte line per incidence).  Then candidate vectors, the
-// signed weights and the winner's vector are indexed by row as well (non-pivot rows weigh 0); nothing else changes.
-template <int T, int SW, bool ROWS = false>
+template <int T, int SW>
 __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *smem, const float *llr, uint64_t *qglb, uint64_t *mt,
                                             int npiv, int nnp)
 {
@@ -477,11 +474,10 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     SweepBest *bests = reinterpret_cast<SweepBest *>(scr2);                  // [NW]
     uint64_t *twin = reinterpret_cast<uint64_t *>(scr2 + 1024);              // [SW] winner's vector
     const int m_pad = a.m_pad, kw_lds = a.f_kw, n = a.n;
-    const int Wp = ROWS ? a.mw : (npiv + 63) >> 6;
+    const int Wp = (npiv + 63) >> 6;
     uint64_t *tv = mt + (size_t)a.mw * m_pad;                                // [64][SW] vectors of the first non-pivot columns
 
     // ---- MT = transpose of (Q rows in pivot order), block by block
-    if constexpr (!ROWS)
     for (int bi = tid >> 6; bi < Wp * Wp; bi += NW) {
         const int kb = bi / Wp, jb = bi - kb * Wp;
         const int k = kb * 64 + lane;
@@ -498,10 +494,7 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     }
     for (int k = tid; k < Wp * 64; k += T) {
         int32_t v = 0;
-        if (ROWS) {
-            const int j = k < a.m ? (int)S.rowpiv[k] : -1;
-            if (j >= 0) { const int32_t w = (int32_t)a.wfix[S.pcol[j]]; v = S.sp[k] ? -w : w; }
-        } else if (k < npiv) {
+        if (k < npiv) {
             const int32_t w = (int32_t)a.wfix[S.pcol[k]];
             v = S.sp[S.prow[k]] ? -w : w;                  // a pivot that is on in the OSD-0 solution gets cheaper when flipped
         }
@@ -510,7 +503,7 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     __syncthreads();                                       // every Q word has been read, every MT word written
     // (word kw_lds, when the rank needs one more plane than Q had in LDS, goes where the batch words lived: S.tb is idle now)
     // words beyond that stay in the scratch (L2)
-    if constexpr (!ROWS) {
+    {
         for (int i = tid; i < min(Wp, kw_lds + 1) * m_pad; i += T) {
             if (i < kw_lds * m_pad) S.q[i] = mt[i];
             else S.tb[i - kw_lds * m_pad] = mt[i];
@@ -524,13 +517,12 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
             const int rr = a.csc_row[e];
             const int j = S.rowpiv[rr];
             if (j < 0) continue;
-            const int eb = ROWS ? rr : j;                                    // where the identity part of the column sits
+            const int eb = j;                                                // where the identity part of the column sits
 #pragma unroll
             for (int w = 0; w < SW; ++w)
                 if (w < Wp) {                                               // (uniform branches: no speculative loads)
                     uint64_t v;
-                    if (ROWS) v = mt[(size_t)j * a.mw + w];                  // column j, contiguous (L2)
-                    else if (w < kw_lds) v = S.q[(size_t)w * m_pad + j];
+                    if (w < kw_lds) v = S.q[(size_t)w * m_pad + j];
                     else if (w == kw_lds) v = S.tb[j];
                     else v = mt[(size_t)w * m_pad + j];
                     t[w] ^= v ^ ((w == (eb >> 6)) ? (1ull << (eb & 63)) : 0ull);
@@ -630,7 +622,7 @@ __device__ __noinline__ void qd_osd_sweep_t(const OsdRegArgs &a, unsigned char *
     }
     __syncthreads();
     for (int k = tid; k < npiv; k += T) {
-        const int tbit = ROWS ? (int)S.prow[k] : k;
+        const int tbit = k;
         if ((uint32_t)S.sp[S.prow[k]] ^ (uint32_t)((twin[tbit >> 6] >> (tbit & 63)) & 1ull)) {
             const uint32_t j = S.pcol[k];
             atomicOr(&S.outw[j >> 5], 1u << (j & 31u));
@@ -1177,259 +1169,6 @@ __global__ void __launch_bounds__(T, (WFULL ? T / 256 : QD_OSD0_WPS)) qd_osd0_re
     }
 }
 
-// ---- higher-order OSD, elimination by COLUMN -----------------------------------------------------------------------------
-// OSD-CS / OSD-E need the complete factorisation: ~8000 columns go through the transform at the headline window before the
-// last pivot turns up, and with Q stored by row every (column, pivoted row) incidence costs one word read per ROW
-// (qd_osd0_reg_kernel<.., true>: 77 % of its time).  Here Q is stored by column: thread k keeps column k of Q -- the m-bit
-// vector {r : pivot row k was added to row r} -- in registers, and
-//   * the image of a sorted column c is  t_c = h_c xor XOR_{pivoted rows r of c} Qcol[order(r)]:  NWD word XORs per
-//     incidence instead of m bit extractions.  The owner of Qcol[k] adds it (LDS atomics) to the pending columns that contain
-//     pivot row k; which ones is one 64-bit word per pivot, HP[k], scattered from the batch's 64 sparse columns;
-//   * a pivot (row p, image t' = t_c without bit p) turns  Q[r] ^= Q[p] ^ e_K for r in t'  into: every column that has bit p
-//     set gets t' added -- Qcol[k] (its owner tests its own register), the pending columns of the batch and the syndrome --
-//     and Qcol[K] = t'.  Bit p is the one bit these updates leave alone, so testing it needs no ordering;
-//   * two barriers per pivot: [first unpivoted row of every pending column -> LDS minimum per column] | every wavefront
-//     picks the first live column and everybody applies its pivot |.  Dependent columns never show up and cost nothing.
-// Same column order (qd_osd_draw_tier), same pivot rule (first independent column, lowest unpivoted row), hence the same
-// pivots, rows and transformed syndrome as the row-wise kernel; the sweep runs on the columns as they are (ROWS form above).
-// T threads hold CPT columns each (rank <= T * CPT), NWD words per column (m <= 64 * NWD).  LDS holds only the batch and the
-// bookkeeping (~50 KB at the headline window), so two workgroups share a CU when the columns leave room in the registers.
-template <int T, int CPT, int NWD, int WPS>                   // WPS: wavefronts per SIMD the register budget is cut for
-__global__ void __launch_bounds__(T, WPS) qd_osdw_col_kernel(OsdRegArgs a)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int nfail = a.slot_list ? *a.slot_count : *a.fail_count;
-    OsdLds S;
-    qd_osd_carve(smem, a.off, S);
-    uint64_t *sortbuf = reinterpret_cast<uint64_t *>(smem + a.off_sort);
-    uint16_t *order = reinterpret_cast<uint16_t *>(smem + a.off_order);
-    uint32_t *red = S.red;
-    uint32_t *sumbuf = red + 96;
-    uint32_t *pivmask = reinterpret_cast<uint32_t *>(smem + a.off_pivmask);
-    uint32_t *npl = reinterpret_cast<uint32_t *>(smem + a.off_npl);
-    // scratch of the elimination, inside the region that receives Q at the end
-    uint64_t *TB = S.q;                                        // [64][NWD] pending columns of the batch, by row
-    uint64_t *HP = TB + 64 * NWD;                              // [T * CPT]  pivot order -> batch columns containing its row
-    uint64_t *pivm = HP + T * CPT;                             // [NWD] rows that are pivot rows
-    uint64_t *sv = pivm + NWD;                                 // [NWD] transformed syndrome
-    uint32_t *cand = reinterpret_cast<uint32_t *>(sv + NWD);   // [2][64] first unpivoted row of a pending column
-    const int lam_max = min(a.osd_order, 64);
-    const int m = a.m, m_pad = a.m_pad;
-    uint64_t *mt = a.mt_ws + (size_t)blockIdx.x * ((size_t)a.mw * m_pad + 64 * 32);
-    for (int item = blockIdx.x; item < nfail; item += gridDim.x) {
-        const int slot = a.slot_list ? a.slot_list[item] : item;
-        const int64_t shot = a.fail_list[slot];
-        const float *llr = a.llr_ws + (int64_t)slot * a.n_pad;
-        const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
-        const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
-
-#ifdef QD_OSD_TIMING
-        unsigned long long acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        unsigned long long tick_ = wall_clock64();
-#endif
-        uint64_t mycol[CPT][NWD];
-#pragma unroll
-        for (int i = 0; i < CPT; ++i)
-#pragma unroll
-            for (int w = 0; w < NWD; ++w) mycol[i][w] = 0ull;
-        if (tid < 2 * NWD) pivm[tid] = 0ull;                   // pivm and sv
-        for (int r = tid; r < m_pad; r += T) S.rowpiv[r] = -1;
-        for (int w = tid; w < a.out_words; w += T) { S.outw[w] = 0u; pivmask[w] = 0u; }
-        if (tid < 64) red[tid] = ((tid & 16) == 0) ? QD_NOKEY : 0u;
-        __syncthreads();
-        for (int r = tid; r < m; r += T) {
-            uint32_t sbit = det[r] & 1u;
-            if (upd && r < a.upd_rows) sbit ^= upd[r] & 1u;
-            if (sbit) atomicOr(reinterpret_cast<unsigned long long *>(&sv[r >> 6]), 1ull << (r & 63));
-        }
-        __syncthreads();
-
-        int npiv = 0, sphase = 0, nnp = 0;
-        uint32_t lo_key = 0, lo_idx = 0;
-        for (;;) {
-            TierState ts{lo_key, lo_idx, sphase, 0, QD_OSD_TIER};
-            QD_TICK(10)
-            const int cnt = qd_osd_draw_tier<T>(a, llr, sortbuf, order, red, sumbuf, ts);
-            lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
-            QD_TICK(0)
-            if (ts.exhausted) break;
-            if (npiv >= a.rank) {                              // factorisation complete: every further column is a non-pivot column
-                if (tid == 0)
-                    for (int i = 0; i < cnt && nnp + i < lam_max; ++i) npl[nnp + i] = order[i];
-                nnp = min(lam_max, nnp + cnt);
-                __syncthreads();
-                if (nnp >= lam_max) break;
-                continue;
-            }
-            for (int base = 0; base < cnt; base += 64) {
-                const int nb = min(64, cnt - base);
-                // ---- the batch: raw columns by row, and for every pivot the batch columns that contain its row
-                for (int x = tid; x < 64 * NWD; x += T) TB[x] = 0ull;
-                for (int k = tid; k < npiv; k += T) HP[k] = 0ull;
-                if (tid < 64) { S.bcols[tid] = tid < nb ? (uint32_t)order[base + tid] : 0xFFFFFFFFu; cand[tid] = QD_NOKEY; cand[64 + tid] = QD_NOKEY; }
-                __syncthreads();
-                for (int x = tid; x < 64 * a.max_cdeg; x += T) {
-                    const int c = x / a.max_cdeg, q = x - c * a.max_cdeg;
-                    const uint32_t col = S.bcols[c];
-                    if (col != 0xFFFFFFFFu) {
-                        const uint32_t e0 = a.csc_ptr[col], e1 = a.csc_ptr[col + 1];
-                        if (e0 + q < e1) {
-                            const int r = a.csc_row[e0 + q];
-                            atomicXor(reinterpret_cast<unsigned long long *>(&TB[c * NWD + (r >> 6)]), 1ull << (r & 63));
-                            const int k = S.rowpiv[r];
-                            if (k >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&HP[k]), 1ull << c);
-                        }
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int i = 0; i < CPT; ++i) {
-                    const int k = tid + i * T;
-                    if (k < npiv)
-                        for (uint64_t bits = HP[k]; bits; bits &= bits - 1ull) {
-                            const int c = (int)__builtin_ctzll(bits);
-#pragma unroll
-                            for (int w = 0; w < NWD; ++w)
-                                if (mycol[i][w]) atomicXor(reinterpret_cast<unsigned long long *>(&TB[c * NWD + w]), (unsigned long long)mycol[i][w]);
-                        }
-                }
-                __syncthreads();
-                QD_TICK(1)
-                // ---- pivots of the batch, in column order
-                int cur = 0, ph = 0;
-                constexpr int XI = (64 * NWD + T - 1) / T;     // pending words per thread
-                bool fresh[XI];                                // the column of my word changed (or is new): its first unpivoted row has to be found again
-#pragma unroll
-                for (int q = 0; q < XI; ++q) fresh[q] = true;
-                for (;;) {
-#pragma unroll
-                    for (int q = 0; q < XI; ++q) {
-                        const int x = tid + q * T, c = x / NWD, w = x - c * NWD;
-                        if (x < 64 * NWD && fresh[q] && c >= cur && c < nb) {
-                            const uint64_t nz = TB[x] & ~pivm[w];
-                            if (nz) atomicMin(&cand[ph * 64 + c], (uint32_t)(w * 64 + (int)__builtin_ctzll(nz)));
-                        }
-                    }
-                    QD_TICK(4)
-                    __syncthreads();
-                    QD_TICK(5)
-                    const uint32_t cv = cand[ph * 64 + lane];
-                    const unsigned long long live = __ballot(cv != QD_NOKEY);
-                    const bool more = live != 0ull && npiv < a.rank;
-                    const int cstar = more ? (int)__builtin_ctzll(live) : nb;
-                    if (nnp < lam_max) {                       // batch columns [cur, cstar) depend on earlier pivots: the first lam_max in order
-                        if (tid == 0)
-                            for (int x = cur; x < cstar && nnp + (x - cur) < lam_max; ++x) npl[nnp + (x - cur)] = S.bcols[x];
-                        nnp = min(lam_max, nnp + max(0, cstar - cur));
-                    }
-                    if (!more) break;
-                    const int p = __builtin_amdgcn_readlane((int)cv, cstar);
-                    const int K = npiv, pw = p >> 6;
-                    const uint64_t pb = 1ull << (p & 63);
-                    const uint64_t *tq = TB + cstar * NWD;     // nobody writes this column any more
-                    // t' = the column's image without bit p.  Every vector that has bit p set gets the image added as it is and bit p
-                    // toggled back; so does the new column K (all zero until now: it becomes t').  The word that holds bit p is
-                    // picked by a scalar switch (pw is wave-uniform): registers cannot be indexed, and a select chain costs 2 NWD
-                    // instructions per column and round.
-                    uint64_t sel[CPT];
-#pragma unroll
-                    for (int i = 0; i < CPT; ++i) sel[i] = 0ull;
-                    switch (pw) {
-#define QD_X(W) case W: if constexpr (W < NWD) { _Pragma("unroll") for (int i = 0; i < CPT; ++i) sel[i] = mycol[i][W < NWD ? W : 0]; } break;
-                        QD_X(0) QD_X(1) QD_X(2) QD_X(3) QD_X(4) QD_X(5) QD_X(6) QD_X(7) QD_X(8) QD_X(9) QD_X(10) QD_X(11)
-                        QD_X(12) QD_X(13) QD_X(14) QD_X(15) QD_X(16) QD_X(17) QD_X(18) QD_X(19) QD_X(20) QD_X(21) QD_X(22) QD_X(23)
-#undef QD_X
-                        default: break;
-                    }
-                    uint64_t tog[CPT];
-#pragma unroll
-                    for (int i = 0; i < CPT; ++i) {
-                        const int k = tid + i * T;
-                        tog[i] = 0ull;
-                        if ((k < K && (sel[i] & pb)) || k == K) {   // (a wavefront whose columns all lie beyond K, or miss bit p, skips this)
-#pragma unroll
-                            for (int w = 0; w < NWD; ++w) mycol[i][w] ^= tq[w];
-                            tog[i] = pb;
-                        }
-                    }
-                    switch (pw) {
-#define QD_X(W) case W: if constexpr (W < NWD) { _Pragma("unroll") for (int i = 0; i < CPT; ++i) mycol[i][W < NWD ? W : 0] ^= tog[i]; } break;
-                        QD_X(0) QD_X(1) QD_X(2) QD_X(3) QD_X(4) QD_X(5) QD_X(6) QD_X(7) QD_X(8) QD_X(9) QD_X(10) QD_X(11)
-                        QD_X(12) QD_X(13) QD_X(14) QD_X(15) QD_X(16) QD_X(17) QD_X(18) QD_X(19) QD_X(20) QD_X(21) QD_X(22) QD_X(23)
-#undef QD_X
-                        default: break;
-                    }
-#pragma unroll
-                    for (int q = 0; q < XI; ++q) {
-                        const int x = tid + q * T, c = x / NWD, w = x - c * NWD;
-                        fresh[q] = false;
-                        if (x < 64 * NWD && c < nb) {
-                            const bool hit = c > cstar && (TB[c * NWD + pw] & pb);
-                            if (hit) TB[x] ^= tq[w] ^ ((w == pw) ? pb : 0ull);
-                            fresh[q] = hit;
-                            // next round's candidates: kept for the columns this pivot leaves alone
-                            if (w == 0) cand[(ph ^ 1) * 64 + c] = (c > cstar && !hit) ? cand[ph * 64 + c] : QD_NOKEY;
-                        }
-                    }
-                    if (tid < NWD && (sv[pw] & pb)) sv[tid] ^= tq[tid] ^ ((tid == pw) ? pb : 0ull);
-                    if (tid == T - 1) {
-                        const uint32_t pc = S.bcols[cstar];
-                        S.rowpiv[p] = (int16_t)K; S.prow[K] = (uint16_t)p; S.pcol[K] = pc;
-                        atomicOr(&pivmask[pc >> 5], 1u << (pc & 31u));
-                    }
-                    if (tid == T - 2) pivm[pw] |= pb;
-                    npiv = K + 1; cur = cstar + 1; ph ^= 1;
-                    QD_TICK(7)
-                    __syncthreads();
-                    QD_TICK(6)
-                }
-                QD_TICK(2)
-                __syncthreads();
-                if (npiv >= a.rank) {                          // the rest of this tier is non-pivot as well
-                    const int rest0 = base + 64;
-                    if (tid == 0)
-                        for (int i = rest0; i < cnt && nnp + (i - rest0) < lam_max; ++i) npl[nnp + (i - rest0)] = order[i];
-                    nnp = min(lam_max, nnp + max(0, cnt - rest0));
-                    __syncthreads();
-                    break;
-                }
-            }
-            if (npiv >= a.rank && nnp >= lam_max) break;
-        }
-        // ---- residual left on a non-pivot row <=> syndrome outside the column space; syndrome back to one byte per row
-        uint64_t resid = 0ull;
-#pragma unroll
-        for (int w = 0; w < NWD; ++w) resid |= sv[w] & ~pivm[w];
-        const int inconsistent = resid != 0ull;
-        for (int r = tid; r < m_pad; r += T) S.sp[r] = (uint8_t)((sv[r >> 6] >> (r & 63)) & 1ull);
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {                        // Q columns to where the sweep reads them
-            const int k = tid + i * T;
-            if (k < npiv) {
-#pragma unroll
-                for (int w = 0; w < NWD; ++w)
-                    if (w < a.mw) mt[(size_t)k * a.mw + w] = mycol[i][w];
-            }
-        }
-        __syncthreads();
-        QD_TICK(2)
-        if (NWD <= 8) qd_osd_sweep_t<T, 8, true>(a, smem, llr, nullptr, mt, npiv, nnp);
-        else if (NWD <= 16) qd_osd_sweep_t<T, 16, true>(a, smem, llr, nullptr, mt, npiv, nnp);
-        else qd_osd_sweep_t<T, 32, true>(a, smem, llr, nullptr, mt, npiv, nnp);
-        for (int w = tid; w < a.out_words; w += T) a.err_bits[shot * a.out_words + w] = S.outw[w];
-        if (tid == 0) a.status[shot] = (a.status[shot] & 0xFFFF) | (1 << 17) | (inconsistent ? (1 << 18) : 0) | (min(npiv, 4095) << 20);
-        QD_TICK(3)
-#ifdef QD_OSD_TIMING
-        if (tid == 0) {
-            for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc_[i]);
-            atomicAdd(&a.dbg[8], 1ull); atomicAdd(&a.dbg[9], (unsigned long long)npiv); atomicAdd(&a.dbg[10], acc_[10]);
-        }
-#endif
-        __syncthreads();   // LDS is recycled by the next shot
-    }
-}
-
 // ---- full path: every column sorted, every Q plane available ------------------------------------------------------------
 template <int T>
 __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphDev bg, DecodeArgs a,
@@ -1469,32 +1208,15 @@ __global__ void __launch_bounds__(T) qd_osd0_full_kernel(OsdGraphDev g, BpGraphD
 }
 
 
-#ifndef QD_COLK2_T
-#define QD_COLK2_T 512        // threads / wavefronts-per-SIMD budget of the m <= 1024 instantiation (1024 columns in all)
-#define QD_COLK2_WPS 4
-#endif
-#ifndef QD_COLK1_T
-#define QD_COLK1_T 256        // threads of the small-window instantiation of the column kernel (512 columns in all): a shot of a
-                              // 360-check window is ~1700 barriers, so fewer wavefronts per barrier and six shots per CU beat 512 threads and
-                              // three (W=5 F=3 windows of the [[144,12,12]] code, OSD-CS(1): 42.8 -> 25.5 ms per launch)
-#endif
 template <int TF, int RPT>
 static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks, hipStream_t s, bool handed_over)
 {
     const bool wl = a.osd_w != 0;                              // higher-order OSD uses the one-workgroup-per-CU layout
     auto k = wl ? qd_osd0_reg_kernel<TF, RPT, true> : qd_osd0_reg_kernel<TF, RPT, false>;
-    // higher-order OSD: elimination by column (qd_osdw_col_kernel, always 512 threads) when the host laid it out (c_* layout).
-    // c_cpt names the instantiation: 1 = one column of 8 words per thread (m <= 512: the sliding windows the reference really
-    // runs, W = 3..5 rounds of a [[144,12,12]] or smaller code), 2 = two of 16 (m <= 1024), 3 = three of 22 (m <= 1408)
-    int colk = 0;
-    {
-        const bool row_form = std::getenv("QD_OSDW_ROWS") && std::atoi(std::getenv("QD_OSDW_ROWS")) == 1;   // the round-1 kernel, for A/B runs
-        if (wl && a.mt_ws && !row_form && g.c_lds_bytes > 0) colk = g.c_cpt;
-    }
-    const int lds = colk ? g.c_lds_bytes : wl ? g.w_lds_bytes : g.f_lds_bytes;
-    hipError_t e = hipFuncSetAttribute(colk == 1 ? (const void *)qd_osdw_col_kernel<QD_COLK1_T, 512 / QD_COLK1_T, 8, 6> : colk == 2 ? (const void *)qd_osdw_col_kernel<QD_COLK2_T, 1024 / QD_COLK2_T, 16, QD_COLK2_WPS>
-                                       : colk == 3 ? (const void *)qd_osdw_col_kernel<512, 3, 22, 2> : (const void *)k,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    // higher-order OSD here = the full-rank elimination by ROW (one workgroup per CU): since round 5 only the windows the panel kernel
+    // (osd_cs.hip) does not take -- more than 1408 detectors, or more faults than its sort holds -- and QD_OSDCS_OLD=1 (A/B)
+    const int lds = wl ? g.w_lds_bytes : g.f_lds_bytes;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     OsdRegArgs r{};
     r.m = g.m; r.n = g.n; r.m_pad = g.m_pad; r.n_pad = bg.n_pad; r.max_cdeg = g.max_cdeg; r.mw = g.mw; r.f_kw = wl ? g.w_kw : g.f_kw;
@@ -1508,14 +1230,7 @@ static hipError_t launch_reg(const OsdGraphDev &g, const BpGraphDev &bg, const D
     r.err_bits = a.err_bits; r.status = a.status; r.dbg = a.dbg;
     r.off_pivmask = wl ? g.w_off_pivmask : g.f_off_pivmask; r.off_npl = wl ? g.w_off_npl : g.f_off_npl;
     r.osd_w = a.osd_w; r.osd_order = a.osd_order; r.rank = a.rank; r.wfix = g.wfix; r.bit_slot_of = bg.bit_slot_of;
-    if (colk) {
-        for (int i = 0; i < 10; ++i) r.off[i] = g.c_off[i];
-        r.off_sort = g.c_off_sort; r.off_order = g.c_off_order; r.off_pivmask = g.c_off_pivmask; r.off_npl = g.c_off_npl;
-    }
-    if (colk == 1) hipLaunchKernelGGL((qd_osdw_col_kernel<QD_COLK1_T, 512 / QD_COLK1_T, 8, 6>), dim3((unsigned)blocks), dim3(QD_COLK1_T), lds, s, r);
-    else if (colk == 2) hipLaunchKernelGGL((qd_osdw_col_kernel<QD_COLK2_T, 1024 / QD_COLK2_T, 16, QD_COLK2_WPS>), dim3((unsigned)blocks), dim3(QD_COLK2_T), lds, s, r);
-    else if (colk == 3) hipLaunchKernelGGL((qd_osdw_col_kernel<512, 3, 22, 2>), dim3((unsigned)blocks), dim3(512), lds, s, r);
-    else hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TF), lds, s, r);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(TF), lds, s, r);
     return hipGetLastError();
 }
 

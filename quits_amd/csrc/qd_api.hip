@@ -681,24 +681,6 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         for (int per_cu = per_cu0; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu)
             od.f_lds_bytes = lay(per_cu, false, od.f_off, od.f_off_sort, od.f_off_order, od.f_off_pivmask, od.f_off_npl, od.f_kw);
         od.w_lds_bytes = lay(1, true, od.w_off, od.w_off_sort, od.w_off_order, od.w_off_pivmask, od.w_off_npl, od.w_kw);
-        // the column-form kernel (osd_kernels.hip, qd_osdw_col_kernel): 512 threads, 2 columns of 16 words each (m <= 1024, two
-        // workgroups per CU by registers) or 3 of 22 (m <= 1408, one per CU); the Q region holds 64 pending columns, one word
-        // per pivot and a few vectors
-        od.c_lds_bytes = 0; od.c_cpt = 0; od.c_per_cu = 0;
-        if (od.w_lds_bytes > 0 && m <= 1408) {
-            const int var = m <= 512 ? 1 : (m <= 1024 ? 2 : 3);            // instantiation (osd_kernels.hip, launch_reg)
-            const int cpt = var, nwd = var == 1 ? 8 : (var == 2 ? 16 : 22);
-            const int need = (64 * nwd + 512 * cpt + 2 * nwd) * 8 + 512;
-            int o = carve(od.c_off, need, 0);
-            od.c_off_sort = o; o += sort_b;
-            od.c_off_order = o; o += order_b;
-            od.c_off_pivmask = o; o += align16(bp.out_words * 4);
-            od.c_off_npl = o; o += 256;
-            if (o <= QD_LDS_BYTES) {
-                od.c_lds_bytes = o; od.c_cpt = var;
-                od.c_per_cu = std::max(1, std::min(var == 1 ? (std::getenv("QD_COLK1_PER_CU") ? std::atoi(std::getenv("QD_COLK1_PER_CU")) : 6) : (var == 2 ? (std::getenv("QD_COLK2_PER_CU") ? std::atoi(std::getenv("QD_COLK2_PER_CU")) : 2) : 1), QD_LDS_BYTES / o));   // the instantiations' register budgets
-            }
-        }
     }
     // OSD-0 with simultaneous singleton pivots (osd_sr.hip): columns in ELL form (one load per entry, no pointer chase), its own
     // LDS layout; taken whenever the mirrored register kernel exists too (it decodes the shots the new kernel hands over)
@@ -969,7 +951,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
             const int v = std::atoi(ev);
             if (v > 0) d->osd_blocks_fast = ncu * v;
         }
-        if (d->osd_w) d->osd_blocks_fast = ncu * std::max(1, g->osd.c_per_cu);   // higher-order OSD: w_* layout (one workgroup per CU) or the column kernel's
+        if (d->osd_w) d->osd_blocks_fast = ncu;                                   // higher-order OSD by row: w_* layout, one workgroup per CU
         if (d->lsd) {
             const int lds = qd_lsd_lds_bytes(g->m, g->n, g->bp.out_words);
             d->lsd_blocks = ncu * std::max(1, std::min(8, QD_LDS_BYTES / std::max(1, lds)));     // one wavefront per shot, several shots per CU
@@ -990,7 +972,7 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         d->osd_blocks_cs = 0;
         {
             // higher-order OSD: the rebuilt column-form kernel (osd_cs.hip) wherever its layout takes the window; QD_OSDCS_OLD=1 keeps
-            // qd_osdw_col_kernel / the row form for A/B runs
+            // the row form (osd_kernels.hip) for A/B runs
             const char *ev = std::getenv("QD_OSDCS_OLD");
             if (d->osd_w && !d->lsd && g->osd.csc_ell && !(ev && std::atoi(ev) == 1)) {
                 int per = 0;

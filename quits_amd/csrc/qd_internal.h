@@ -132,8 +132,6 @@ struct OsdGraphDev {
     // ... and of the register kernel for OSD-CS / OSD-E (one workgroup per CU, as many Q planes in LDS as fit: the
     //     candidate sweep reads arbitrary Q bits of every pivot row)
     int w_off[10], w_off_sort, w_off_order, w_off_pivmask, w_off_npl, w_kw, w_lds_bytes;
-    // higher-order OSD by column (qd_osdw_col_kernel): its own, smaller layout -- the Q region only holds the elimination's scratch
-    int c_off[10], c_off_sort, c_off_order, c_off_pivmask, c_off_npl, c_lds_bytes, c_cpt, c_per_cu;
     const uint32_t *wfix;       // [n] integer candidate costs round(log(1/p) * 2^18) for OSD-CS / OSD-E
     uint32_t max_wfix;          // largest of them (the rebuilt OSD-CS / OSD-E kernel adds 64 of them in 32 bits)
     int threads;

@@ -89,7 +89,7 @@ class BatchDecoder:
         """Arithmetic of this decoder (qd_decoder_info): LLR grid bits (-1 = float LLRs as they are), coarse grid, kernel."""
         arr = (C.c_int32 * 4)()
         _lib.check(self._L.qd_decoder_info(self._h, arr))
-        post = {0: "none", 1: "qd_osd0_sr_kernel", 2: "qd_osd0_reg_kernel", 3: "qd_osdw_col_kernel", 4: "qd_osdcs_kernel",
+        post = {0: "none", 1: "qd_osd0_sr_kernel", 2: "qd_osd0_reg_kernel", 3: "qd_osd0_reg_kernel<row form>", 4: "qd_osdcs_kernel",
                 5: "qd_lsd0_kernel"}.get(int(self._L.qd_decoder_postproc_kernel(self._h)), "?")
         return {"llr_grid_bits": int(arr[0]), "llr_coarse_bits": int(arr[1]), "edge_kernel": bool(arr[2]),
                 "scatter_kernel": bool(arr[3]), "scatter_wide_kernel": int(arr[3]) == 2, "post_kernel": post}

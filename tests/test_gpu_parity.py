@@ -987,10 +987,11 @@ def test_bplsd_sliding_window_functions(gpu):
     assert np.array_equal(d1.decode(s1.astype(int)), go.decode_batch(s1.reshape(1, -1), prm)[0][0])
 
 
-def test_osdw_row_form_and_column_form_agree(gpu, monkeypatch):
-    """Higher-order OSD has two full-rank eliminations: by column (qd_osdw_col_kernel, the default where the window fits it)
-    and by row (qd_osd0_reg_kernel<.., true>: QD_OSDW_ROWS=1, and every window of more than 1408 checks).  Same pivots, same
-    sweep, same bits -- on the headline window both ways, and on a 1708-check block-diagonal window (row form only) vs the oracle."""
+def test_osdw_panel_kernel_and_row_form_agree(gpu, monkeypatch):
+    """Higher-order OSD has two full-rank eliminations: the panel kernel (osd_cs.hip, qd_osdcs_kernel: the default wherever its layout
+    takes the window) and the elimination by row (qd_osd0_reg_kernel<.., true>: QD_OSDCS_OLD=1, and every window of more than 1408
+    checks).  Same pivots, same sweep, same bits -- on the headline window both ways, and on a 1708-check block-diagonal window (row
+    form only) vs the oracle."""
     import torch
     from scipy.sparse import block_diag, csc_matrix
     from quits_amd.decoder.device import BatchDecoder, WindowGraph, unpack_bits
@@ -1005,8 +1006,9 @@ def test_osdw_row_form_and_column_form_agree(gpu, monkeypatch):
         wg = WindowGraph(H, pri)
         out = []
         for rows in ("0", "1"):
-            monkeypatch.setenv("QD_OSDW_ROWS", rows)
+            monkeypatch.setenv("QD_OSDCS_OLD", rows)
             dec = BatchDecoder(wg, max_iter=1, osd_method="osd_cs", osd_order=3)
+            assert dec.info()["post_kernel"] == ("qd_osdcs_kernel" if (rows == "0" and m <= 1408) else "qd_osd0_reg_kernel<row form>")
             bits, status = dec.osd0(torch.from_numpy(synd).cuda(), torch.from_numpy(llr).cuda())
             out.append((unpack_bits(bits, n).cpu().numpy(), status.cpu().numpy()))
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
