@@ -49,6 +49,10 @@ typedef __attribute__((address_space(3))) int32_t qs_lds_i32;
 #define QS_ADD(off, v_) *QS_LDS(off) = v_;
 #elif defined(QS_ABL_CONSTV)    /* ... the atomic add of a constant (the value's arithmetic is dead code) */
 #define QS_ADD(off, v_) (void)__hip_atomic_fetch_add(QS_LDS(off), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#elif defined(QS_ABL_READ)      /* ... a plain LDS read per edge instead of the atomic add (what a gather-form bit pass would issue at least) */
+#define QS_ADD(off, v_) { const int r_ = *QS_LDS(off) ^ (v_); asm volatile("" ::"v"(r_)); }
+#elif defined(QS_ABL_NOADD)     /* ... no LDS operation at all in the scatter pass (its vector arithmetic stays) */
+#define QS_ADD(off, v_) asm volatile("" ::"v"(v_));
 #else
 #define QS_ADD(off, v_) (void)__hip_atomic_fetch_add(QS_LDS(off), v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif

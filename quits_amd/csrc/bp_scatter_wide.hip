@@ -205,7 +205,9 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                 anyun |= v.x | v.y | v.z | v.w;
             }
         }
+#ifndef QS_ABL_FORCE_ITERS       /* timing experiments only: every shot runs max_iter iterations, whatever the (wrong) arithmetic of an ablation build does */
         if (t >= 1 && !anyun) { converged = 1; break; }
+#endif
         if (t == a.max_iter) break;
         // ---- scatter pass, in place: each edge's accumulator moves by (new message) - (message sent last time)
         __builtin_amdgcn_s_setprio(QS_PRIO);
