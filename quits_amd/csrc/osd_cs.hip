@@ -316,6 +316,11 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         scatter(0, Pbuf, needb);
         __syncthreads();
 
+        // Which Q columns a thread owns.  Wavefront 0 -- the one that finds the pivots -- owns the HIGHEST pivot orders, which only exist in the last
+        // batches of a shot; the other wavefronts share the rest.  So while wavefront 0 works on a panel the others apply each pivot to their columns
+        // as soon as it is published (phase [B] below), and wavefront 0 itself has nothing to update until late in the shot.
+        auto kown = [&](int c) -> int { return wave == 0 ? NPIV - 64 * CPT + c * 64 + lane : (tid - 64) + c * (T - 64); };
+        const int kmin_wave = wave == 0 ? NPIV - 64 * CPT : (wave - 1) * 64;       // the lowest pivot order any lane of this wavefront owns
         int npiv = 0;
         for (int base = 0, bi = 0; base < n; base += 64, ++bi) {
             const int nb = min(64, n - base);
@@ -324,7 +329,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             // ---- [A] images: the owner of Q column k adds it to the batch columns that contain pivot row k; the other buffers are cleared
 #pragma unroll
             for (int i = 0; i < CPT; ++i) {
-                const int k = tid + i * T;
+                const int k = kown(i);
                 if (k < npiv)
                     for (uint64_t bits = ndc[k]; bits; bits &= bits - 1ull) {
                         const int c = (int)__builtin_ctzll(bits);
@@ -335,6 +340,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             }
             for (int x = tid; x < 64 * PSTR; x += T) Pn[x] = 0ull;
             for (int x = tid; x < NPIV; x += T) ndn[x] = 0ull;
+            if (tid == 0) { misc[6] = 0u; misc[7] = 0u; }              // pivots published / panel finished (phase [B])
 #ifdef QD_OSD_TIMING
             ++acc_[10];
 #endif
@@ -451,6 +457,10 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                             for (int r2 = r; r2 < NR; ++r2)
                                 if (c0 + r2 * NSLOT < nlive) apply_row(x[r2], tq, pbit, sh, isw);  // (columns already passed are dead: harmless)
                             ++g;
+                            // published: the other wavefronts may apply pivot g - 1 now.  (This wavefront's LDS operations complete in order, so whoever
+                            // reads the new count reads the image and the record behind it; the fence only keeps the compiler from reordering.)
+                            QD_WAVE_SYNC();
+                            if (lane == 0) __hip_atomic_store(&misc[6], (uint32_t)g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                     }
                     QD_SUBT(1, 13)
@@ -462,23 +472,23 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     const uint32_t pj = pivp[lane];
                     const int p = (int)(pj & 0xFFFFu), K = npiv + lane;
                     const uint32_t cb = tab[pj >> 16];                 // rank among the live columns -> column of the batch
-                    pivp[lane] = (uint32_t)p | (cb << 16);
                     const uint32_t pc = order[base + (int)cb];
                     rowpiv[p] = (int16_t)K; prow[K] = (uint16_t)p; pcol[K] = (uint16_t)pc;
                     atomicOr(&pivmask[pc >> 5], 1u << (pc & 31u));
                 }
                 QD_SUBT(1, 14)
+                QD_WAVE_SYNC();
+                if (lane == 0) __hip_atomic_store(&misc[7], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     // the panel is finished: records written
                 __builtin_amdgcn_s_setprio(0);
             }
             QD_TICK(2)
-            __syncthreads();
-            QD_TICK(6)
-            // ---- [C] every Q column takes the batch's pivots, in order: a column that has bit p set gets the pivot's image added (bit p stays:
-            // the image is stored without it); column K, all zero until now, becomes that image.  The image travels in scalar registers.
-            const int g = (int)misc[0];
-            for (int i = 0; i < g; ++i) {
+            // ---- [C] every Q column takes the batch's pivots, in order: a column that has bit p set gets the pivot's image added (bit p stays: the
+            // image is stored without it); column K, all zero until now, becomes that image.  Wavefronts 1.. do this WHILE wavefront 0 is still
+            // at work on the panel: they poll the published count (two LDS reads, then a short sleep) and apply what has arrived; wavefront 0
+            // applies the batch to its own columns afterwards, which exist in the last batches of a shot only.
+            auto apply_pivot = [&](int i) {
                 const int K = npiv + i;
-                if (wave * 64 > K) continue;                           // none of this wavefront's columns exists yet (uniform)
+                if (kmin_wave > K) return;                             // none of this wavefront's columns exists yet (uniform)
                 const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pivp[i]);
                 const int p = (int)(pj & 0xFFFFu), pw = p >> 6;
                 const uint64_t pb = 1ull << (p & 63);
@@ -495,7 +505,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 bool hit[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) {
-                    const int k = tid + c * T;
+                    const int k = kown(c);
                     hit[c] = (k < K && (sel[c] & pb) != 0ull) || k == K;
                 }
                 // the image comes as broadcast LDS reads (every lane the same address): the LDS pipe is idle in this phase, the vector ALU
@@ -515,6 +525,16 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                                 if (wb + u < NWD) mycol[c][wb + u] ^= tv_[u];
                         }
                 }
+            };
+            int g = 0;                                                 // (one call site of apply_pivot: wavefront 0 arrives here with its panel finished)
+            for (;;) {
+                const uint32_t fin = __hip_atomic_load(&misc[7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        // (before the count: finished => the count is final)
+                QD_WAVE_SYNC();
+                const int avail = (int)__hip_atomic_load(&misc[6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                QD_WAVE_SYNC();
+                for (; g < avail; ++g) apply_pivot(g);
+                if (fin) break;
+                __builtin_amdgcn_s_sleep(2);
             }
             npiv += g;
             const bool done = npiv >= a.rank || base + 64 >= n;
@@ -531,7 +551,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         if (tid < NWD && (sv[tid] & unpm[tid]) != 0ull) atomicOr(&misc[2], 1u);      // (misc[0..63] was cleared at the head of the shot)
 #pragma unroll
         for (int c = 0; c < CPT; ++c) {
-            const int k = tid + c * T;
+            const int k = kown(c);
             if (k < npiv) {
 #pragma unroll
                 for (int w = 0; w < NWD; ++w) mt[(size_t)k * NWD + w] = mycol[c][w];
