@@ -149,7 +149,6 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
     constexpr unsigned long long LPSMASK = (LPS == 32) ? 0xFFFFFFFFull : ((1ull << LPS) - 1ull);
     constexpr int PSTR = NWD + 1;                                  // padded column stride (words): a lane-per-column read of one word spreads over the banks
     constexpr int NPIV = T * CPT;
-    const int m = a.m, n = a.n, dlog = a.ell_log2, ellw = 1 << dlog;
 
     using L = CsLds<T, CPT, NWD>;
     uint64_t *sb = reinterpret_cast<uint64_t *>(smem);                                   // [n] sort buffer (the sort phase owns all of LDS)
@@ -170,12 +169,14 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
     uint64_t *tvl = reinterpret_cast<uint64_t *>(smem + L::o_tv);                        // [64][NWD] images of the first non-pivot columns (patterns)
 
     const int nfail = *a.fail_count;
+    int tid = threadIdx.x, n = a.n;
     for (int item = blockIdx.x; item < nfail; item += gridDim.x) {
         // The thread index is made opaque once per shot: everything derived from it (the IPT item indices of the sort, their bounds
         // tests and global addresses, ...) is invariant across shots, and the compiler otherwise hoists all of it out of this loop
         // and keeps it live -- in scratch -- for the whole kernel (the first build: 628 bytes per lane)
-        int tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
+        asm volatile("" : "+v"(tid));                                  // (loop-carried and opaque: ONE register holds the thread index across shots)
+        asm volatile("" : "+s"(n));                                    // (likewise: a copy of n in a vector register, made before the loop, was kept in scratch)
+        const int m = a.m, dlog = a.ell_log2, ellw = 1 << dlog;
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int slot = item;
         const int64_t shot = a.fail_list[slot];
@@ -197,7 +198,11 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             const int ns = nbk * QD_CS_NSAMP_PER_BUCKET;                     // <= 256 <= T
             auto key_of = [&](int b) -> uint64_t { return ((uint64_t)qd_mono_key(llr[b]) << 32) | (uint64_t)a.bit_orig[b]; };
             if (tid < ns) sb[tid] = key_of((int)(((long long)tid * n) / ns));
-            if (tid < 32) spl[tid] = ~0ull;
+            {
+                uint64_t ones = ~0ull;
+                asm volatile("" : "+v"(ones));                         // (made here, every shot: hoisted out of the shot loop this constant was kept in scratch)
+                if (tid < 32) spl[tid] = ones;
+            }
             if (tid < 40) { bcnt[tid] = 0u; }
             __syncthreads();
             if (nbk > 1 && tid < ns) {
@@ -227,6 +232,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     bkreg[i >> 2] |= bk << (8 * (i & 3));
                     atomicAdd(&bcnt[bk], 1u);
                 }
+                if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // (four items' searches in flight at a time, not IPT: the sort must not be the kernel's register peak)
             }
             __syncthreads();
             QD_SUBT(2, 12)
@@ -247,10 +253,12 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     const int b = tid + i * T;
                     pos[i] = b < n ? atomicAdd(&bcur[(bkreg[i >> 2] >> (8 * (i & 3))) & 0xFFu], 1u) : 0u;
                 }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < IPT; ++i) {
                     const int b = tid + i * T;
                     if (b < n) sb[pos[i]] = key_of(b);
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
@@ -373,7 +381,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 // rank -> column table of the live columns (chunks are consecutive rank ranges; a pivot's record keeps the rank)
                 uint32_t *tab = misc + 192;                            // [64]
                 const int nlive = (int)__popcll(live);
-                if ((live >> lane) & 1ull) tab[__popcll(live & ((1ull << lane) - 1ull))] = (uint32_t)lane;
+                if ((live >> lane) & 1ull) tab[__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u))] = (uint32_t)lane;   // (rank = set bits below my lane)
                 QD_WAVE_SYNC();
                 // A chunk = NR registers x NSLOT slots: the column of rank c0 + r * NSLOT + q has word w in lane (q * LPS + w) of x[r].  A pivot's
                 // image goes through Tp (it has to be stored there anyway) back into every slot; whether a register's columns hold the
@@ -544,6 +552,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             QD_TICK(7)
             if (done) break;
         }
+        asm volatile("" : "+v"(tid));                                  // (what the loops below derive from the thread index is not shared with -- kept live since -- the head of the shot)
         // ================================================================== OSD-0 solution, then the candidate sweep
         // residual on a non-pivot row <=> syndrome outside the column space (the answer is still the oracle's: same pivot rule)
         QD_SUBT0(3)
@@ -703,7 +712,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     bool np_ = false;
                     if (i < n) { col = order[i]; np_ = !((pivmask[col >> 5] >> (col & 31u)) & 1u); }
                     const unsigned long long bal = __ballot(np_);
-                    const int at = cnt + (int)__popcll(bal & ((1ull << lane) - 1ull));
+                    const int at = cnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     if (np_ && at < lam) npl[at] = col;
                     cnt += (int)__popcll(bal);
                 }
