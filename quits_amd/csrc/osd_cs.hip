@@ -26,7 +26,7 @@
 #ifndef QD_CS_NSAMP_PER_BUCKET
 #define QD_CS_NSAMP_PER_BUCKET 8
 #endif
-#define QD_CS_MAX_BUCKETS 32
+#define QD_CS_MAX_BUCKETS 64
 
 // sub-phase timers of a -DQD_OSD_TIMING build: -DQD_CS_SUB=1 (default) panel phase, 2 the sort, 3 the sweep (tools/osdcs_timing.py)
 #ifndef QD_CS_SUB
@@ -137,6 +137,33 @@ __device__ __forceinline__ void qd_cs_wave_sort(uint64_t *buf, int len, int lane
     }
 }
 
+// The same for a short range (len <= 64 * QD_CS_RANK_KM), by counting: a lane keeps its <= KM keys in registers and counts, for each, the keys
+// of the range below it -- broadcast reads that depend on nothing, where the network above is ~40 dependent LDS round trips --, then every
+// key goes to the position of its rank (the keys are distinct: the fault index is part of them).  All reads precede all writes.
+#define QD_CS_RANK_KM 6
+__device__ __forceinline__ void qd_cs_wave_ranksort(uint64_t *buf, int len, int lane)
+{
+    uint64_t own[QD_CS_RANK_KM];
+    int rk[QD_CS_RANK_KM];
+#pragma unroll
+    for (int u = 0; u < QD_CS_RANK_KM; ++u) {
+        const int idx = lane + 64 * u;
+        own[u] = idx < len ? buf[idx] : ~0ull;
+        rk[u] = 0;
+    }
+#pragma unroll 4
+    for (int j = 0; j < len; ++j) {
+        const uint64_t x = buf[j];
+#pragma unroll
+        for (int u = 0; u < QD_CS_RANK_KM; ++u) rk[u] += x < own[u] ? 1 : 0;
+    }
+    QD_WAVE_SYNC();
+#pragma unroll
+    for (int u = 0; u < QD_CS_RANK_KM; ++u)
+        if (lane + 64 * u < len) buf[rk[u]] = own[u];
+    QD_WAVE_SYNC();
+}
+
 // T threads hold CPT columns of Q each (rank <= T * CPT), NWD words per column (m <= 64 * NWD); WPS = wavefronts per SIMD the
 // register budget is cut for; IPT = sorted items per thread (n <= T * IPT).
 template <int T, int CPT, int NWD, int WPS, int IPT>
@@ -191,19 +218,19 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         // ================================================================== the column order: sample sort of (key, fault) in LDS
         {
             QD_SUBT0(2)
-            uint64_t *spl = reinterpret_cast<uint64_t *>(smem + a.o_sort_aux);                   // [32] splitters
-            uint32_t *bcnt = reinterpret_cast<uint32_t *>(smem + a.o_sort_aux + 256);            // [33] bucket starts
-            uint32_t *bcur = bcnt + 40;                                                          // [32] bucket cursors
-            const int nbk = min(QD_CS_MAX_BUCKETS, max(1, n >> 8));
-            const int ns = nbk * QD_CS_NSAMP_PER_BUCKET;                     // <= 256 <= T
+            uint64_t *spl = reinterpret_cast<uint64_t *>(smem + a.o_sort_aux);                   // [64] splitters
+            uint32_t *bcnt = reinterpret_cast<uint32_t *>(smem + a.o_sort_aux + 512);            // [65] bucket starts
+            uint32_t *bcur = bcnt + 72;                                                          // [64] bucket cursors
+            const int nbk = min(min(QD_CS_MAX_BUCKETS, T / QD_CS_NSAMP_PER_BUCKET), max(1, n >> 7));   // ~150 keys per bucket
+            const int ns = nbk * QD_CS_NSAMP_PER_BUCKET;                     // <= T
             auto key_of = [&](int b) -> uint64_t { return ((uint64_t)qd_mono_key(llr[b]) << 32) | (uint64_t)a.bit_orig[b]; };
             if (tid < ns) sb[tid] = key_of((int)(((long long)tid * n) / ns));
             {
                 uint64_t ones = ~0ull;
                 asm volatile("" : "+v"(ones));                         // (made here, every shot: hoisted out of the shot loop this constant was kept in scratch)
-                if (tid < 32) spl[tid] = ones;
+                if (tid < 64) spl[tid] = ones;
             }
-            if (tid < 40) { bcnt[tid] = 0u; }
+            if (tid < 72) { bcnt[tid] = 0u; }
             __syncthreads();
             if (nbk > 1 && tid < ns) {
                 // rank by counting (the keys are distinct: the fault index is part of them); every 8th sample is a splitter
@@ -217,7 +244,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             auto bucket_of = [&](uint64_t x) -> uint32_t {
                 uint32_t lo = 0;
 #pragma unroll
-                for (int step = 16; step >= 1; step >>= 1) lo += (spl[lo + step - 1] <= x) ? step : 0;
+                for (int step = 32; step >= 1; step >>= 1) lo += (spl[lo + step - 1] <= x) ? step : 0;
                 return lo;
             };
             QD_SUBT(2, 11)
@@ -237,13 +264,13 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             __syncthreads();
             QD_SUBT(2, 12)
             if (tid < 64) {
-                // exclusive scan of the <= 32 counts (lanes 32.. carry zeros); bcnt[k] becomes the start of bucket k, bcnt[nbk .. 32] = n
-                const uint32_t c = tid < 32 ? bcnt[tid] : 0u;
+                // exclusive scan of the <= 64 counts; bcnt[k] becomes the start of bucket k, bcnt[nbk .. 64] = n
+                const uint32_t c = bcnt[tid];
                 uint32_t incl = c;
 #pragma unroll
-                for (int d = 1; d < 32; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
-                if (tid < 32) { bcnt[tid] = incl - c; bcur[tid] = incl - c; }
-                if (tid == 32) bcnt[32] = (uint32_t)n;
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += o; }
+                bcnt[tid] = incl - c; bcur[tid] = incl - c;
+                if (tid == 0) bcnt[64] = (uint32_t)n;
             }
             __syncthreads();                                                  // (the samples in sb[0 .. ns) are dead: everybody has its bucket numbers)
             {
@@ -265,7 +292,8 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             QD_SUBT(2, 13)
             for (int bk = wave; bk < nbk; bk += NW) {
                 const int lo = (int)bcnt[bk], hi = (int)bcnt[bk + 1];
-                qd_cs_wave_sort(sb + lo, hi - lo, lane);
+                if (hi - lo <= 64 * QD_CS_RANK_KM) qd_cs_wave_ranksort(sb + lo, hi - lo, lane);
+                else qd_cs_wave_sort(sb + lo, hi - lo, lane);            // (a bucket several times its expected size: the sorting network takes any length)
             }
             __syncthreads();
             QD_SUBT(2, 14)
@@ -835,7 +863,7 @@ int qd_osdcs_layout(int m, int n, int out_words, uint32_t max_wfix, int *off, in
     off[1] = o; o += al(n * 2);                       // order
     // the sort phase owns everything: n keys of 8 bytes, then splitters / counters
     off[2] = al(n * 8);
-    const int sort_end = off[2] + 1024;
+    const int sort_end = off[2] + 2048;
     const int total = std::max(o, sort_end);
     const int by_regs = sh.WPS * 256 / sh.T;          // workgroups per CU the register budget allows
     const int by_lds = QD_LDS_BYTES / total;
