@@ -287,6 +287,9 @@ def test_osd_alone_on_crafted_llrs(gpu, case):
     ("bb72_custom_r6_p0.003", "osd_e", 5, 40),
     ("hgp225_cardinal_r3_p0.01", "osd_cs", 3, 6),
     ("bb144_custom_r12_p0.003", "osd_cs", 2, 6),
+    ("bb72_custom_r6_p0.003", "osd_cs", 64, 8),        # the largest orders the device takes: 2016 pairs / 4095 patterns over the first non-pivot columns
+    ("bb72_custom_r6_p0.003", "osd_e", 12, 8),
+    ("bb144_custom_r12_p0.003", "osd_e", 9, 4),
 ])
 def test_higher_order_osd_bit_exact(gpu, name, method, order, shots):
     """OSD-CS / OSD-E on the device against the oracle with the same integer candidate costs: full-rank elimination,
