@@ -223,8 +223,11 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU; the decoder has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dist = parallel.init_distributed("nccl")      # "nccl" is RCCL on ROCm; None for a single process
+    # QD_BENCH_SHARE_GPU=1 + QD_BENCH_DIST_BACKEND=gloo: the N > 1 branch on a box with fewer GPUs than ranks (ranks share devices,
+    # the 16-byte reductions go over gloo) -- a plumbing check of this code path on hardware, never a scaling measurement
+    share = os.environ.get("QD_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if share else local_rank)
+    dist = parallel.init_distributed(os.environ.get("QD_BENCH_DIST_BACKEND", "nccl"))      # "nccl" is RCCL on ROCm; None for a single process
 
     out = run(args, rank, world, dist, full=True)
     if rank == 0 and world == 1 and not args.no_other_configs and args.code == "bb144" and args.window is None \

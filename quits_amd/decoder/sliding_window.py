@@ -143,7 +143,7 @@ class DeviceWindowPlan:
         # QD_NO_PIPELINE=1 or plan.pipeline = False keeps everything on the caller's stream.  Not the default where BP runs in the
         # per-edge kernel: HBM-bound, it loses more to the co-running post-processor than the overlap returns (W = 5 / F = 3
         # windows with the reference's settings 219 k -> 209 k shots/s, profiles/r03x_pipelined_driver_multiwindow_ab.txt)
-        self.pipeline = not _env_flag("QD_NO_PIPELINE") and not any(d.info()["edge_kernel"] for d in decs)
+        self.pipeline = not _env_flag("QD_NO_PIPELINE") and (_env_flag("QD_PIPELINE_EDGE") or not any(d.info()["edge_kernel"] for d in decs))
         self._side = None
         self._stage = None
         self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", 4 * self.chunk))   # shots per staged piece (>= 2 chunks: the pipelined driver)

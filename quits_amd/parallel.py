@@ -39,11 +39,17 @@ def init_distributed(backend: str = "nccl"):
     return dist
 
 
+def _collective_device(dist, device):
+    """gloo reduces host tensors whatever the caller asked for; RCCL ("nccl") needs them on the rank's GPU."""
+    return "cpu" if dist.get_backend() == "gloo" else device
+
+
 def reduce_counts(dist, n_errors: int, n_shots: int, device="cpu") -> Tuple[int, int]:
     """All-reduce SUM of the two counters; identity without a process group."""
     if dist is None:
         return int(n_errors), int(n_shots)
     import torch
+    device = _collective_device(dist, device)
     t = torch.tensor([int(n_errors), int(n_shots)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return int(t[0].item()), int(t[1].item())
@@ -53,6 +59,7 @@ def reduce_max(dist, value: float, device="cpu") -> float:
     if dist is None:
         return float(value)
     import torch
+    device = _collective_device(dist, device)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
