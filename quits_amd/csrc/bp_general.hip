@@ -68,8 +68,11 @@ __device__ __forceinline__ uint32_t qd_lanes_or(uint32_t v, uint32_t (*red)[64],
 
 // D: bound on the column weight the instantiation unrolls for (4, 8 or QD_MAX_COL_DEG; registers: five arrays of D in the serial schedule)
 //    LP: serial schedule with the rows' running prefixes in LDS slots (GenGraphDev::nslots > 0)
+#ifndef QD_GEN_WPE
+#define QD_GEN_WPE 1          // wavefronts per SIMD the serial instantiations for column weight <= 8 are budgeted for (1: no bound)
+#endif
 template <int METHOD, int SCHED, int G, int D, bool LP>
-__global__ void __launch_bounds__(64 * G) qd_bp_edge_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
+__global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8) ? QD_GEN_WPE : 1) qd_bp_edge_kernel(GenGraphDev g, const int32_t *__restrict__ rp, const int32_t *__restrict__ ci,
                                                             const int32_t *__restrict__ cp, const int32_t *__restrict__ ri,
                                                             const int32_t *__restrict__ c2r, const float *__restrict__ llr0,
                                                             const uint32_t *__restrict__ srec,
@@ -677,9 +680,14 @@ static hipError_t launch_kd(const GenGraphDev &g, const DecodeArgs &a, const Gen
 template <int METHOD, int SCHED, int G>
 static hipError_t launch_k(const GenGraphDev &g, int max_cdeg, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
 {
-    if (max_cdeg <= 4) return launch_kd<METHOD, SCHED, G, 4>(g, a, w, shot0, nshots, s);
-    if (max_cdeg <= 8) return launch_kd<METHOD, SCHED, G, 8>(g, a, w, shot0, nshots, s);
-    return launch_kd<METHOD, SCHED, G, QD_MAX_COL_DEG>(g, a, w, shot0, nshots, s);
+    switch (qd_gen_unroll(max_cdeg)) {
+    case 4: return launch_kd<METHOD, SCHED, G, 4>(g, a, w, shot0, nshots, s);
+#if QD_GEN_D6
+    case 6: return launch_kd<METHOD, SCHED, G, 6>(g, a, w, shot0, nshots, s);
+#endif
+    case 8: return launch_kd<METHOD, SCHED, G, 8>(g, a, w, shot0, nshots, s);
+    default: return launch_kd<METHOD, SCHED, G, QD_MAX_COL_DEG>(g, a, w, shot0, nshots, s);
+    }
 }
 
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,

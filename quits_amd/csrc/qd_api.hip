@@ -432,7 +432,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             }
             gg.nslots = ((int)busy_until.size() * 256 <= QD_GEN_PREFIX_LDS && m < (1 << 23) && !std::getenv("QD_NO_LDS_PREFIX")) ? (int)busy_until.size() : 0;
             // one record per (step, wavefront): see GenGraphDev
-            const int G = QD_GEN_GS, D = max_cdeg <= 4 ? 4 : (max_cdeg <= 8 ? 8 : QD_MAX_COL_DEG);
+            const int G = QD_GEN_GS, D = qd_gen_unroll(max_cdeg);
             const int RW = (2 + 2 * D + 3) & ~3;
             size_t nstep = 0;
             for (int l = 0; l < nlev; ++l) nstep += (size_t)(lp[l + 1] - lp[l] + G - 1) / G;

@@ -76,6 +76,11 @@ struct ScatArgs {
 };
 
 // The general (one message per edge) BP kernel's view: plain CSR + CSC in fault / detector order, prior LLRs in float.
+// column-weight bound the per-edge kernel's serial schedule unrolls for (register arrays of that length, record width)
+#ifndef QD_GEN_D6
+#define QD_GEN_D6 0           // 1: a weight-6 instantiation between 4 and 8 (A/B, profiles/r05_k1g_*)
+#endif
+static inline int qd_gen_unroll(int max_cdeg) { return max_cdeg <= 4 ? 4 : ((QD_GEN_D6 && max_cdeg <= 6) ? 6 : (max_cdeg <= 8 ? 8 : QD_MAX_COL_DEG)); }
 #ifndef QD_GEN_GS
 #define QD_GEN_GS 4           // wavefronts per 64 shots in the serial schedule (faults of one dependency level in parallel)
 #endif
