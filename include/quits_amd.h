@@ -85,8 +85,9 @@ int qd_device_count(void);
 int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, const int32_t *col_idx, const double *priors,
                     int32_t device, qd_graph **out);
 void qd_graph_destroy(qd_graph *g);
-/* info[0..9] = m, n, nnz, max row weight, max column weight, BP block threads, BP LDS bytes, OSD block threads,
- *              OSD LDS bytes, GF(2) rank of the matrix */
+/* info[0..11] = m, n, nnz, max row weight, max column weight, BP block threads, BP LDS bytes, OSD block threads,
+ *               OSD LDS bytes, GF(2) rank of the matrix, modelled LDS cycles of one pass of the scatter kernels' walk over the
+ *               accumulators (bank conflicts included) and the same without any conflict (0, 0: the window does not run there) */
 int qd_graph_info(const qd_graph *g, int32_t *info);
 
 /* ---- decoder: replaces BpOsdDecoder.__init__'s parameter half. */

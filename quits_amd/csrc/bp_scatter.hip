@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
     }
     {
         int32_t *bA = reinterpret_cast<int32_t *>(smem + sg.offA);
-        for (int b = tid; b < n_pad + 4; b += T) bA[b] = b < g.n ? x.prior_g[b] : 0;    // slots beyond n: padding and the trash slot of the short rows (stay 0)
+        for (int b = tid; b < sg.nslots; b += T) bA[b] = x.prior_g[b];                 // (unused slots and the trash slots of the short rows hold 0 and stay 0)
     }
     for (int w = tid; w < g.out_words; w += T) outw[w] = 0u;
     __syncthreads();
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
         uint32_t kst = 0u, q0 = 0u, q1 = 0u;
 #ifndef QS_ABL_NOGATHER
         if (active) {
-            uint32_t neg0 = 0u, neg1 = 0u, hp = 0u;
+            uint32_t neg0 = 0u, neg1 = 0u, hp = 0u, hpa = 0u;
             for (int k0 = 0; k0 < trip; k0 += 32) {
                 const uint32_t sgnw = k0 ? o1 : o0;
                 uint32_t neww = 0u, ltw = 0u;
@@ -116,14 +116,14 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
                         eb = QS_ADJ(row0 + (kk >> 2) + 1);            // (the table has spare group rows)
                         {
                             const int sb = kend - 1 - kk, k = k0 + kk;
-                            QS_EDGE(nx.x, k, sb, QS_NOFIX) QS_EDGE(nx.y, k + 1, sb - 1, QS_NOFIX)
-                            QS_EDGE(nx.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(nx.w, k + 3, sb - 3, QS_NOFIX)
+                            QS_EDGE_H(nx.x, k, sb, QS_NOFIX, QS_HPA) QS_EDGE_H(nx.y, k + 1, sb - 1, QS_NOFIX, QS_HPB)
+                            QS_EDGE_H(nx.z, k + 2, sb - 2, QS_NOFIX, QS_HPA) QS_EDGE_H(nx.w, k + 3, sb - 3, QS_NOFIX, QS_HPB)
                         }
                         nx = QS_ADJ(row0 + (kk >> 2) + 2);
                         {
                             const int sb = kend - 5 - kk, k = k0 + kk + 4;
-                            QS_EDGE(eb.x, k, sb, QS_NOFIX) QS_EDGE(eb.y, k + 1, sb - 1, QS_NOFIX)
-                            QS_EDGE(eb.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(eb.w, k + 3, sb - 3, QS_NOFIX)
+                            QS_EDGE_H(eb.x, k, sb, QS_NOFIX, QS_HPA) QS_EDGE_H(eb.y, k + 1, sb - 1, QS_NOFIX, QS_HPB)
+                            QS_EDGE_H(eb.z, k + 2, sb - 2, QS_NOFIX, QS_HPA) QS_EDGE_H(eb.w, k + 3, sb - 3, QS_NOFIX, QS_HPB)
                         }
                     }
                 }
@@ -132,10 +132,10 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
                     const uint4 e4 = nx;
                     nx = QS_ADJ(row0 + (kk >> 2) + 1);
                     const int sb = kend - 1 - kk, k = k0 + kk;
-                    QS_EDGE(e4.x, k, sb, QS_NOFIX)
-                    QS_EDGE(e4.y, k + 1, sb - 1, QS_NOFIX)
-                    QS_EDGE(e4.z, k + 2, sb - 2, QS_NOFIX)
-                    QS_EDGE(e4.w, k + 3, sb - 3, QS_NOFIX)
+                    QS_EDGE_H(e4.x, k, sb, QS_NOFIX, QS_HPA)
+                    QS_EDGE_H(e4.y, k + 1, sb - 1, QS_NOFIX, QS_HPB)
+                    QS_EDGE_H(e4.z, k + 2, sb - 2, QS_NOFIX, QS_HPA)
+                    QS_EDGE_H(e4.w, k + 3, sb - 3, QS_NOFIX, QS_HPB)
                 }
 #pragma unroll 1
                 for (; kk < kend; kk += 4) {
@@ -254,9 +254,9 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
         }
     }
     // ---- hard decision, packed by fault index
-    for (int b = tid; b < g.n; b += T)
+    for (int b = tid; b < sg.nslots; b += T)
         if (*QS_LDS(cur + 4u * (uint32_t)b) < 0) {
-            const uint32_t j = g.bit_orig[b];
+            const uint32_t j = sg.slot_fault[b];
             atomicOr(&outw[j >> 5], 1u << (j & 31u));
         }
     if (!converged && a.want_llr && tid == 0) misc[48] = atomicAdd(a.fail_count, 1);
@@ -265,7 +265,10 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
     if (!converged && a.want_llr) {
         const int slot = misc[48];
         float *dst = a.llr_ws + (int64_t)slot * n_pad;
-        for (int b = tid; b < g.n; b += T) dst[b] = (float)(*QS_LDS(cur + 4u * (uint32_t)b) + 1) * x.grid_inv;
+        for (int b = tid; b < sg.nslots; b += T) {       // rows of the OSD workspace are in the gather kernel's bit-slot order
+            const uint32_t k1 = sg.slot_k1[b];
+            if (k1 != 0xFFFFFFFFu) dst[k1] = (float)(*QS_LDS(cur + 4u * (uint32_t)b) + 1) * x.grid_inv;
+        }
         if (tid == 0) a.fail_list[slot] = (int32_t)shot;
     }
     if (tid == 0) a.status[shot] = t | (converged << 16) | a.status_or;

@@ -25,15 +25,24 @@ typedef __attribute__((address_space(3))) int32_t qs_lds_i32;
 // edge in the check's walk (wave-uniform), compared with the argmin label of the last pass; sb = bit of `sgnw` that holds the sign of the message this check sent
 // on the edge.  d_ = (L - 1) - prev = bm - 1 is an integer-valued float, so (bm <= 0) is its sign bit (-0.0 cannot occur: an
 // integer converted to float is never -0, and x - y is -0 only for x = -0).
-#define QS_EDGE(off, k_, sb, TAILFIX)                                                                        \
+// HP: how the accumulator's bits enter `hp` (only bit 31, the hard decision, is used): QS_HP1 one XOR per edge; QS_HPA / QS_HPB on the
+// two edges of a pair -- the first is remembered in `hpa`, the second folds both in with one v_bitop3_b32 (a ^ b ^ c): half an instruction per edge
+// QS_SIGN31(sb): the sign this check sent on the edge (bit `sb` of sgnw) moved to bit 31.  (Keeping sgnw pre-shifted so that the shift amounts are
+// immediates instead of one scalar each measured slower: 42.6 -> 43.1 ms, profiles/r05_k1sw_micro_ab.txt.)
+#define QS_SIGN31(sb) (((sgnw >> (sb)) & 1u) << 31)
+#define QS_HP1(A_) hp ^= (uint32_t)(A_);
+#define QS_HPA(A_) hpa = (uint32_t)(A_);
+#define QS_HPB(A_) hp = __builtin_amdgcn_bitop3_b32(hp, hpa, (uint32_t)(A_), 0x96);
+#define QS_EDGE(off, k_, sb, TAILFIX) QS_EDGE_H(off, k_, sb, TAILFIX, QS_HP1)
+#define QS_EDGE_H(off, k_, sb, TAILFIX, HP)                                                                  \
     {                                                                                                        \
-        const int A_ = *QS_LDS(off);                                                                         \
+        const int A_ = *QS_LDS(QS_ADDR(off));                                                                \
         const float mag_ = ((uint32_t)(k_) == kold) ? s2 : s1;                                               \
-        const float prev_ = __uint_as_float(((sgnw >> (sb)) & 1u) << 31 | __float_as_uint(mag_));            \
+        const float prev_ = __uint_as_float(QS_SIGN31(sb) | __float_as_uint(mag_));                          \
         float d_ = (float)A_ - prev_;                                                                        \
         TAILFIX(d_, k_)                                                                                      \
         const float bm_ = d_ + 1.0f;                                                                         \
-        hp ^= (uint32_t)A_;                                                                                  \
+        HP(A_)                                                                                               \
         neww = __builtin_amdgcn_alignbit(neww, __float_as_uint(d_), 31);                                     \
         /* ltw = ltw << 1 | (|bm| < a1): the argmin is the edge of the LAST strict improvement */           \
         asm("v_cmp_lt_f32 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(ltw) : "v"(bm_), "v"(a1) : "vcc"); \
@@ -45,6 +54,14 @@ typedef __attribute__((address_space(3))) int32_t qs_lds_i32;
 // nor a minimum
 #define QS_TAILFIX(x_, k_) x_ = ((int)(k_) < dc) ? x_ : QS_BIG;
 
+#if defined(QS_ABL_NOCONF)      /* timing experiment only (wrong results): every lane's accumulator address moved to bank (lane mod 32) of its 128-byte row */
+#define QS_ADDR(off) ((((uint32_t)(off)) & ~0x7Cu) | ((threadIdx.x & 31u) << 2))
+#elif defined(QS_ABL_ADDRCTL)   /* ... its control: the same extra instruction per access, addresses unchanged */
+__device__ __forceinline__ uint32_t qs_opaque(uint32_t x) { asm volatile("" : "+s"(x)); return x; }
+#define QS_ADDR(off) ((((uint32_t)(off)) & qs_opaque(0xFFFFFFFFu)) | (threadIdx.x & qs_opaque(0u)))
+#else
+#define QS_ADDR(off) (off)
+#endif
 #if defined(QS_ABL_STORE)       /* timing experiments only (wrong results): a plain store instead of the atomic add ... */
 #define QS_ADD(off, v_) *QS_LDS(off) = v_;
 #elif defined(QS_ABL_CONSTV)    /* ... the atomic add of a constant (the value's arithmetic is dead code) */
@@ -54,7 +71,7 @@ typedef __attribute__((address_space(3))) int32_t qs_lds_i32;
 #elif defined(QS_ABL_NOADD)     /* ... no LDS operation at all in the scatter pass (its vector arithmetic stays) */
 #define QS_ADD(off, v_) asm volatile("" ::"v"(v_));
 #else
-#define QS_ADD(off, v_) (void)__hip_atomic_fetch_add(QS_LDS(off), v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define QS_ADD(off, v_) (void)__hip_atomic_fetch_add(QS_LDS(QS_ADDR(off)), v_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
 // Scatter pass, one edge: (new message) - (message sent in the last iteration) = sn a - so b with a, b = min1 of the two passes
 // (the argmin edges are corrected after the loop) and sn, so = +-1 the outgoing signs: sn (a - b) where the signs agree, sn (a + b)

@@ -29,6 +29,12 @@
 // in bp_scatter.hip): the wavefronts closest to the barrier go first, so a workgroup's stragglers are fewer.  Headline BP stage 44.1 ->
 // 43.2 ms per 65 536 shots; the other way round (first round high) 43.7, scatter pass at 0 / 2 / 3 no change, alternate wavefronts
 // high no change (profiles/r03x_wavefront_priority_ab.txt).
+// Scatter pass: the sign / difference bit of an edge is picked with a scalar bit position (v_bfe_i32 with an SGPR offset) instead of shifting
+// the two words by 4 per group: half a vector instruction per edge moves to the scalar unit.  BP stage 42.35 -> 42.24 ms per 65 536 headline
+// shots (profiles/r05_k1sw_micro_ab.txt); 0 = the shifting form.
+#ifndef QSW_SCAT_SGPR_POS
+#define QSW_SCAT_SGPR_POS 1
+#endif
 #ifndef QSW_GPRIO
 #define QSW_GPRIO 1
 #endif
@@ -74,7 +80,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
     }
     {
         int32_t *bA = reinterpret_cast<int32_t *>(smem + sg.offA);
-        for (int b = tid; b < n_pad + 4; b += T) bA[b] = b < g.n ? x.prior_g[b] : 0;    // slots beyond n: padding and the trash slot of the short rows (stay 0)
+        for (int b = tid; b < sg.nslots; b += T) bA[b] = x.prior_g[b];                 // (unused slots and the trash slots of the short rows hold 0 and stay 0)
     }
     for (int w = tid; w < g.out_words; w += T) outw[w] = 0u;
     __syncthreads();
@@ -123,7 +129,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                 const float s1 = S1[j], s2 = S2[j];
                 const uint32_t kold = KOLD[j];
                 const int dc = dcs[j];
-                uint32_t hp = 0u, par = 0u;
+                uint32_t hp = 0u, hpa = 0u, par = 0u;
                 uint32_t neg[NSW];
 #pragma unroll
                 for (int w = 0; w < NSW; ++w) {
@@ -144,14 +150,14 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                                 eb = QS_ADJ(row0 + (kk >> 2) + 1);            // (the table has spare group rows)
                                 {
                                     const int sb = kend - 1 - kk, k = k0 + kk;
-                                    QS_EDGE(nx.x, k, sb, QS_NOFIX) QS_EDGE(nx.y, k + 1, sb - 1, QS_NOFIX)
-                                    QS_EDGE(nx.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(nx.w, k + 3, sb - 3, QS_NOFIX)
+                                    QS_EDGE_H(nx.x, k, sb, QS_NOFIX, QS_HPA) QS_EDGE_H(nx.y, k + 1, sb - 1, QS_NOFIX, QS_HPB)
+                                    QS_EDGE_H(nx.z, k + 2, sb - 2, QS_NOFIX, QS_HPA) QS_EDGE_H(nx.w, k + 3, sb - 3, QS_NOFIX, QS_HPB)
                                 }
                                 nx = QS_ADJ(row0 + (kk >> 2) + 2);
                                 {
                                     const int sb = kend - 5 - kk, k = k0 + kk + 4;
-                                    QS_EDGE(eb.x, k, sb, QS_NOFIX) QS_EDGE(eb.y, k + 1, sb - 1, QS_NOFIX)
-                                    QS_EDGE(eb.z, k + 2, sb - 2, QS_NOFIX) QS_EDGE(eb.w, k + 3, sb - 3, QS_NOFIX)
+                                    QS_EDGE_H(eb.x, k, sb, QS_NOFIX, QS_HPA) QS_EDGE_H(eb.y, k + 1, sb - 1, QS_NOFIX, QS_HPB)
+                                    QS_EDGE_H(eb.z, k + 2, sb - 2, QS_NOFIX, QS_HPA) QS_EDGE_H(eb.w, k + 3, sb - 3, QS_NOFIX, QS_HPB)
                                 }
                             }
                         }
@@ -160,10 +166,10 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                             const uint4 e4 = nx;
                             nx = QS_ADJ(row0 + (kk >> 2) + 1);
                             const int sb = kend - 1 - kk, k = k0 + kk;
-                            QS_EDGE(e4.x, k, sb, QS_NOFIX)
-                            QS_EDGE(e4.y, k + 1, sb - 1, QS_NOFIX)
-                            QS_EDGE(e4.z, k + 2, sb - 2, QS_NOFIX)
-                            QS_EDGE(e4.w, k + 3, sb - 3, QS_NOFIX)
+                            QS_EDGE_H(e4.x, k, sb, QS_NOFIX, QS_HPA)
+                            QS_EDGE_H(e4.y, k + 1, sb - 1, QS_NOFIX, QS_HPB)
+                            QS_EDGE_H(e4.z, k + 2, sb - 2, QS_NOFIX, QS_HPA)
+                            QS_EDGE_H(e4.w, k + 3, sb - 3, QS_NOFIX, QS_HPB)
                         }
 #pragma unroll 1
                         for (; kk < kend; kk += 4) {
@@ -238,18 +244,26 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                 const uint32_t fixn_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((kst >> 2) * (uint32_t)adj_row + (kst & 3u) * 4u) + adj_voff, 0, 0);
                 const uint32_t fixo_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((ko >> 2) * (uint32_t)adj_row + (ko & 3u) * 4u) + adj_voff, 0, 0);
                 const int ng = trip >> 2;
+#if QSW_SCAT_SGPR_POS
+#define QS_GROUP_POS(gi_) const int b0_ = 31 - 4 * ((gi_) - 8 * w);
+#define QS_GROUP_STEP
+#else
+#define QS_GROUP_POS(gi_) constexpr int b0_ = 31;
+#define QS_GROUP_STEP own <<= 4; xw <<= 4;
+#endif
 #define QS_GROUP(e4, gi_)                                                                                                            \
                 {                                                                                                                    \
                     const int k = (gi_) * 4;                                                                                         \
+                    QS_GROUP_POS(gi_)                                                                                                \
                     if (k + 4 <= wmin4) {                                                                                            \
-                        QS_SCAT(e4.x, 0, 31, QS_NOFIX) QS_SCAT(e4.y, 0, 30, QS_NOFIX) QS_SCAT(e4.z, 0, 29, QS_NOFIX) QS_SCAT(e4.w, 0, 28, QS_NOFIX) \
+                        QS_SCAT(e4.x, 0, b0_, QS_NOFIX) QS_SCAT(e4.y, 0, b0_ - 1, QS_NOFIX) QS_SCAT(e4.z, 0, b0_ - 2, QS_NOFIX) QS_SCAT(e4.w, 0, b0_ - 3, QS_NOFIX) \
                     } else {                                                                                                         \
-                        QS_SCAT(e4.x, k, 31, QS_TAILZERO)                                                                            \
-                        if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, 30, QS_TAILZERO)                                                      \
-                        if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, 29, QS_TAILZERO)                                                      \
-                        if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, 28, QS_TAILZERO)                                                      \
+                        QS_SCAT(e4.x, k, b0_, QS_TAILZERO)                                                                           \
+                        if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, b0_ - 1, QS_TAILZERO)                                                 \
+                        if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, b0_ - 2, QS_TAILZERO)                                                 \
+                        if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, b0_ - 3, QS_TAILZERO)                                                 \
                     }                                                                                                                \
-                    own <<= 4; xw <<= 4;                                                                                             \
+                    QS_GROUP_STEP                                                                                                    \
                 }
 #pragma unroll
                 for (int w = 0; w < NSW; ++w) {
@@ -268,6 +282,8 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                     }
                 }
 #undef QS_GROUP
+#undef QS_GROUP_POS
+#undef QS_GROUP_STEP
                 // the argmin edges carry min2, not min1: the new one gains +-(min2 - min1), the old one gives its own back
                 {
                     const int kw = (int)(kst >> 5), kendw = min(trip - 32 * kw, 32);
@@ -311,9 +327,9 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
         }
     }
     // ---- hard decision, packed by fault index
-    for (int b = tid; b < g.n; b += T)
+    for (int b = tid; b < sg.nslots; b += T)
         if (*QS_LDS(cur + 4u * (uint32_t)b) < 0) {
-            const uint32_t jf = g.bit_orig[b];
+            const uint32_t jf = sg.slot_fault[b];
             atomicOr(&outw[jf >> 5], 1u << (jf & 31u));
         }
     if (!converged && a.want_llr && tid == 0) misc[48] = atomicAdd(a.fail_count, 1);
@@ -322,7 +338,10 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
     if (!converged && a.want_llr) {
         const int slot = misc[48];
         float *dst = a.llr_ws + (int64_t)slot * n_pad;
-        for (int b = tid; b < g.n; b += T) dst[b] = (float)(*QS_LDS(cur + 4u * (uint32_t)b) + 1) * x.grid_inv;
+        for (int b = tid; b < sg.nslots; b += T) {       // rows of the OSD workspace are in the gather kernel's bit-slot order
+            const uint32_t k1 = sg.slot_k1[b];
+            if (k1 != 0xFFFFFFFFu) dst[k1] = (float)(*QS_LDS(cur + 4u * (uint32_t)b) + 1) * x.grid_inv;
+        }
         if (tid == 0) a.fail_list[slot] = (int32_t)shot;
     }
     if (tid == 0) a.status[shot] = t | (converged << 16) | a.status_or;
@@ -348,7 +367,7 @@ hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg
         return two_words ? launch_scatter_wide_t<512, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
     case 256 * 8 + 2:           // 257..512 checks: eight workgroups per CU
         return two_words ? launch_scatter_wide_t<256, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
-    case 128 * 8 + 2:           // <= 256 checks: sixteen workgroups of two wavefronts per CU (A/B: QD_SCATTER_SMALL)
+    case 128 * 8 + 2:           // <= 256 checks: sixteen workgroups of two wavefronts per CU (ONE wavefront with four checks per lane, no barrier partner: 7.73 -> 8.99 ms on 216-check windows, profiles/r05_scatter_small_ab.txt)
         return two_words ? launch_scatter_wide_t<128, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
     case 704 * 8 + 2:           // 11 wavefronts; two workgroups per CU: <= 6 per SIMD, 80 registers
         return launch_scatter_wide_t<704, 6, 2, 3>(g, sg, a, x, B, s);

@@ -94,6 +94,8 @@ struct qd_graph {
     ScatGraphDev sc{};                 // scatter form of the flooding min-sum kernel (bp_scatter.hip); sc.ok = 0: not for this window
     std::vector<uint32_t> h_bit_rec;   // host copy of bp.bit_rec: a decoder on an LLR grid uploads its own with word 0 replaced
     std::vector<uint32_t> h_bit_orig;  // bit slot -> fault
+    std::vector<int32_t> h_sc_slot;    // fault -> accumulator slot of the scatter kernels (empty: they are not used)
+    long long sc_walk_cycles = 0, sc_walk_ideal = 0;   // modelled LDS cycles of one pass of the scatter kernels' walk, and without any bank conflict
 };
 
 struct qd_decoder {
@@ -148,6 +150,156 @@ struct qd_spmat {
 #define QD_GRID_MIN_BITS 10
 static inline int align16(int x) { return (x + 15) & ~15; }
 static inline int pad64(int x) { return (x + 63) & ~63; }
+
+// ---- LDS banks for the scatter kernels (bp_scatter.hip, bp_scatter_wide.hip) --------------------------------------------------
+// Step k of a wavefront's walk is one ds_read_b32 (gather pass) and one ds_add_u32 (scatter pass) over the accumulators of the faults
+// its 64 checks meet at that step, serviced in two groups of 32 lanes with bank = (address / 4) mod 32 and one extra LDS cycle per
+// additional lane on a busy bank (MI355X_MICROARCH.md, LDS; an atomic does not broadcast).  Two things are free: which bank a fault's
+// accumulator lives in (the slot order is the kernels' own) and the order in which a check walks its edges (min, second min and sign
+// parity are symmetric).  A group of 32 checks x 32 banks is a bipartite multigraph; if no bank receives more edges from the group
+// than the group has steps, it splits into that many matchings (Koenig), i.e. a walk without a single conflict.  So:
+//   scatter_banks: choose the banks so that every group's 32 bank loads are as equal as possible (descent on the sum of squared loads,
+//                  one fault at a time, deterministic; starts from the degree-sorted bit slots mod 32);
+//   scatter_walk:  step by step, a maximum matching of the group's unfinished checks into the banks (banks with the largest remaining
+//                  load first: a bank whose remaining load equals the remaining steps must be served now); a check the matching leaves out
+//                  takes its edge on the least busy bank; steps beyond a check's degree point at a trash slot on a bank nobody uses.
+// Headline window (1008 x 9504): 1932 modelled cycles per pass with the round-3 greedy walk over the degree-sorted slots, 1109 here,
+// 1052 without any conflict (WindowGraph.info(): scatter_walk_cycles / _ideal).
+static void scatter_banks(int m, int n, const int32_t *row_ptr, const int32_t *col_idx, const std::vector<int> &chk_orig,
+                          const std::vector<int> &bit_slot_of, std::vector<int> &bank)
+{
+    const int nh = (m + 31) / 32;
+    bank.resize(n);
+    for (int j = 0; j < n; ++j) bank[j] = bit_slot_of[j] & 31;
+    if (std::getenv("QD_SCATTER_BANKS_BY_SLOT")) return;            // A/B: the round-3 assignment
+    // fault -> (group, edges from that group)
+    std::vector<std::vector<std::pair<int, int>>> fh(n);
+    std::vector<int> load((size_t)nh * 32, 0), cnt(32, 0);
+    for (int h = 0; h < nh; ++h)
+        for (int s = 32 * h; s < std::min(m, 32 * h + 32); ++s) {
+            const int i = chk_orig[s];
+            for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
+                const int j = col_idx[e];
+                if (!fh[j].empty() && fh[j].back().first == h) fh[j].back().second++;
+                else fh[j].push_back({h, 1});
+                load[(size_t)h * 32 + bank[j]]++;
+            }
+        }
+    for (int j = 0; j < n; ++j) cnt[bank[j]]++;
+    const int cap = (n + 31) / 32 + 1;                               // slots per bank: the LDS footprint stays within 32 slots of pad64(n)
+    for (int pass = 0; pass < 40; ++pass) {
+        int moved = 0;
+        for (int j = 0; j < n; ++j) {
+            if (fh[j].empty()) continue;
+            const int b0 = bank[j];
+            long long stay = 0;                                      // what the sum of squares gains back when j leaves b0 ...
+            for (auto &hm : fh[j]) stay += 2ll * load[(size_t)hm.first * 32 + b0] * hm.second - (long long)hm.second * hm.second;
+            long long best = stay;
+            int bb = b0;
+            for (int b = 0; b < 32; ++b) {
+                if (b == b0 || cnt[b] >= cap) continue;
+                long long add = 0;                                   // ... and what it pays to enter b
+                for (auto &hm : fh[j]) add += 2ll * load[(size_t)hm.first * 32 + b] * hm.second + (long long)hm.second * hm.second;
+                if (add < best) { best = add; bb = b; }
+            }
+            if (bb != b0) {
+                for (auto &hm : fh[j]) { load[(size_t)hm.first * 32 + b0] -= hm.second; load[(size_t)hm.first * 32 + bb] += hm.second; }
+                cnt[b0]--; cnt[bb]++; bank[j] = bb; ++moved;
+            }
+        }
+        if (!moved) break;
+    }
+}
+
+// put(s, k, e, trash_bank): check slot s takes CSR edge e at step k (e < 0: a step beyond its degree, reading / adding 0 to the trash slot of trash_bank)
+template <class Put>
+static void scatter_walk(int m, const int32_t *row_ptr, const int32_t *col_idx, const std::vector<int> &chk_orig, const std::vector<int> &bank,
+                         Put put, long long *cycles, long long *ideal)
+{
+    const bool greedy_only = std::getenv("QD_SCATTER_WALK_GREEDY") != nullptr;      // A/B: no matching, every check takes its least busy bank
+    std::vector<std::vector<int>> rem(32);
+    for (int w0 = 0; w0 < m; w0 += 64) {
+        int trip = 0;
+        for (int s = w0; s < std::min(m, w0 + 64); ++s) trip = std::max(trip, (int)(row_ptr[chk_orig[s] + 1] - row_ptr[chk_orig[s]]));
+        trip = (trip + 3) & ~3;                                      // what the wavefront of these 64 slots walks (ScatGraphDev::deg_w)
+        for (int g0 = w0; g0 < std::min(m, w0 + 64); g0 += 32) {
+            const int gn = std::min(32, m - g0);
+            for (int l = 0; l < gn; ++l) {
+                const int i = chk_orig[g0 + l];
+                rem[l].assign(col_idx + row_ptr[i], col_idx + row_ptr[i + 1]);     // faults; the CSR edge is found again by its column
+            }
+            auto take = [&](int l, int b, int k) {                   // lane l takes one of its remaining edges on bank b at step k
+                const int i = chk_orig[g0 + l];
+                for (size_t y = 0; y < rem[l].size(); ++y)
+                    if (bank[rem[l][y]] == b) {
+                        const int j = rem[l][y];
+                        rem[l].erase(rem[l].begin() + (long)y);
+                        const int e = (int)(std::lower_bound(col_idx + row_ptr[i], col_idx + row_ptr[i + 1], j) - col_idx);
+                        put(g0 + l, k, e, 0);
+                        return;
+                    }
+            };
+            for (int k = 0; k < trip; ++k) {
+                int rl[32] = {0}, used[32] = {0}, match_b[32], nact = 0, act[32];
+                for (int b = 0; b < 32; ++b) match_b[b] = -1;
+                for (int l = 0; l < gn; ++l)
+                    if (!rem[l].empty()) { act[nact++] = l; for (int j : rem[l]) rl[bank[j]]++; }
+                if (nact) {
+                    // options of a lane: the banks of its remaining edges, busiest (remaining load) first
+                    std::vector<int> opts[32];
+                    for (int x = 0; x < nact; ++x) {
+                        const int l = act[x];
+                        bool has[32] = {false};
+                        for (int j : rem[l]) has[bank[j]] = true;
+                        for (int b = 0; b < 32; ++b) if (has[b]) opts[l].push_back(b);
+                        std::stable_sort(opts[l].begin(), opts[l].end(), [&](int a, int b) { return rl[a] > rl[b]; });
+                    }
+                    std::stable_sort(act, act + nact, [&](int a, int b) { return opts[a].size() < opts[b].size(); });
+                    bool seen[32];
+                    // augmenting paths (Kuhn); 32 x 32, recursion depth <= 32
+                    struct Aug {
+                        std::vector<int> *opts; int *match_b; bool *seen;
+                        bool run(int l) {
+                            for (int b : opts[l]) {
+                                if (seen[b]) continue;
+                                seen[b] = true;
+                                if (match_b[b] < 0 || run(match_b[b])) { match_b[b] = l; return true; }
+                            }
+                            return false;
+                        }
+                    } aug{opts, match_b, seen};
+                    std::vector<int> left;
+                    for (int x = 0; x < nact; ++x) {
+                        if (greedy_only) { left.push_back(act[x]); continue; }
+                        for (int b = 0; b < 32; ++b) seen[b] = false;
+                        if (!aug.run(act[x])) left.push_back(act[x]);
+                    }
+                    for (int b = 0; b < 32; ++b)
+                        if (match_b[b] >= 0) { take(match_b[b], b, k); used[b]++; }
+                    for (int l : left) {                              // no free bank among its edges: the least busy one
+                        int bb = -1;
+                        for (int j : rem[l]) if (bb < 0 || used[bank[j]] < used[bb]) bb = bank[j];
+                        take(l, bb, k); used[bb]++;
+                    }
+                    int mx = 0;
+                    for (int b = 0; b < 32; ++b) mx = std::max(mx, used[b]);
+                    *cycles += mx; *ideal += 1;
+                }
+                // lanes past their degree: the trash slot of a bank nobody uses at this step (there are 32 banks for 32 lanes)
+                int fb = 0;
+                for (int l = 0; l < 32; ++l) {
+                    const bool real_lane = l < gn;
+                    const int deg = real_lane ? (int)(row_ptr[chk_orig[g0 + l] + 1] - row_ptr[chk_orig[g0 + l]]) : 0;
+                    if (k < deg) continue;
+                    while (fb < 32 && used[fb]) ++fb;
+                    const int b = fb < 32 ? fb : (l & 31);
+                    if (fb < 32) used[fb]++;
+                    if (g0 + l < ((m + 63) & ~63)) put(g0 + l, k, -1, b);
+                }
+            }
+        }
+    }
+}
 
 extern "C" int qd_version(void) { return 100; }
 extern "C" const char *qd_last_error(void) { return g_err; }
@@ -209,7 +361,10 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     // 128 lanes x 2 checks it is 3.98 -> 3.75 ms on the former (108 checks: taken) and 8.95 -> 9.45 ms on the latter (216 checks:
     // stay with the gather kernel unless QD_SCATTER_SMALL is set), profiles/r03x_scatter_shapes_ab.txt)
     const int min_rdeg_ = *std::min_element(rdeg.begin(), rdeg.end());
-    const bool scatter_narrow = m <= bp_threads_ && (bp_threads_ >= 512 || m <= 128 || std::getenv("QD_SCATTER_SMALL")) && max_rdeg_pad <= 64 && min_rdeg_ >= 2;
+    // (round 5: with the accumulators' banks balanced per group of 32 checks -- scatter_banks / scatter_walk -- the 128-lane shape is 8.92 -> 7.73 ms per
+    // launch on those 216-check windows and 3.78 -> 3.00 ms on the 108-check ones, so every window of <= 256 checks goes there; QD_NO_SCATTER_SMALL=1:
+    // the 129..256-check windows stay with the gather kernel, profiles/r05_scatter_small_ab.txt)
+    const bool scatter_narrow = m <= bp_threads_ && (bp_threads_ >= 512 || m <= 128 || !std::getenv("QD_NO_SCATTER_SMALL")) && max_rdeg_pad <= 64 && min_rdeg_ >= 2;
     // ... and of its two-checks-per-lane form (bp_scatter_wide.hip): more checks than a workgroup has lanes, or rows of 65..96 faults --
     // the QLP windows of BASELINE configs[4] (1326 checks of up to 78 faults on 704 lanes)
     const int wide_threads_ = pad64((m + 1) / 2) <= 704 ? 704 : 1024;
@@ -516,7 +671,19 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         ScatGraphDev &sc = g->sc;
         sc = ScatGraphDev{};
         const int min_rdeg = *std::min_element(rdeg.begin(), rdeg.end());
-        const int buf = align16((n_pad + 4) * 4);
+        // ---- the accumulators' own slot order: a bank for every fault (scatter_banks), then bank + 32 * (rank inside the bank)
+        std::vector<int> sc_bank, sc_slot;
+        int sc_rows = 0;
+        if (scatter_shape) {
+            scatter_banks(m, n, row_ptr, col_idx, chk_orig, bit_slot_of, sc_bank);
+            std::vector<int> fillb(32, 0);
+            sc_slot.resize(n);
+            for (int j = 0; j < n; ++j) sc_slot[j] = sc_bank[j] + 32 * fillb[sc_bank[j]]++;
+            sc_rows = *std::max_element(fillb.begin(), fillb.end());
+        }
+        const int sc_trash = 32 * sc_rows;                     // 32 trash slots, one per bank, behind the accumulators
+        sc.nslots = scatter_shape ? sc_trash + 32 : n_pad + 4;
+        const int buf = align16(sc.nslots * 4);
         sc.offA = 0; sc.offB = 0; sc.off_out = buf;            // one buffer: the scatter pass works in place
         sc.off_bmap = sc.off_out + align16(bp.out_words * 4);
         sc.off_misc = sc.off_bmap;
@@ -532,19 +699,44 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         } else if (!std::getenv("QD_SCATTER_CPL1")) {
             if (bp.threads == 1024 && 4 * sc.lds_bytes <= QD_LDS_BYTES) { shape_threads = 512; shape_cpl = 2; }
             else if (bp.threads == 512 && 8 * sc.lds_bytes <= QD_LDS_BYTES && !std::getenv("QD_SCATTER_NO_CPL2_256")) { shape_threads = 256; shape_cpl = 2; }
-            else if (bp.threads == 256 && 16 * sc.lds_bytes <= QD_LDS_BYTES) { shape_threads = 128; shape_cpl = 2; }    // (<= 128 checks, or QD_SCATTER_SMALL)
+            else if (bp.threads == 256 && 16 * sc.lds_bytes <= QD_LDS_BYTES) { shape_threads = 128; shape_cpl = 2; }    // (<= 256 checks)
         }
         const int res_new = std::min(2048 / shape_threads, QD_LDS_BYTES / sc.lds_bytes);
         if (scatter_shape && min_rdeg >= 2 && bp.lds_bytes <= QD_LDS_BYTES && res_new >= 1 && res_new >= res_old) {
             const int rows = max_rdeg_pad / 4 + 2;            // two spare group rows: the kernel loads up to two groups ahead unconditionally
-            std::vector<uint32_t> adjA((size_t)rows * m_pad * 4, (uint32_t)(sc.offA + n_pad * 4));
-            for (int s = 0; s < m; ++s) {
-                const int i = chk_orig[s];
+            // every entry starts at the trash slot of bank (lane mod 32): the steps nobody reaches and the two spare rows
+            std::vector<uint32_t> adjA((size_t)rows * m_pad * 4);
+            for (int r = 0; r < rows; ++r)
+                for (int s = 0; s < m_pad; ++s)
+                    for (int q = 0; q < 4; ++q) adjA[((size_t)r * m_pad + s) * 4 + q] = (uint32_t)sc.offA + (uint32_t)(sc_trash + (s & 31)) * 4u;
+            long long walk_cyc = 0, walk_ideal = 0;
+            std::vector<uint8_t> edge_step((size_t)nnz, 0xFF);
+            bool walk_ok = true;
+            scatter_walk(m, row_ptr, col_idx, chk_orig, sc_bank, [&](int s, int k, int e, int trash_bank) {
+                const uint32_t slot = e >= 0 ? (uint32_t)sc_slot[col_idx[e]] : (uint32_t)(sc_trash + trash_bank);
+                if (k < 0 || k >= rows * 4 || s < 0 || s >= m_pad) { walk_ok = false; return; }
+                if (e >= 0) {                                      // a real edge: once, at a step below its check's degree
+                    const int i = s < m ? chk_orig[s] : -1;
+                    if (i < 0 || e < row_ptr[i] || e >= row_ptr[i + 1] || k >= rdeg[i] || edge_step[e] != 0xFF) { walk_ok = false; return; }
+                    edge_step[e] = (uint8_t)k;
+                }
+                adjA[((size_t)(k >> 2) * m_pad + s) * 4 + (k & 3)] = (uint32_t)sc.offA + slot * 4u;
+            }, &walk_cyc, &walk_ideal);
+            for (int i = 0; i < m && walk_ok; ++i) {               // every step below the degree taken exactly once
+                uint64_t seen_lo = 0, seen_hi = 0;
                 for (int e = row_ptr[i]; e < row_ptr[i + 1]; ++e) {
-                    const int k = step_of[e];
-                    adjA[((size_t)(k >> 2) * m_pad + s) * 4 + (k & 3)] = (uint32_t)sc.offA + (uint32_t)bit_slot_of[col_idx[e]] * 4u;
+                    const int k = edge_step[e];
+                    if (k == 0xFF) { walk_ok = false; break; }
+                    uint64_t &w = k < 64 ? seen_lo : seen_hi;
+                    if ((w >> (k & 63)) & 1u) { walk_ok = false; break; }
+                    w |= 1ull << (k & 63);
                 }
             }
+            if (!walk_ok) { g->mem.release(); delete g; return fail(QD_ECAPACITY, "scatter walk: an edge was not placed exactly once below its check's degree"); }
+            g->sc_walk_cycles = walk_cyc; g->sc_walk_ideal = walk_ideal;
+            std::vector<uint32_t> slot_fault((size_t)sc.nslots, 0xFFFFFFFFu), slot_k1((size_t)sc.nslots, 0xFFFFFFFFu);
+            for (int j = 0; j < n; ++j) { slot_fault[sc_slot[j]] = (uint32_t)j; slot_k1[sc_slot[j]] = (uint32_t)bit_slot_of[j]; }
+            g->h_sc_slot.assign(sc_slot.begin(), sc_slot.end());
             std::vector<uint32_t> deg_w(m_pad / 64, 0u);
             for (int w0 = 0; w0 < m; w0 += 64) {
                 int mx = 0, mn = 255;
@@ -553,6 +745,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             }
             int rcs = 0;
             rcs |= g->mem.upload(adjA, &sc.adjA); sc.adjB = sc.adjA;
+            rcs |= g->mem.upload(slot_fault, &sc.slot_fault); rcs |= g->mem.upload(slot_k1, &sc.slot_k1);
             rcs |= g->mem.upload(deg_w, &sc.deg_w); rcs |= g->mem.upload(chk_deg, &sc.chk_deg);
             if (rcs) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while uploading the scatter adjacency"); }
             sc.ok = 1;
@@ -751,6 +944,7 @@ extern "C" int qd_graph_info(const qd_graph *g, int32_t *info)
     info[0] = g->m; info[1] = g->n; info[2] = g->nnz; info[3] = g->max_rdeg; info[4] = g->max_cdeg;
     info[5] = g->bp.threads; info[6] = g->bp.lds_bytes; info[7] = g->osd.threads; info[8] = g->osd.lds_bytes;
     info[9] = host_rank(const_cast<qd_graph *>(g));
+    info[10] = (int32_t)g->sc_walk_cycles; info[11] = (int32_t)g->sc_walk_ideal;
     return QD_OK;
 }
 
@@ -828,11 +1022,11 @@ extern "C" int qd_decoder_create(const qd_graph *g, const qd_params *p, qd_decod
         if (g->sc.ok && !std::getenv("QD_NO_SCATTER")) {
             // scatter kernel: fine-grid priors of the bit slots as integers (grid units) and the second-minimum bound that
             // certifies a run (bp_scatter.hip): max|prior| + max_cdeg * max min2 < 2^23
-            std::vector<int32_t> pg((size_t)g->bp.n_pad, 0);
+            std::vector<int32_t> pg((size_t)g->sc.nslots, 0);      // (unused and trash slots: 0)
             long long mxp = 0;
-            for (int s = 0; s < g->n; ++s) {
-                const long long v = std::llround(std::ldexp((double)on_grid(g->h_llr0[g->h_bit_orig[s]], d->grid_k), d->grid_k));
-                pg[s] = (int32_t)v - 1;              // an accumulator holds L - 1: (L <= 0) is its sign bit
+            for (int j = 0; j < g->n; ++j) {
+                const long long v = std::llround(std::ldexp((double)on_grid(g->h_llr0[j], d->grid_k), d->grid_k));
+                pg[g->h_sc_slot[j]] = (int32_t)v - 1;              // an accumulator holds L - 1: (L <= 0) is its sign bit
                 mxp = std::max(mxp, std::llabs(v));
             }
             const long long lim = ((1ll << 23) - mxp) / std::max(1, g->max_cdeg) - 1;

@@ -61,6 +61,11 @@ struct ScatGraphDev {
     const uint32_t *deg_w;      // [m_pad/64]             per wavefront of check slots: trip count (multiple of 4) | largest degree << 8 | smallest << 16
     const uint8_t *chk_deg;     // [m_pad]                degree of the check slot (0 beyond m)
     int offA, offB, off_out, off_bmap, off_misc, lds_bytes;
+    // The accumulators have their own slot order (not BpGraphDev's bit slots): bank = slot mod 32 is chosen per fault so that the 32 lanes of a
+    // half-wavefront can meet 32 different banks at every step of the walk (qd_graph_create: scatter_banks / scatter_walk).
+    int nslots;                 // accumulators incl. unused slots and 32 trash slots (one per bank) for the steps beyond a check's degree; multiple of 4
+    const uint32_t *slot_fault; // [nslots] fault of the slot, 0xFFFFFFFF: none (its accumulator stays 0)
+    const uint32_t *slot_k1;    // [nslots] the fault's bit slot in BpGraphDev's order (the OSD workspace's row layout), 0xFFFFFFFF: none
     const int32_t *wave_map;    // [wide_cpl][wide_threads / 64] the 64 consecutive check slots (index / 64) a wavefront takes in its j-th round, -1:
                                 //                        none; chosen so that the wavefronts of a workgroup walk equally many edges (slots are sorted by degree)
     int wide_threads, wide_cpl; // 0: one check per lane (bp_scatter.hip); else the workgroup size and the checks per lane of
