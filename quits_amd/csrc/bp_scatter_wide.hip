@@ -251,18 +251,22 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
 #define QS_GROUP_POS(gi_) constexpr int b0_ = 31;
 #define QS_GROUP_STEP own <<= 4; xw <<= 4;
 #endif
-#define QS_GROUP(e4, gi_)                                                                                                            \
+                // a group every lane of the wavefront has in full ...
+#define QS_GROUP_PLAIN(e4, gi_)                                                                                                      \
+                {                                                                                                                    \
+                    QS_GROUP_POS(gi_)                                                                                                \
+                    QS_SCAT(e4.x, 0, b0_, QS_NOFIX) QS_SCAT(e4.y, 0, b0_ - 1, QS_NOFIX) QS_SCAT(e4.z, 0, b0_ - 2, QS_NOFIX) QS_SCAT(e4.w, 0, b0_ - 3, QS_NOFIX) \
+                    QS_GROUP_STEP                                                                                                    \
+                }
+                // ... and one that reaches beyond the smallest degree: lanes past their degree add 0 to a trash slot
+#define QS_GROUP_TAIL(e4, gi_)                                                                                                       \
                 {                                                                                                                    \
                     const int k = (gi_) * 4;                                                                                         \
                     QS_GROUP_POS(gi_)                                                                                                \
-                    if (k + 4 <= wmin4) {                                                                                            \
-                        QS_SCAT(e4.x, 0, b0_, QS_NOFIX) QS_SCAT(e4.y, 0, b0_ - 1, QS_NOFIX) QS_SCAT(e4.z, 0, b0_ - 2, QS_NOFIX) QS_SCAT(e4.w, 0, b0_ - 3, QS_NOFIX) \
-                    } else {                                                                                                         \
-                        QS_SCAT(e4.x, k, b0_, QS_TAILZERO)                                                                           \
-                        if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, b0_ - 1, QS_TAILZERO)                                                 \
-                        if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, b0_ - 2, QS_TAILZERO)                                                 \
-                        if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, b0_ - 3, QS_TAILZERO)                                                 \
-                    }                                                                                                                \
+                    QS_SCAT(e4.x, k, b0_, QS_TAILZERO)                                                                               \
+                    if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, b0_ - 1, QS_TAILZERO)                                                     \
+                    if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, b0_ - 2, QS_TAILZERO)                                                     \
+                    if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, b0_ - 3, QS_TAILZERO)                                                     \
                     QS_GROUP_STEP                                                                                                    \
                 }
 #pragma unroll
@@ -270,18 +274,33 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                     if (32 * w < trip) {
                         const int kendw = min(trip - 32 * w, 32);
                         uint32_t own = Q[j][w] << (32 - kendw), xw = (Q[j][w] ^ O[j][w]) << (32 - kendw);
-                        const int g1 = min(ng, 8 * w + 8);
+                        const int g1 = min(ng, 8 * w + 8);                    // groups of this word: [8 w, g1)
+                        const int gp = min(g1, max(wmin4 >> 2, 8 * w));       // ... of which [8 w, gp) are plain (as in the gather pass: three loops, no test per group)
                         uint4 ea = QS_ADJ(8 * w), eb;
+                        int gi = 8 * w;
 #pragma unroll 1
-                        for (int gi = 8 * w; gi < g1; gi += 2) {
+                        for (; gi + 2 <= gp; gi += 2) {                       // two groups per trip on two register sets
                             eb = QS_ADJ(gi + 1);                              // (the table has two spare group rows)
-                            QS_GROUP(ea, gi)
+                            QS_GROUP_PLAIN(ea, gi)
                             ea = QS_ADJ(gi + 2);
-                            if (gi + 1 < g1) QS_GROUP(eb, gi + 1)
+                            QS_GROUP_PLAIN(eb, gi + 1)
+                        }
+#pragma unroll 1
+                        for (; gi < gp; ++gi) {
+                            const uint4 e4 = ea;
+                            ea = QS_ADJ(gi + 1);
+                            QS_GROUP_PLAIN(e4, gi)
+                        }
+#pragma unroll 1
+                        for (; gi < g1; ++gi) {
+                            const uint4 e4 = ea;
+                            ea = QS_ADJ(gi + 1);
+                            QS_GROUP_TAIL(e4, gi)
                         }
                     }
                 }
-#undef QS_GROUP
+#undef QS_GROUP_PLAIN
+#undef QS_GROUP_TAIL
 #undef QS_GROUP_POS
 #undef QS_GROUP_STEP
                 // the argmin edges carry min2, not min1: the new one gains +-(min2 - min1), the old one gives its own back
