@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             if (j == 0) __builtin_amdgcn_s_setprio(0); else if (j == CPL - 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
 #endif
             if (act[j]) {
-                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
+                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin = (dws[j] >> 16) & 0xFF, wmin4 = wmin & ~3;
                 const int adj_voff = cs[j] * 16;
                 const float s1 = S1[j], s2 = S2[j];
                 const uint32_t kold = KOLD[j];
@@ -176,10 +176,14 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                             const uint4 e4 = nx;
                             nx = QS_ADJ(row0 + (kk >> 2) + 1);
                             const int sb = kend - 1 - kk, k = k0 + kk;
-                            QS_EDGE(e4.x, k, sb, QS_TAILFIX)                  // (k < wmax: a group starts below the largest degree)
-                            if (k + 1 < wmax) QS_EDGE(e4.y, k + 1, sb - 1, QS_TAILFIX) else { neww <<= 1; ltw <<= 1; }
-                            if (k + 2 < wmax) QS_EDGE(e4.z, k + 2, sb - 2, QS_TAILFIX) else { neww <<= 1; ltw <<= 1; }
-                            if (k + 3 < wmax) QS_EDGE(e4.w, k + 3, sb - 3, QS_TAILFIX) else { neww <<= 1; ltw <<= 1; }
+                            // an edge below the smallest degree of the wavefront is real on every lane (no fix), one at or beyond the largest is
+                            // nobody's; only in between does a lane have to ask (wave-uniform tests; k < wmax: a group starts below the largest degree)
+#define QS_TAIL_EDGE(off, q_)                                                                                     \
+                            if (k + (q_) < wmin) QS_EDGE(off, k + (q_), sb - (q_), QS_NOFIX)                      \
+                            else if (k + (q_) < wmax) QS_EDGE(off, k + (q_), sb - (q_), QS_TAILFIX)               \
+                            else { neww <<= 1; ltw <<= 1; }
+                            QS_TAIL_EDGE(e4.x, 0) QS_TAIL_EDGE(e4.y, 1) QS_TAIL_EDGE(e4.z, 2) QS_TAIL_EDGE(e4.w, 3)
+#undef QS_TAIL_EDGE
                         }
                         neg[w] = neww;
                         par ^= neww;
@@ -234,7 +238,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             }
 #endif
             if (act[j]) {
-                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin4 = ((dws[j] >> 16) & 0xFF) & ~3;
+                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin = (dws[j] >> 16) & 0xFF, wmin4 = wmin & ~3;
                 const int adj_voff = cs[j] * 16;
                 const int dc = dcs[j];
                 const int n1i = (int)A1[j], s1i = (int)S1[j];
@@ -259,14 +263,14 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                     QS_GROUP_STEP                                                                                                    \
                 }
                 // ... and one that reaches beyond the smallest degree: lanes past their degree add 0 to a trash slot
+#define QS_SCAT_TAIL(off, q_)                                                                                                        \
+                    if (k + (q_) < wmin) QS_SCAT(off, 0, b0_ - (q_), QS_NOFIX)                                                       \
+                    else if (k + (q_) < wmax) QS_SCAT(off, k + (q_), b0_ - (q_), QS_TAILZERO)
 #define QS_GROUP_TAIL(e4, gi_)                                                                                                       \
                 {                                                                                                                    \
                     const int k = (gi_) * 4;                                                                                         \
                     QS_GROUP_POS(gi_)                                                                                                \
-                    QS_SCAT(e4.x, k, b0_, QS_TAILZERO)                                                                               \
-                    if (k + 1 < wmax) QS_SCAT(e4.y, k + 1, b0_ - 1, QS_TAILZERO)                                                     \
-                    if (k + 2 < wmax) QS_SCAT(e4.z, k + 2, b0_ - 2, QS_TAILZERO)                                                     \
-                    if (k + 3 < wmax) QS_SCAT(e4.w, k + 3, b0_ - 3, QS_TAILZERO)                                                     \
+                    QS_SCAT_TAIL(e4.x, 0) QS_SCAT_TAIL(e4.y, 1) QS_SCAT_TAIL(e4.z, 2) QS_SCAT_TAIL(e4.w, 3)                          \
                     QS_GROUP_STEP                                                                                                    \
                 }
 #pragma unroll
@@ -301,6 +305,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                 }
 #undef QS_GROUP_PLAIN
 #undef QS_GROUP_TAIL
+#undef QS_SCAT_TAIL
 #undef QS_GROUP_POS
 #undef QS_GROUP_STEP
                 // the argmin edges carry min2, not min1: the new one gains +-(min2 - min1), the old one gives its own back
