@@ -500,15 +500,22 @@ def run(args, rank, world, dist, full=True):
             # scatter pass (one ds_add_u32 per edge); per-edge counts from profiles/k1s_issue_model.json <- tools/isa_histogram.py
             ms = {"gather_pass_loop_4_edges": {"valu_fast": 26, "valu_slow": 32}, "scatter_pass_plain_block": {"valu_fast": 6, "valu_slow": 9},
                   "scatter_pass_edges_in_block": 3}
+            # (the several-checks-per-lane kernel of bp_scatter_wide.hip -- the headline's -- has its own count: profiles/k1sw_issue_model.json,
+            #  from this round's assembly, profiles/r05_k1sw_isa_loops.txt)
+            wide = bool(decs[0].info().get("scatter_wide_kernel"))
+            model_src = "profiles/k1sw_issue_model.json <- profiles/r05_k1sw_isa_loops.txt" if wide else "profiles/k1s_issue_model.json <- profiles/r03z_k1s_isa_histogram.txt"
             try:
-                ms = json.load(open(os.path.join(ROOT, "profiles", "k1s_issue_model.json")))["summary"]
+                ms = json.load(open(os.path.join(ROOT, "profiles", "k1sw_issue_model.json" if wide else "k1s_issue_model.json")))["summary"]
             except (OSError, ValueError, KeyError):
-                pass
+                model_src = "built-in counts (profiles/k1s*_issue_model.json not readable)"
+            slow_clk = float(ms.get("slow_class_clk", 4))
             cf, cs = ms["gather_pass_loop_4_edges"]["valu_fast"] / 4.0, ms["gather_pass_loop_4_edges"]["valu_slow"] / 4.0
             bf, bs = (ms["scatter_pass_plain_block"][k] / float(ms["scatter_pass_edges_in_block"]) for k in ("valu_fast", "valu_slow"))
             ws_b_tot = ws_c_tot                                                          # the scatter pass pads like the gather pass
         n_inst = ws_c_tot * (cf + cs) + ws_b_tot * (bf + bs)
-        issue_clk = ws_c_tot * (2 * cf + 4 * cs) + ws_b_tot * (2 * bf + 4 * bs)          # SIMD-cycles, fast class 2 clk, slow class 4
+        if not scatter:
+            slow_clk, model_src = 4.0, "profiles/k1_issue_model.json <- profiles/r02_k1_isa_histogram.txt"
+        issue_clk = ws_c_tot * (2 * cf + slow_clk * cs) + ws_b_tot * (2 * bf + slow_clk * bs)   # SIMD-cycles: fast class 2 clk, slow class 3 (K1sw model: measured 1.5 x) or 4 (older models)
         if scatter:
             lds_clk = ws_c_tot * 2 + ws_b_tot * 4                                        # ds_read_b32 2 cycles; ds_add_u32 ~4 (1.75 ns measured, conflict-free)
             lds_bytes = (ws_c_tot + ws_b_tot) * 64 * 4
@@ -523,13 +530,14 @@ def run(args, rank, world, dist, full=True):
             "avg_launch_ms": prof["bp_ms"] / nlaunch,
             "algorithmic_instructions_per_launch": n_inst / nlaunch,
             "model": ("VALU wave-instructions = check-side wave-steps x (%.2f gather pass + %.2f scatter pass) (per edge, from "
-                      "profiles/r03z_k1s_isa_histogram.txt), summed over the BP iterations each shot really ran; per-check overhead "
-                      "outside the two edge loops is not counted, so `achieved` is a floor" % (cf + cs, bf + bs)) if scatter else
+                      "%s), summed over the BP iterations each shot really ran; per-check overhead "
+                      "outside the two edge loops is not counted, so `achieved` is a floor" % (cf + cs, bf + bs, model_src)) if scatter else
                      ("VALU wave-instructions = check-pass wave-steps x %.2f + bit-pass wave-steps x %.2f (per edge, from "
                       "profiles/r02_k1_isa_histogram.txt), summed over the BP iterations each shot really ran; per-node overhead "
                       "outside the two edge loops is not counted, so `achieved` is a floor" % (cf + cs, bf + bs)),
-            # the same instructions priced by class: two-operand add/sub/logic/shift/fma issue in 2 clk per wavefront per SIMD,
-            # compares / cndmask / min / max / med3 / three-operand logic / 64-bit shifts in 4 (profiles/r01f_valu_issue_rates.txt)
+            # the same instructions priced by class: add / sub / xor / fma / v_bitop3 issue in 2 clk per wavefront per SIMD, shifts / bit-field
+            # extracts / cvt / compares / cndmask / min / max / med3 / carry ops in 3 (K1sw model: tools/microbench/valu_rates.hip measured
+            # 1.5 x, profiles/r05_valu_rates.txt) or 4 (the older models' estimate, profiles/r01f_valu_issue_rates.txt)
             "frac_priced_by_class": issue_clk / (bp_s * NUM_CU * 4 * CLOCK_HZ) if bp_s > 0 else 0.0,
             # the same fraction from the hardware counters of the COMMITTED PMC pass (profiles/pmc_traffic.json <- tools/profile_bench.sh; all
             # VALU instructions, overhead included) -- read from that file, NOT measured in this run (rocprofv3 cannot run inside this process)
