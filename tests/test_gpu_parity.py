@@ -1103,3 +1103,38 @@ def test_scatter_kernel_and_gather_kernel_agree(gpu, monkeypatch, name, shots, m
     g, prm = _oracle(H, pri, max_iter, "osd_0")
     ref, flags = g.decode_batch(np.ascontiguousarray(det[:nref].cpu().numpy()), prm)
     assert np.array_equal(out[("scatter", 3)][0][:nref], ref)
+
+
+@pytest.mark.parametrize("fixture,window", [("bb144_custom_r12_p0.003", None), ("bb144_custom_r12_p0.003", (3, 1, 1)), ("bb72_custom_r6_p0.003", None)])
+def test_scatter_accumulator_banks_and_walk_do_not_change_results(gpu, monkeypatch, fixture, window):
+    """The scatter kernels keep their accumulators in a slot order of their own: a bank per fault balanced over the groups of 32 checks
+    (scatter_banks) and a walk per check found by matching (scatter_walk; qd_api.hip).  Neither may change a bit: the same shots through
+    the round-3 layout (QD_SCATTER_BANKS_BY_SLOT=1: degree-sorted bit slots), through the greedy walk (QD_SCATTER_WALK_GREEDY=1) and through the
+    default give identical decisions, status words and posteriors-driven OSD-0 outputs; and the default's modelled LDS cycles per pass are within
+    15 % of the conflict-free count."""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
+    if window is None:
+        H, L, pri = helpers.dem_matrices(fixture)
+    else:
+        w = helpers.window_set(fixture, window[0], window[1])[window[2]]
+        H, pri = w["H"], w["priors"]
+        L = H[:8]
+    det, _ = DemSampler(H, L, pri).sample(1024, seed=11)
+    outs, infos = [], []
+    for env in ({}, {"QD_SCATTER_BANKS_BY_SLOT": "1"}, {"QD_SCATTER_WALK_GREEDY": "1"}, {"QD_SCATTER_BANKS_BY_SLOT": "1", "QD_SCATTER_WALK_GREEDY": "1"}):
+        for k in ("QD_SCATTER_BANKS_BY_SLOT", "QD_SCATTER_WALK_GREEDY"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = WindowGraph(H, pri)
+        d = BatchDecoder(g, max_iter=50, osd_method="osd_0")
+        assert d.info()["scatter_kernel"]
+        bits, st = d.decode(det)
+        torch.cuda.synchronize()
+        outs.append((bits.cpu().numpy(), st.cpu().numpy()))
+        infos.append(g.info())
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+    assert 0 < infos[0]["scatter_walk_ideal"] <= infos[0]["scatter_walk_cycles"] <= 1.15 * infos[0]["scatter_walk_ideal"], infos[0]
+    assert infos[3]["scatter_walk_cycles"] > infos[0]["scatter_walk_cycles"]          # the old layout and walk cost more LDS cycles in the same model
