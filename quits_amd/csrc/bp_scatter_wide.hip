@@ -39,6 +39,8 @@
 #define QSW_GPRIO 1
 #endif
 
+__device__ __forceinline__ uint4 qs_reuse4(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); return v; }   // (QS_ABL_NOADJ: opaque, so that the reads it feeds stay in the loops)
+
 template <int T, int MW, int CPL, int NSW>
 __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g, ScatGraphDev sg, DecodeArgs a, ScatArgs x)
 {
@@ -111,7 +113,14 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
     const uint32_t cur = (uint32_t)sg.offA;
     const __amdgpu_buffer_rsrc_t adj_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)sg.adjA, 0, (g.max_rdeg_pad / 4 + 2) * m_pad * 16, 0x00020000);
     const int adj_row = m_pad * 16;
-#define QS_ADJ(row_) qs_as_uint4(__builtin_amdgcn_raw_buffer_load_b128(adj_rsrc, adj_voff, (row_) * adj_row, 0))
+#define QS_ADJ_LOAD(row_) qs_as_uint4(__builtin_amdgcn_raw_buffer_load_b128(adj_rsrc, adj_voff, (row_) * adj_row, 0))
+#ifdef QS_ABL_NOADJ      /* timing experiment only (wrong results): one group of offsets per check and pass, reused for every step -- no adjacency traffic in the loops */
+#define QS_ADJ(row_) qs_reuse4(adjc)
+#define QS_ABL_ADJC uint4 adjc = QS_ADJ_LOAD(0);
+#else
+#define QS_ADJ(row_) QS_ADJ_LOAD(row_)
+#define QS_ABL_ADJC
+#endif
     int t = 0, converged = 0;
     for (;;) {
         // ---- gather pass t+1 over L(t); the parity of the hard decisions it meets is the convergence test of iteration t
@@ -126,6 +135,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             if (act[j]) {
                 const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin = (dws[j] >> 16) & 0xFF, wmin4 = wmin & ~3;
                 const int adj_voff = cs[j] * 16;
+                QS_ABL_ADJC
                 const float s1 = S1[j], s2 = S2[j];
                 const uint32_t kold = KOLD[j];
                 const int dc = dcs[j];
@@ -240,6 +250,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             if (act[j]) {
                 const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin = (dws[j] >> 16) & 0xFF, wmin4 = wmin & ~3;
                 const int adj_voff = cs[j] * 16;
+                QS_ABL_ADJC
                 const int dc = dcs[j];
                 const int n1i = (int)A1[j], s1i = (int)S1[j];
                 const int pdif = n1i - s1i, pxq = pdif ^ (n1i + s1i);
@@ -337,6 +348,8 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
         ++t;
     }
 #undef QS_ADJ
+#undef QS_ADJ_LOAD
+#undef QS_ABL_ADJC
     // L(t) - 1 is in the buffer: the scatter pass of the last iteration did not run
 
     // ---- did the bound hold?
@@ -395,7 +408,7 @@ hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg
         return two_words ? launch_scatter_wide_t<128, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
     case 704 * 8 + 2:           // 11 wavefronts; two workgroups per CU: <= 6 per SIMD, 80 registers
         return launch_scatter_wide_t<704, 6, 2, 3>(g, sg, a, x, B, s);
-    case 1024 * 8 + 2: return launch_scatter_wide_t<1024, 4, 2, 3>(g, sg, a, x, B, s);
+    case 1024 * 8 + 2: return launch_scatter_wide_t<1024, 8, 2, 3>(g, sg, a, x, B, s);      // 62 registers: two workgroups of 16 wavefronts per CU where the LDS holds two shots
     case 512 * 8 + 3: return launch_scatter_wide_t<512, 4, 3, 3>(g, sg, a, x, B, s);      // QLP windows: 8 wavefronts x 3 rounds, 89 registers, two workgroups per CU
     default: return hipErrorInvalidValue;
     }

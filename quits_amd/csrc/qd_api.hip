@@ -695,7 +695,8 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         int shape_threads = bp.threads, shape_cpl = 1;
         if (scatter_wide) {
             shape_threads = wide_threads_; shape_cpl = 2;
-            if (m <= 1536 && !std::getenv("QD_SCATTER_WIDE_T704")) { shape_threads = 512; shape_cpl = 3; }    // 19.8 -> 19.3 ms per QLP launch
+            if (std::getenv("QD_SCATTER_WIDE_T1024")) { shape_threads = 1024; shape_cpl = 2; }                // A/B: 16 wavefronts x 2 checks
+            else if (m <= 1536 && !std::getenv("QD_SCATTER_WIDE_T704")) { shape_threads = 512; shape_cpl = 3; }    // 19.8 -> 19.3 ms per QLP launch
         } else if (!std::getenv("QD_SCATTER_CPL1")) {
             if (bp.threads == 1024 && 4 * sc.lds_bytes <= QD_LDS_BYTES) { shape_threads = 512; shape_cpl = 2; }
             else if (bp.threads == 512 && 8 * sc.lds_bytes <= QD_LDS_BYTES && !std::getenv("QD_SCATTER_NO_CPL2_256")) { shape_threads = 256; shape_cpl = 2; }
