@@ -104,8 +104,11 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
     // outgoing signs: edge k of a word of kend edges at bit kend - 1 - k) and what the gather pass of this iteration found
     float S1[CPL], S2[CPL], A1[CPL], A2[CPL], mx2 = 0.f;
     uint32_t KOLD[CPL], KST[CPL], O[CPL][NSW], Q[CPL][NSW];
+    uint32_t FOFF[CPL];                                 // where and what the last scatter pass added for its argmin edge (min2 - min1, signed): given back by the next
+    int FVAL[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) {
+        FOFF[j] = (uint32_t)sg.offA + (uint32_t)(sg.nslots - 32 + (tid & 31)) * 4u; FVAL[j] = 0;      // (a trash slot)
         S1[j] = 0.f; S2[j] = 0.f; A1[j] = FLT_MAX; A2[j] = FLT_MAX; KOLD[j] = 0xFFFFFFFFu; KST[j] = 0u;
 #pragma unroll
         for (int w = 0; w < NSW; ++w) { O[j][w] = 0u; Q[j][w] = 0u; }
@@ -255,9 +258,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                 const int n1i = (int)A1[j], s1i = (int)S1[j];
                 const int pdif = n1i - s1i, pxq = pdif ^ (n1i + s1i);
                 const uint32_t kst = KST[j];
-                const uint32_t ko = KOLD[j] == 0xFFFFFFFFu ? 0u : KOLD[j];     // (no message sent yet: s1 = s2 = 0, any edge will do)
                 const uint32_t fixn_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((kst >> 2) * (uint32_t)adj_row + (kst & 3u) * 4u) + adj_voff, 0, 0);
-                const uint32_t fixo_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((ko >> 2) * (uint32_t)adj_row + (ko & 3u) * 4u) + adj_voff, 0, 0);
                 const int ng = trip >> 2;
 #if QSW_SCAT_SGPR_POS
 #define QS_GROUP_POS(gi_) const int b0_ = 31 - 4 * ((gi_) - 8 * w);
@@ -327,16 +328,11 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                     for (int w = 1; w < NSW; ++w) wd = (kw == w) ? Q[j][w] : wd;
                     const uint32_t sg_ = (wd >> (kendw - 1 - (int)(kst & 31u))) & 1u;
                     const int dlt = (int)A2[j] - n1i;
-                    (void)__hip_atomic_fetch_add(QS_LDS(fixn_off), sg_ ? -dlt : dlt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                {
-                    const int kw = (int)(ko >> 5), kendw = min(trip - 32 * kw, 32);
-                    uint32_t wd = O[j][0];
-#pragma unroll
-                    for (int w = 1; w < NSW; ++w) wd = (kw == w) ? O[j][w] : wd;
-                    const uint32_t sg_ = (wd >> (kendw - 1 - (int)(ko & 31u))) & 1u;
-                    const int dlt = (int)S2[j] - s1i;
-                    (void)__hip_atomic_fetch_add(QS_LDS(fixo_off), sg_ ? dlt : -dlt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int vn = sg_ ? -dlt : dlt;
+                    (void)__hip_atomic_fetch_add(QS_LDS(fixn_off), vn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    // ... which is exactly what the last pass added for ITS argmin edge, kept from then (0 at the trash slot before any message was sent)
+                    (void)__hip_atomic_fetch_add(QS_LDS(FOFF[j]), -FVAL[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    FOFF[j] = fixn_off; FVAL[j] = vn;
                 }
             }
             S1[j] = A1[j]; S2[j] = A2[j]; KOLD[j] = KST[j];
