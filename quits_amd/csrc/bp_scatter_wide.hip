@@ -124,6 +124,13 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
 #define QS_ADJ(row_) QS_ADJ_LOAD(row_)
 #define QS_ABL_ADJC
 #endif
+    // The first group of offsets of a pass (round 0, word 0) is requested BEFORE the barrier the pass starts behind: every wavefront of the workgroup
+    // would otherwise begin the pass by waiting for the same L2 round trip at the same time (QSW_PREFETCH=0: not).
+#ifndef QSW_PREFETCH
+#define QSW_PREFETCH 1
+#endif
+#define QS_ADJ_FIRST qs_as_uint4(__builtin_amdgcn_raw_buffer_load_b128(adj_rsrc, cs[0] * 16, 0, 0))
+    uint4 pf = QS_ADJ_FIRST;
     int t = 0, converged = 0;
     for (;;) {
         // ---- gather pass t+1 over L(t); the parity of the hard decisions it meets is the convergence test of iteration t
@@ -154,7 +161,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                         const int kend = min(trip - k0, 32);                  // multiple of 4
                         const int kplain = min(max(wmin4 - k0, 0), kend);     // groups every lane of the wavefront has in full
                         const int row0 = k0 >> 2;
-                        uint4 nx = QS_ADJ(row0);
+                        uint4 nx = (QSW_PREFETCH && j == 0 && w == 0) ? pf : QS_ADJ(row0);
                         int kk = 0;
                         {
                             uint4 eb;                                         // two groups per trip on two register sets (bp_scatter.hip)
@@ -215,6 +222,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
 #if QSW_GPRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+        if (QSW_PREFETCH) pf = QS_ADJ_FIRST;              // for the scatter pass behind the barrier
         {
             const unsigned long long bal = __ballot(us);
             if ((tid & 63) == 0) misc[32 + (tid >> 6)] = (bal != 0ull);
@@ -292,7 +300,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                         uint32_t own = Q[j][w] << (32 - kendw), xw = (Q[j][w] ^ O[j][w]) << (32 - kendw);
                         const int g1 = min(ng, 8 * w + 8);                    // groups of this word: [8 w, g1)
                         const int gp = min(g1, max(wmin4 >> 2, 8 * w));       // ... of which [8 w, gp) are plain (as in the gather pass: three loops, no test per group)
-                        uint4 ea = QS_ADJ(8 * w), eb;
+                        uint4 ea = (QSW_PREFETCH && j == 0 && w == 0) ? pf : QS_ADJ(8 * w), eb;
                         int gi = 8 * w;
 #pragma unroll 1
                         for (; gi + 2 <= gp; gi += 2) {                       // two groups per trip on two register sets
@@ -340,10 +348,12 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             for (int w = 0; w < NSW; ++w) O[j][w] = Q[j][w];
         }
         __builtin_amdgcn_s_setprio(0);
+        if (QSW_PREFETCH) pf = QS_ADJ_FIRST;              // for the next gather pass
         __syncthreads();
         ++t;
     }
 #undef QS_ADJ
+#undef QS_ADJ_FIRST
 #undef QS_ADJ_LOAD
 #undef QS_ABL_ADJC
     // L(t) - 1 is in the buffer: the scatter pass of the last iteration did not run
@@ -404,7 +414,7 @@ hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg
         return two_words ? launch_scatter_wide_t<128, 8, 2, 2>(g, sg, a, x, B, s) : hipErrorInvalidValue;
     case 704 * 8 + 2:           // 11 wavefronts; two workgroups per CU: <= 6 per SIMD, 80 registers
         return launch_scatter_wide_t<704, 6, 2, 3>(g, sg, a, x, B, s);
-    case 1024 * 8 + 2: return launch_scatter_wide_t<1024, 8, 2, 3>(g, sg, a, x, B, s);      // 62 registers: two workgroups of 16 wavefronts per CU where the LDS holds two shots
+    case 1024 * 8 + 2: return launch_scatter_wide_t<1024, 4, 2, 3>(g, sg, a, x, B, s);      // (a 64-register budget -- two workgroups of 16 wavefronts per CU -- measured no faster on the QLP windows and spills with the prefetch registers)
     case 512 * 8 + 3: return launch_scatter_wide_t<512, 4, 3, 3>(g, sg, a, x, B, s);      // QLP windows: 8 wavefronts x 3 rounds, 89 registers, two workgroups per CU
     default: return hipErrorInvalidValue;
     }
