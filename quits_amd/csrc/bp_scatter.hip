@@ -265,10 +265,8 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_kernel(BpGraphDev g, Scat
     if (!converged && a.want_llr) {
         const int slot = misc[48];
         float *dst = a.llr_ws + (int64_t)slot * n_pad;
-        for (int b = tid; b < sg.nslots; b += T) {       // rows of the OSD workspace are in the gather kernel's bit-slot order
-            const uint32_t k1 = sg.slot_k1[b];
-            if (k1 != 0xFFFFFFFFu) dst[k1] = (float)(*QS_LDS(cur + 4u * (uint32_t)b) + 1) * x.grid_inv;
-        }
+        // (rows of the OSD workspace are in the gather kernel's bit-slot order: walk THAT order, so that the stores are whole lines)
+        for (int k1 = tid; k1 < g.n; k1 += T) dst[k1] = (float)(*QS_LDS(cur + 4u * sg.k1_slot[k1]) + 1) * x.grid_inv;
         if (tid == 0) a.fail_list[slot] = (int32_t)shot;
     }
     if (tid == 0) a.status[shot] = t | (converged << 16) | a.status_or;

@@ -735,8 +735,8 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             }
             if (!walk_ok) { g->mem.release(); delete g; return fail(QD_ECAPACITY, "scatter walk: an edge was not placed exactly once below its check's degree"); }
             g->sc_walk_cycles = walk_cyc; g->sc_walk_ideal = walk_ideal;
-            std::vector<uint32_t> slot_fault((size_t)sc.nslots, 0xFFFFFFFFu), slot_k1((size_t)sc.nslots, 0xFFFFFFFFu);
-            for (int j = 0; j < n; ++j) { slot_fault[sc_slot[j]] = (uint32_t)j; slot_k1[sc_slot[j]] = (uint32_t)bit_slot_of[j]; }
+            std::vector<uint32_t> slot_fault((size_t)sc.nslots, 0xFFFFFFFFu), k1_slot((size_t)n, 0u);
+            for (int j = 0; j < n; ++j) { slot_fault[sc_slot[j]] = (uint32_t)j; k1_slot[bit_slot_of[j]] = (uint32_t)sc_slot[j]; }
             g->h_sc_slot.assign(sc_slot.begin(), sc_slot.end());
             std::vector<uint32_t> deg_w(m_pad / 64, 0u);
             for (int w0 = 0; w0 < m; w0 += 64) {
@@ -746,7 +746,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             }
             int rcs = 0;
             rcs |= g->mem.upload(adjA, &sc.adjA); sc.adjB = sc.adjA;
-            rcs |= g->mem.upload(slot_fault, &sc.slot_fault); rcs |= g->mem.upload(slot_k1, &sc.slot_k1);
+            rcs |= g->mem.upload(slot_fault, &sc.slot_fault); rcs |= g->mem.upload(k1_slot, &sc.k1_slot);
             rcs |= g->mem.upload(deg_w, &sc.deg_w); rcs |= g->mem.upload(chk_deg, &sc.chk_deg);
             if (rcs) { g->mem.release(); delete g; return fail(QD_EHIP, "device allocation failed while uploading the scatter adjacency"); }
             sc.ok = 1;

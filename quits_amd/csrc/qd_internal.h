@@ -65,7 +65,7 @@ struct ScatGraphDev {
     // half-wavefront can meet 32 different banks at every step of the walk (qd_graph_create: scatter_banks / scatter_walk).
     int nslots;                 // accumulators incl. unused slots and 32 trash slots (one per bank) for the steps beyond a check's degree; multiple of 4
     const uint32_t *slot_fault; // [nslots] fault of the slot, 0xFFFFFFFF: none (its accumulator stays 0)
-    const uint32_t *slot_k1;    // [nslots] the fault's bit slot in BpGraphDev's order (the OSD workspace's row layout), 0xFFFFFFFF: none
+    const uint32_t *k1_slot;    // [n] BpGraphDev's bit slot (the OSD workspace's row layout) -> accumulator slot of that fault
     const int32_t *wave_map;    // [wide_cpl][wide_threads / 64] the 64 consecutive check slots (index / 64) a wavefront takes in its j-th round, -1:
                                 //                        none; chosen so that the wavefronts of a workgroup walk equally many edges (slots are sorted by degree)
     int wide_threads, wide_cpl; // 0: one check per lane (bp_scatter.hip); else the workgroup size and the checks per lane of
