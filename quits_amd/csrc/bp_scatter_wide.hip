@@ -143,7 +143,11 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             if (j == 0) __builtin_amdgcn_s_setprio(0); else if (j == CPL - 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
 #endif
             if (act[j]) {
-                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin = (dws[j] >> 16) & 0xFF, wmin4 = wmin & ~3;
+                // (the round's loop bounds are re-derived from one scalar every pass: hoisted out of the iteration loop they, and everything computed
+                //  from them for CPL rounds x NSW words, outgrow the scalar registers and come back through v_readlane)
+                int dwj = dws[j];
+                asm volatile("" : "+s"(dwj));
+                const int trip = dwj & 0xFF, wmax = (dwj >> 8) & 0xFF, wmin = (dwj >> 16) & 0xFF, wmin4 = wmin & ~3;
                 const int adj_voff = cs[j] * 16;
                 QS_ABL_ADJC
                 const float s1 = S1[j], s2 = S2[j];
@@ -259,7 +263,9 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             }
 #endif
             if (act[j]) {
-                const int trip = dws[j] & 0xFF, wmax = (dws[j] >> 8) & 0xFF, wmin = (dws[j] >> 16) & 0xFF, wmin4 = wmin & ~3;
+                int dwj = dws[j];
+                asm volatile("" : "+s"(dwj));
+                const int trip = dwj & 0xFF, wmax = (dwj >> 8) & 0xFF, wmin = (dwj >> 16) & 0xFF, wmin4 = wmin & ~3;
                 const int adj_voff = cs[j] * 16;
                 QS_ABL_ADJC
                 const int dc = dcs[j];
