@@ -195,20 +195,24 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                             QS_EDGE_H(e4.z, k + 2, sb - 2, QS_NOFIX, QS_HPA)
                             QS_EDGE_H(e4.w, k + 3, sb - 3, QS_NOFIX, QS_HPB)
                         }
-#pragma unroll 1
-                        for (; kk < kend; kk += 4) {
-                            const uint4 e4 = nx;
-                            nx = QS_ADJ(row0 + (kk >> 2) + 1);
-                            const int sb = kend - 1 - kk, k = k0 + kk;
-                            // an edge below the smallest degree of the wavefront is real on every lane (no fix), one at or beyond the largest is
-                            // nobody's; only in between does a lane have to ask (wave-uniform tests; k < wmax: a group starts below the largest degree)
+                        // an edge below the smallest degree of the wavefront is real on every lane (no fix), one at or beyond the largest is
+                        // nobody's; only in between does a lane have to ask (wave-uniform tests; k < wmax: a group starts below the largest degree)
 #define QS_TAIL_EDGE(off, q_)                                                                                     \
                             if (k + (q_) < wmin) QS_EDGE(off, k + (q_), sb - (q_), QS_NOFIX)                      \
                             else if (k + (q_) < wmax) QS_EDGE(off, k + (q_), sb - (q_), QS_TAILFIX)               \
                             else { neww <<= 1; ltw <<= 1; }
+#pragma unroll 1
+                        for (; kk + 4 < kend; kk += 4) {
+                            const uint4 e4 = nx;
+                            nx = QS_ADJ(row0 + (kk >> 2) + 1);
+                            const int sb = kend - 1 - kk, k = k0 + kk;
                             QS_TAIL_EDGE(e4.x, 0) QS_TAIL_EDGE(e4.y, 1) QS_TAIL_EDGE(e4.z, 2) QS_TAIL_EDGE(e4.w, 3)
-#undef QS_TAIL_EDGE
                         }
+                        if (kk < kend) {              // the word's last group (for rows of 33..36 faults the second word's only one): nothing to request behind it, no copy
+                            const int sb = kend - 1 - kk, k = k0 + kk;
+                            QS_TAIL_EDGE(nx.x, 0) QS_TAIL_EDGE(nx.y, 1) QS_TAIL_EDGE(nx.z, 2) QS_TAIL_EDGE(nx.w, 3)
+                        }
+#undef QS_TAIL_EDGE
                         neg[w] = neww;
                         par ^= neww;
                         if (ltw) kst = (uint32_t)(k0 + kend - 1 - (int)__builtin_ctz(ltw));   // a later word's improvement overrides an earlier one's
@@ -322,11 +326,12 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                             QS_GROUP_PLAIN(e4, gi)
                         }
 #pragma unroll 1
-                        for (; gi < g1; ++gi) {
+                        for (; gi + 1 < g1; ++gi) {
                             const uint4 e4 = ea;
                             ea = QS_ADJ(gi + 1);
                             QS_GROUP_TAIL(e4, gi)
                         }
+                        if (gi < g1) QS_GROUP_TAIL(ea, gi)          // the word's last group: nothing to request behind it, no copy
                     }
                 }
 #undef QS_GROUP_PLAIN
