@@ -106,7 +106,13 @@ struct OsdRegArgs {
     unsigned long long *dbg;
 };
 
-struct TierState { uint32_t lo_key, lo_idx; int sphase, exhausted, limit; };   // limit: tier size wanted (<= QD_OSD_TIER)
+struct TierState {
+    uint32_t lo_key, lo_idx; int sphase, exhausted, limit;    // limit: tier size wanted (<= QD_OSD_TIER)
+    // guess (in, 0: none): an upper key bound to try first -- every key in [lo_key, guess) is gathered in ONE pass over the posteriors; if that is between
+    // 1 and `limit` columns it IS the tier (any cut gives a valid tier: the elimination depends on the column order, not on where tiers end), otherwise the
+    // radix selection below runs as before.  A tier's cut moves little from shot to shot, so the caller carries it (cut / count, out).
+    uint32_t guess = 0u, cut = 0u, count = 0u;
+};
 
 // Draws the next tier: the <= QD_OSD_TIER not yet consumed columns with the smallest (key, fault index), sorted, as fault
 // indices in order[0..cnt).  State: every column with (key, index) < (lo_key, lo_idx) has been consumed.
@@ -178,7 +184,28 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const ARGS &a, const float *l
                 if (count_ties(lo_key, lo_idx, 0xFFFFFFFFu) > 0) by_index = true;
                 else { lo_key += 1; lo_idx = 0; }
             }
-            if (!by_index) {
+            bool gathered = false;
+            if (!by_index && ts.guess > lo_key) {
+                const uint32_t g_hi = ts.guess;
+                if (tid == 0) red[80] = 0u;
+                __syncthreads();
+                auto spec = [&](uint32_t u, int b) {
+                    if (u >= lo_key && u < g_hi) {
+                        const uint32_t at = atomicAdd(&red[80], 1u);
+                        if (at < lim) sortbuf[at] = ((uint64_t)u << 32) | a.bit_orig[b];
+                    }
+                };
+                if (in_regs) {
+#pragma unroll
+                    for (int i = 0; i < KPT; ++i) spec(kreg[i], tid + i * T);
+                } else scan_keys(spec);
+                __syncthreads();
+                const uint32_t c = red[80];
+                ts.count = c;
+                if (c > 0u && c <= lim) { gathered = true; cnt = (int)c; t_lo = lo_key; t_hi = g_hi; lo_key = g_hi; ts.cut = g_hi; }
+                __syncthreads();                                                   // red[80] / sortbuf are reused below when the guess failed
+            }
+            if (!by_index && !gathered) {
                 // largest bin boundary t_hi with  #{lo_key <= key < t_hi} <= lim   (key 0xFFFFFFFF is reserved for "no
                 // column").  Radix selection: a histogram of the keys over 2048 bins of 2^21 (one LDS atomic per key), a scan
                 // for the bin where the running count passes `lim`; when the cut in front of that bin would leave a thin tier,
@@ -241,6 +268,7 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const ARGS &a, const float *l
                 }
                 __syncthreads();                                                   // hist (= sortbuf) is reused by the gather
                 t_lo = lo_key; t_hi = thi64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)thi64;
+                if (cnt > 0) { ts.cut = t_hi; ts.count = (uint32_t)cnt; }
                 if (cnt == 0) {
                     if (t_hi == 0xFFFFFFFFu) exhausted = true;                 // nothing at or above lo_key
                     else { lo_key = t_hi; lo_idx = 0; by_index = true; }       // more than `lim` columns share the next key value
@@ -261,6 +289,7 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const ARGS &a, const float *l
             }
             if (exhausted) { ts.lo_key = lo_key; ts.lo_idx = lo_idx; ts.sphase = sphase; ts.exhausted = 1; return 0; }
             // gather and sort the tier
+            if (!gathered) {
             if (tid == 0) red[80] = 0u;
             __syncthreads();
             if (in_regs && !by_index) {
@@ -292,6 +321,7 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const ARGS &a, const float *l
                 if (take) sortbuf[atomicAdd(&red[80], 1u)] = ((uint64_t)u << 32) | j;
             });
             __syncthreads();
+            }
             int P = 64;
             while (P < cnt) P <<= 1;
             for (int i = cnt + tid; i < P; i += T) sortbuf[i] = ~0ull;

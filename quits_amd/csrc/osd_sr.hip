@@ -40,6 +40,9 @@
 #include <cstdlib>
 #include <algorithm>
 
+#ifndef QD_SR_TIER_GUESS
+#define QD_SR_TIER_GUESS 1       // 0: every first tier through the radix selection (A/B)
+#endif
 struct OsdSrArgs {
     int m, n, m_pad, n_pad, mw, out_words, upd_rows, ell_log2;
     int o_tb, o_rowpiv, o_prow, o_pcol, o_ppos, o_nz, o_cand, o_stq, o_stsp, o_bcols, o_red, o_out, o_order;
@@ -82,6 +85,7 @@ __global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrA
     const int m = a.m, m_pad = a.m_pad, mw = a.mw, dlog = a.ell_log2;
     uint64_t *qglb = a.q_spill + (size_t)blockIdx.x * (size_t)(mw > KWR ? mw - KWR : 0) * m_pad;
     const int nfail = *a.fail_count;
+    uint32_t tier_guess = 0u;                               // carried from shot to shot: where the last first tier was cut, nudged towards 70 % fill
     for (int item = blockIdx.x; item < nfail; item += gridDim.x) {
         const int slot = item;
         const int64_t shot = a.fail_list[slot];
@@ -119,9 +123,19 @@ __global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrA
         uint32_t lo_key = 0, lo_idx = 0;                 // every column with (key, fault index) < (lo_key, lo_idx) has been consumed
         while (!done) {
             TierState ts{lo_key, lo_idx, sphase, 0, ntier == 0 ? a.tier_first : QD_OSD_TIER};
+            const bool first_tier = ntier == 0;
+            if (first_tier) ts.guess = tier_guess;          // (TierState::guess)
             ++ntier;
             const int cnt = qd_osd_draw_tier<T, QD_OSD_KPT, OsdSrArgs, 6>(a, llr, sortbuf, order, red, sumbuf, ts);
             lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
+            if (first_tier && QD_SR_TIER_GUESS) {
+                // aim the next shot's first tier at 55..85 % of its size: fuller, and a shot with a few more unreliable columns overflows it (one pass
+                // wasted, then the radix selection); emptier, and more shots need a second tier
+                const uint32_t lim1 = (uint32_t)a.tier_first, step = 1u << 20;      // an eighth of a binade of the monotone key
+                if (ts.cut) tier_guess = ts.count * 20u > lim1 * 17u ? ts.cut - step : (ts.count * 20u < lim1 * 11u ? ts.cut + step : ts.cut);
+                else if (tier_guess) tier_guess = ts.count > lim1 ? tier_guess - step : tier_guess;   // (overflowed and the selection then drew ties by index: rare)
+                if (tier_guess > 0xFFFFFFFFu - step) tier_guess = 0u;
+            }
             QD_TICK(0)
             if (ts.exhausted) break;
             for (int base = 0; base < cnt && !done; base += 64, ++bseq) {
