@@ -184,28 +184,13 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const ARGS &a, const float *l
                 if (count_ties(lo_key, lo_idx, 0xFFFFFFFFu) > 0) by_index = true;
                 else { lo_key += 1; lo_idx = 0; }
             }
-            bool gathered = false;
-            if (!by_index && ts.guess > lo_key) {
-                const uint32_t g_hi = ts.guess;
-                if (tid == 0) red[80] = 0u;
-                __syncthreads();
-                auto spec = [&](uint32_t u, int b) {
-                    if (u >= lo_key && u < g_hi) {
-                        const uint32_t at = atomicAdd(&red[80], 1u);
-                        if (at < lim) sortbuf[at] = ((uint64_t)u << 32) | a.bit_orig[b];
-                    }
-                };
-                if (in_regs) {
-#pragma unroll
-                    for (int i = 0; i < KPT; ++i) spec(kreg[i], tid + i * T);
-                } else scan_keys(spec);
-                __syncthreads();
-                const uint32_t c = red[80];
-                ts.count = c;
-                if (c > 0u && c <= lim) { gathered = true; cnt = (int)c; t_lo = lo_key; t_hi = g_hi; lo_key = g_hi; ts.cut = g_hi; }
-                __syncthreads();                                                   // red[80] / sortbuf are reused below when the guess failed
-            }
-            if (!by_index && !gathered) {
+            // the guess first (TierState::guess): the gather below runs with [lo_key, guess) as the cut; if that is not 1..lim columns the selection runs and
+            // the gather is repeated (one instance of the pass over the posteriors serves both)
+            bool spec = !by_index && !in_regs && ts.guess > lo_key;
+            for (;;) {
+            if (spec) { t_lo = lo_key; t_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)ts.guess); }
+            else {
+            if (!by_index) {
                 // largest bin boundary t_hi with  #{lo_key <= key < t_hi} <= lim   (key 0xFFFFFFFF is reserved for "no
                 // column").  Radix selection: a histogram of the keys over 2048 bins of 2^21 (one LDS atomic per key), a scan
                 // for the bin where the running count passes `lim`; when the cut in front of that bin would leave a thin tier,
@@ -288,8 +273,8 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const ARGS &a, const float *l
                 if (i_hi >= (uint32_t)n) { lo_key += 1; lo_idx = 0; } else lo_idx = i_hi;
             }
             if (exhausted) { ts.lo_key = lo_key; ts.lo_idx = lo_idx; ts.sphase = sphase; ts.exhausted = 1; return 0; }
+            }
             // gather and sort the tier
-            if (!gathered) {
             if (tid == 0) red[80] = 0u;
             __syncthreads();
             if (in_regs && !by_index) {
@@ -318,9 +303,20 @@ __device__ QD_OSD_TIER_INLINE int qd_osd_draw_tier(const ARGS &a, const float *l
                 uint32_t j = 0;
                 if (by_index) { if (u == t_lo) { j = a.bit_orig[b]; take = (j >= i_lo && j < i_hi); } }
                 else if (u >= t_lo && u < t_hi) { j = a.bit_orig[b]; take = true; }
-                if (take) sortbuf[atomicAdd(&red[80], 1u)] = ((uint64_t)u << 32) | j;
+                if (take) {
+                    const uint32_t at = atomicAdd(&red[80], 1u);
+                    if (at < (uint32_t)QD_OSD_TIER) sortbuf[at] = ((uint64_t)u << 32) | j;      // (a guess may overflow the buffer; a selected cut never does)
+                }
             });
             __syncthreads();
+            if (!spec) break;
+            {
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)red[80]);
+                ts.count = c;
+                if (c > 0u && c <= lim) { cnt = (int)c; lo_key = t_hi; ts.cut = t_hi; break; }
+                spec = false;                                                      // no column or too many: select, gather again
+                __syncthreads();
+            }
             }
             int P = 64;
             while (P < cnt) P <<= 1;

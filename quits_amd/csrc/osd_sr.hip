@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrA
     const int m = a.m, m_pad = a.m_pad, mw = a.mw, dlog = a.ell_log2;
     uint64_t *qglb = a.q_spill + (size_t)blockIdx.x * (size_t)(mw > KWR ? mw - KWR : 0) * m_pad;
     const int nfail = *a.fail_count;
-    uint32_t tier_guess = 0u;                               // carried from shot to shot: where the last first tier was cut, nudged towards 70 % fill
+    if (tid == 0) red[81] = 0u;                             // red[81]: carried from shot to shot -- where the last first tier was cut, nudged towards 70 % fill
+                                                            // (in LDS, not in a register: the kernel sits at its register budget; the barriers of a shot's set-up order the accesses)
     for (int item = blockIdx.x; item < nfail; item += gridDim.x) {
         const int slot = item;
         const int64_t shot = a.fail_list[slot];
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrA
         while (!done) {
             TierState ts{lo_key, lo_idx, sphase, 0, ntier == 0 ? a.tier_first : QD_OSD_TIER};
             const bool first_tier = ntier == 0;
-            if (first_tier) ts.guess = tier_guess;          // (TierState::guess)
+            if (first_tier) ts.guess = red[81];             // (TierState::guess)
             ++ntier;
             const int cnt = qd_osd_draw_tier<T, QD_OSD_KPT, OsdSrArgs, 6>(a, llr, sortbuf, order, red, sumbuf, ts);
             lo_key = ts.lo_key; lo_idx = ts.lo_idx; sphase = ts.sphase;
@@ -132,9 +133,11 @@ __global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrA
                 // aim the next shot's first tier at 55..85 % of its size: fuller, and a shot with a few more unreliable columns overflows it (one pass
                 // wasted, then the radix selection); emptier, and more shots need a second tier
                 const uint32_t lim1 = (uint32_t)a.tier_first, step = 1u << 20;      // an eighth of a binade of the monotone key
-                if (ts.cut) tier_guess = ts.count * 20u > lim1 * 17u ? ts.cut - step : (ts.count * 20u < lim1 * 11u ? ts.cut + step : ts.cut);
-                else if (tier_guess) tier_guess = ts.count > lim1 ? tier_guess - step : tier_guess;   // (overflowed and the selection then drew ties by index: rare)
-                if (tier_guess > 0xFFFFFFFFu - step) tier_guess = 0u;
+                uint32_t g = ts.guess;
+                if (ts.cut) g = ts.count * 20u > lim1 * 17u ? ts.cut - step : (ts.count * 20u < lim1 * 11u ? ts.cut + step : ts.cut);
+                else if (g) g = ts.count > lim1 ? g - step : g;                     // (overflowed and the selection then drew ties by index: rare)
+                if (g > 0xFFFFFFFFu - step) g = 0u;
+                if (tid == 0) red[81] = g;                  // (read again by the next shot, behind its set-up barriers)
             }
             QD_TICK(0)
             if (ts.exhausted) break;
