@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                 const uint32_t fixn_off = __builtin_amdgcn_raw_buffer_load_b32(adj_rsrc, (int)((kst >> 2) * (uint32_t)adj_row + (kst & 3u) * 4u) + adj_voff, 0, 0);
                 const int ng = trip >> 2;
 #if QSW_SCAT_SGPR_POS
-#define QS_GROUP_POS(gi_) const int b0_ = 31 - 4 * ((gi_) - 8 * w);
+#define QS_GROUP_POS(gi_) const int b0_ = kendw - 1 - 4 * ((gi_) - 8 * w);      /* (the words are used as they are: edge k of the word at bit kendw - 1 - k) */
 #define QS_GROUP_STEP
 #else
 #define QS_GROUP_POS(gi_) constexpr int b0_ = 31;
@@ -307,7 +307,11 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
                 for (int w = 0; w < NSW; ++w) {
                     if (32 * w < trip) {
                         const int kendw = min(trip - 32 * w, 32);
+#if QSW_SCAT_SGPR_POS
+                        const uint32_t own = Q[j][w], xw = Q[j][w] ^ O[j][w];
+#else
                         uint32_t own = Q[j][w] << (32 - kendw), xw = (Q[j][w] ^ O[j][w]) << (32 - kendw);
+#endif
                         const int g1 = min(ng, 8 * w + 8);                    // groups of this word: [8 w, g1)
                         const int gp = min(g1, max(wmin4 >> 2, 8 * w));       // ... of which [8 w, gp) are plain (as in the gather pass: three loops, no test per group)
                         uint4 ea = (QSW_PREFETCH && j == 0 && w == 0) ? pf : QS_ADJ(8 * w), eb;
