@@ -73,7 +73,7 @@ typedef struct qd_params {
     double ms_scaling_factor;   /* not exposed by the reference wrapper -> ldpc default 1.0; 0 = 1-2^-it */
 } qd_params;
 
-int qd_version(void);
+int qd_version(void);                 /* 101 (100: qd_graph_info filled 10 entries, no qd_decoder_postproc_kernel) */
 const char *qd_last_error(void);
 /* Number of visible HIP devices (0 if none): lets a host fail loudly before building anything. */
 int qd_device_count(void);

@@ -66,6 +66,9 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     L.qd_version.restype = C.c_int
+    if L.qd_version() < 101:              # 101: qd_graph_info fills 12 entries -- an older library would be handed a buffer it does not know about
+        raise RuntimeError("quits_amd: %s is version %d, this package needs >= 101 -- rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)"
+                           % (LIB_PATH, L.qd_version()))
     L.qd_last_error.restype = C.c_char_p
     L.qd_device_count.restype = C.c_int
     L.qd_graph_create.argtypes = [i32, i32, vp, vp, vp, i32, C.POINTER(vp)]

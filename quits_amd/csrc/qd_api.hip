@@ -301,7 +301,7 @@ static void scatter_walk(int m, const int32_t *row_ptr, const int32_t *col_idx, 
     }
 }
 
-extern "C" int qd_version(void) { return 100; }
+extern "C" int qd_version(void) { return 101; }      // 101: qd_graph_info fills 12 entries (was 10); qd_decoder_postproc_kernel
 extern "C" const char *qd_last_error(void) { return g_err; }
 extern "C" int qd_device_count(void)
 {
