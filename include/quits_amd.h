@@ -73,7 +73,7 @@ typedef struct qd_params {
     double ms_scaling_factor;   /* not exposed by the reference wrapper -> ldpc default 1.0; 0 = 1-2^-it */
 } qd_params;
 
-int qd_version(void);                 /* 101 (100: qd_graph_info filled 10 entries, no qd_decoder_postproc_kernel) */
+int qd_version(void);                 /* 102 (101: qd_graph_info wrote 12 entries; 102: 10 again + qd_graph_info_ex) */
 const char *qd_last_error(void);
 /* Number of visible HIP devices (0 if none): lets a host fail loudly before building anything. */
 int qd_device_count(void);
@@ -85,10 +85,14 @@ int qd_device_count(void);
 int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, const int32_t *col_idx, const double *priors,
                     int32_t device, qd_graph **out);
 void qd_graph_destroy(qd_graph *g);
-/* info[0..11] = m, n, nnz, max row weight, max column weight, BP block threads, BP LDS bytes, OSD block threads,
- *               OSD LDS bytes, GF(2) rank of the matrix, modelled LDS cycles of one pass of the scatter kernels' walk over the
- *               accumulators (bank conflicts included) and the same without any conflict (0, 0: the window does not run there) */
+/* info[0..9] = m, n, nnz, max row weight, max column weight, BP block threads, BP LDS bytes, OSD block threads,
+ *              OSD LDS bytes, GF(2) rank of the matrix.  Exactly 10 entries are written (as in library version 100; version 101
+ *              wrote 12 -- callers built against that header should move to qd_graph_info_ex). */
 int qd_graph_info(const qd_graph *g, int32_t *info);
+/* The same with the caller saying how many int32 entries `info` has room for; entries 10, 11 = modelled LDS cycles of one pass of
+ * the scatter kernels' walk over the accumulators (bank conflicts included) and the same without any conflict (0, 0: the window
+ * does not run there); entries beyond the ones this version knows are set to 0. */
+int qd_graph_info_ex(const qd_graph *g, int32_t *info, int32_t n_entries);
 
 /* ---- decoder: replaces BpOsdDecoder.__init__'s parameter half. */
 int qd_decoder_create(const qd_graph *g, const qd_params *params, qd_decoder **out);

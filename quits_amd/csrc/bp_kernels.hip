@@ -38,6 +38,11 @@ template <int I> __device__ __forceinline__ uint32_t qd_adj_get(const uint4 &v)
 #ifndef QD_BP_MINWAVES
 #define QD_BP_MINWAVES 8   // waves per SIMD the register allocator must leave room for (8 = two 1024-thread workgroups per CU)
 #endif
+// round 6: at 8 wavefronts per SIMD (64 registers) every instantiation spilled 12-16 bytes per lane; K1 is a fall-back now, so the budget is the
+// one that keeps it out of scratch (tests/test_api.py asserts it)
+#ifndef QD_BP_MINWAVES_T
+#define QD_BP_MINWAVES_T(T) ((T) == 1024 ? 4 : 6)
+#endif
 
 // min(a, |b|) as the single instruction it is: fminf() makes the compiler quiet a possible signalling NaN first
 // (v_max_f32 x, x, x -- one more 4-clock instruction per four edges); neither operand can be a NaN here.
@@ -388,26 +393,15 @@ static hipError_t launch_bp_m(const BpGraphDev &g, const DecodeArgs &a, int64_t 
     return hipGetLastError();
 }
 
-// A window whose LDS footprint leaves room for one 1024-thread workgroup per CU (4 wavefronts per SIMD) gets the
-// instantiation that may use 128 registers instead of 64 (QLP-1020 windows: 38.0 -> 33.3 ms per launch).
-template <int T, int NCH, int SM, typename ADJ4>
-static hipError_t launch_bp_k(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
-{
-    if (T == 1024 && 2 * g.lds_bytes > QD_LDS_BYTES) return launch_bp_m<T, NCH, SM, ADJ4, (T == 1024 ? 4 : QD_BP_MINWAVES)>(g, a, B, s);
-    return launch_bp_m<T, NCH, SM, ADJ4, QD_BP_MINWAVES>(g, a, B, s);
-}
-
+// Round 6: K1 is the recheck / coarse-grid pass of the scatter kernels and the flooding min-sum kernel of the windows they do not take; it is on
+// no timed path.  Its 96 instantiations (16-bit adjacency, a 128-register build for QLP-size windows) are down to the 36 a graph can select:
+// threads x record words x sign mode.
 template <int T, int NCH>
 static hipError_t launch_bp_n(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hipStream_t s)
 {
-    if (g.adj32) {
-        if (g.sign_mode == 0) return launch_bp_k<T, NCH, 0, uint4>(g, a, B, s);
-        if (g.sign_mode == 1) return launch_bp_k<T, NCH, 1, uint4>(g, a, B, s);
-        return launch_bp_k<T, NCH, 2, uint4>(g, a, B, s);
-    }
-    if (g.sign_mode == 0) return launch_bp_k<T, NCH, 0, uint2>(g, a, B, s);
-    if (g.sign_mode == 1) return launch_bp_k<T, NCH, 1, uint2>(g, a, B, s);
-    return launch_bp_k<T, NCH, 2, uint2>(g, a, B, s);
+    if (g.sign_mode == 0) return launch_bp_m<T, NCH, 0, uint4, QD_BP_MINWAVES_T(T)>(g, a, B, s);
+    if (g.sign_mode == 1) return launch_bp_m<T, NCH, 1, uint4, QD_BP_MINWAVES_T(T)>(g, a, B, s);
+    return launch_bp_m<T, NCH, 2, uint4, QD_BP_MINWAVES_T(T)>(g, a, B, s);
 }
 
 template <int T>

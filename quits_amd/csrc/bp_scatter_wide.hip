@@ -388,7 +388,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
     for (int b = tid; b < sg.nslots; b += T)
         if (*QS_LDS(cur + 4u * (uint32_t)b) < 0) {
             const uint32_t jf = sg.slot_fault[b];
-            atomicOr(&outw[jf >> 5], 1u << (jf & 31u));
+            if (jf != 0xFFFFFFFFu) atomicOr(&outw[jf >> 5], 1u << (jf & 31u));   // (unused and trash slots stay at 0 today; never index LDS with their marker)
         }
     if (!converged && a.want_llr && tid == 0) misc[48] = atomicAdd(a.fail_count, 1);
     __syncthreads();

@@ -750,7 +750,9 @@ __device__ QD_OSD_PANEL_INLINE int qd_osd_panel_wave0(const OsdLds &S, const uin
 
 template <int T, int RPT, bool WFULL>
 #ifndef QD_OSD0_WPS
-#define QD_OSD0_WPS (T == 512 ? 6 : T / 128)   // 512 threads: three workgroups per CU (85 registers)
+#define QD_OSD0_WPS (T == 512 ? 4 : T / 128)   // 512 threads: two workgroups per CU, 128 registers.  (Rounds 2-5: three per CU at 85 registers and 88-144 bytes of
+                                               // scratch per lane -- the faster trade while this was THE OSD-0 kernel; since round 4 it only takes the shots qd_osd0_sr_kernel
+                                               // hands over and the windows that kernel does not fit, and a fall-back does not get to spill: ScratchSize 0, tests/test_api.py)
 #endif
 __global__ void __launch_bounds__(T, (WFULL ? T / 256 : QD_OSD0_WPS)) qd_osd0_reg_kernel(OsdRegArgs a)   // full-rank instantiation: one workgroup per CU, so twice the registers
 {

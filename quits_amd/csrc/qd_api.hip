@@ -301,7 +301,7 @@ static void scatter_walk(int m, const int32_t *row_ptr, const int32_t *col_idx, 
     }
 }
 
-extern "C" int qd_version(void) { return 101; }      // 101: qd_graph_info fills 12 entries (was 10); qd_decoder_postproc_kernel
+extern "C" int qd_version(void) { return 102; }      // 102: qd_graph_info fills 10 entries again, qd_graph_info_ex(g, info, n) the rest; 101: qd_decoder_postproc_kernel
 extern "C" const char *qd_last_error(void) { return g_err; }
 extern "C" int qd_device_count(void)
 {
@@ -384,9 +384,9 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
     const int neg_words_ = (max_rdeg_pad + 31) / 32;
     const int off_chk_ = 0, off_cneg_ = (m_pad + 4) * 16;
     const int off_llr_ = off_cneg_ + (sign_mode == 2 ? align16((neg_words_ - 1) * m_pad * 4) : 0);
-    // 32-bit offsets always: the 16-bit packing halves 66 KB of L2-resident adjacency but costs one unpacking instruction per
-    // edge in a loop that is bound by vector-ALU issue (headline BP 62.0 -> 60.4 ms per 65536 shots); QD_ADJ16 brings it back
-    const int adj32 = (off_llr_ + (n_pad + 1) * 4 > 65535 || !std::getenv("QD_ADJ16")) ? 1 : 0;
+    // 32-bit offsets always (round 6: the 16-bit packing -- half of 66 KB of L2-resident adjacency for one more unpacking instruction per
+    // edge, 60.4 -> 62.0 ms when K1 was the headline kernel -- was only reachable through an environment knob and doubled K1's instantiations: removed)
+    const int adj32 = 1;
     const int rec_words = ((1 + max_cdeg) + 3) & ~3;
     std::vector<uint8_t> chk_deg(m_pad, 0), bit_deg(n_pad, 0);
     std::vector<int32_t> chk_degp_w(m_pad / 64, 0);
@@ -411,10 +411,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         chk_degp_w[w0 / 64] = ((mx + 3) & ~3) | (mx << 16);      // trip count | exact maximum (edges beyond it are padding for every lane)
     }
     // check -> fault adjacency, ELL-transposed, as LDS byte offsets of the posteriors
-    std::vector<uint16_t> chk_adj16;
-    std::vector<uint32_t> chk_adj32;
-    if (adj32) chk_adj32.assign((size_t)max_rdeg_pad * m_pad, (uint32_t)(off_llr_ + dummy_bit * 4));
-    else chk_adj16.assign((size_t)max_rdeg_pad * m_pad, (uint16_t)(off_llr_ + dummy_bit * 4));
+    std::vector<uint32_t> chk_adj32((size_t)max_rdeg_pad * m_pad, (uint32_t)(off_llr_ + dummy_bit * 4));
     // Order in which a check walks its edges.  Nothing the check pass computes depends on it (minimum, second minimum and the
     // sign parity are symmetric; a tie for the minimum leaves min1 = min2, so it does not matter which edge carries the argmin
     // label), so it is chosen for the LDS: step k of a wavefront is one ds_read_b32 gather, serviced in two groups of 32 lanes
@@ -480,8 +477,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
             const int k = step_of[e];
             const uint32_t off = (uint32_t)off_llr_ + (uint32_t)bit_slot_of[col_idx[e]] * 4u;
             const size_t at = ((size_t)(k >> 2) * m_pad + s) * 4 + (k & 3);      // [group of 4 edges][slot][4]: one vector load per group
-            if (adj32) chk_adj32[at] = off;
-            else chk_adj16[at] = (uint16_t)off;
+            chk_adj32[at] = off;
         }
     }
     // fault records: prior + (check state offset, where that check keeps this edge's sign)
@@ -633,8 +629,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         bp.bit_thr[q] = cnt;
     }
     int rc = 0;
-    if (adj32) { const uint32_t *p32 = nullptr; rc |= g->mem.upload(chk_adj32, &p32); bp.chk_adj = p32; }
-    else { const uint16_t *p16 = nullptr; rc |= g->mem.upload(chk_adj16, &p16); bp.chk_adj = p16; }
+    { const uint32_t *p32 = nullptr; rc |= g->mem.upload(chk_adj32, &p32); bp.chk_adj = p32; }
     rc |= g->mem.upload(chk_degp_w, &bp.chk_degp_w);
     rc |= g->mem.upload(chk_orig_u, &bp.chk_orig);
     rc |= g->mem.upload(bit_rec, &bp.bit_rec);
@@ -871,7 +866,7 @@ extern "C" int qd_graph_create(int32_t m, int32_t n, const int32_t *row_ptr, con
         od.f_off_hist = 0;
         // three workgroups per CU where the window allows it (two Q planes in LDS, the rest in the HBM spill): most of a shot is spent
         // in single-wavefront phases, so the third workgroup is worth more than the planes (headline 10.8 -> 10.1 ms, p = 6e-3 164 -> 154 ms)
-        const int per_cu0 = std::getenv("QD_OSD_PER_CU") ? std::atoi(std::getenv("QD_OSD_PER_CU")) : 3;
+        const int per_cu0 = std::getenv("QD_OSD_PER_CU") ? std::atoi(std::getenv("QD_OSD_PER_CU")) : 2;   // (the register budget of qd_osd0_reg_kernel<512, ., false>: two per CU)
         for (int per_cu = per_cu0; per_cu >= 1 && od.f_lds_bytes == 0; --per_cu)
             od.f_lds_bytes = lay(per_cu, false, od.f_off, od.f_off_sort, od.f_off_order, od.f_off_pivmask, od.f_off_npl, od.f_kw);
         od.w_lds_bytes = lay(1, true, od.w_off, od.w_off_sort, od.w_off_order, od.w_off_pivmask, od.w_off_npl, od.w_kw);
@@ -939,13 +934,27 @@ static int host_rank(qd_graph *g)
     return rank;
 }
 
+// qd_graph_info fills exactly 10 entries, as it did in library version 100 (version 101 wrote 12 into the caller's buffer, an
+// 8-byte overwrite for a C caller compiled against the older header); whoever wants more says how many it has room for.
+static void graph_info_fill(const qd_graph *g, int32_t *info, int n_entries)
+{
+    const int32_t v[12] = {g->m, g->n, g->nnz, g->max_rdeg, g->max_cdeg, g->bp.threads, g->bp.lds_bytes, g->osd.threads, g->osd.lds_bytes,
+                           n_entries > 9 ? host_rank(const_cast<qd_graph *>(g)) : 0, (int32_t)g->sc_walk_cycles, (int32_t)g->sc_walk_ideal};
+    for (int i = 0; i < n_entries && i < 12; ++i) info[i] = v[i];
+    for (int i = 12; i < n_entries; ++i) info[i] = 0;
+}
+
 extern "C" int qd_graph_info(const qd_graph *g, int32_t *info)
 {
     if (!g || !info) return fail(QD_EINVAL, "null argument");
-    info[0] = g->m; info[1] = g->n; info[2] = g->nnz; info[3] = g->max_rdeg; info[4] = g->max_cdeg;
-    info[5] = g->bp.threads; info[6] = g->bp.lds_bytes; info[7] = g->osd.threads; info[8] = g->osd.lds_bytes;
-    info[9] = host_rank(const_cast<qd_graph *>(g));
-    info[10] = (int32_t)g->sc_walk_cycles; info[11] = (int32_t)g->sc_walk_ideal;
+    graph_info_fill(g, info, 10);
+    return QD_OK;
+}
+
+extern "C" int qd_graph_info_ex(const qd_graph *g, int32_t *info, int32_t n_entries)
+{
+    if (!g || !info || n_entries < 0) return fail(QD_EINVAL, "null argument or negative n_entries");
+    graph_info_fill(g, info, n_entries);
     return QD_OK;
 }
 

@@ -18,6 +18,9 @@ from collections import OrderedDict
 
 from ..dem import as_dem
 
+import threading as _threading
+
+_MATRIX_LOCK = _threading.Lock()      # get / move_to_end / insert / evict under it; the copies handed out are made outside
 _MATRIX_CACHE: "OrderedDict[str, tuple]" = OrderedDict()   # circuit structure (dem.structure_key) -> (check, observable, fold order of the priors)
 
 
@@ -60,11 +63,16 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
     """
     dem = as_dem(dem)
     skey = getattr(dem, "structure_key", None)
-    if skey is not None and skey in _MATRIX_CACHE:
+    hit = None
+    if skey is not None:
+        with _MATRIX_LOCK:
+            hit = _MATRIX_CACHE.get(skey)
+            if hit is not None:
+                _MATRIX_CACHE.move_to_end(skey)
+    if hit is not None:
         # same circuit structure, other probabilities (quits_amd/dem.py): the matrices are the cached ones, the priors are folded again in
         # the order the loop below folds them -- the same floating-point numbers
-        check, obs, steps, no_det = _MATRIX_CACHE[skey]
-        _MATRIX_CACHE.move_to_end(skey)
+        check, obs, steps, no_det = hit
         for inst in no_det:                 # the reference prints an error without detectors on every call (base.py:114-115)
             print(inst)
         p_err = np.fromiter((e[0] for e in dem.errors), dtype=np.float64, count=len(dem.errors))
@@ -121,9 +129,11 @@ def detector_error_model_to_matrix(dem) -> Tuple[csc_matrix, csc_matrix, np.ndar
         cap = _struct_cap()                  # QD_DEM_STRUCT_CACHE sizes (and switches off) both structure caches
         if cap > 0:
             steps = fold_steps(members)
-            _MATRIX_CACHE[skey] = (check.copy(), obs.copy(), steps, tuple(no_det_insts))
-            while len(_MATRIX_CACHE) > cap:
-                _MATRIX_CACHE.popitem(last=False)
+            entry = (check.copy(), obs.copy(), steps, tuple(no_det_insts))
+            with _MATRIX_LOCK:
+                _MATRIX_CACHE[skey] = entry
+                while len(_MATRIX_CACHE) > cap:
+                    _MATRIX_CACHE.popitem(last=False)
     return check, obs, np.array(priors)
 
 

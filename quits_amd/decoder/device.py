@@ -45,8 +45,8 @@ class WindowGraph:
         self.priors = pri
 
     def info(self) -> dict:
-        arr = (C.c_int32 * 12)()                     # (12 entries since library version 101, checked when the library is loaded)
-        _lib.check(self._L.qd_graph_info(self._h, arr))
+        arr = (C.c_int32 * 12)()
+        _lib.check(self._L.qd_graph_info_ex(self._h, arr, 12))
         keys = ("m", "n", "nnz", "max_row_weight", "max_col_weight", "bp_threads", "bp_lds_bytes", "osd_threads",
                 "osd_lds_bytes", "rank", "scatter_walk_cycles", "scatter_walk_ideal")
         return dict(zip(keys, [int(x) for x in arr]))

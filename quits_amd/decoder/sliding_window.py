@@ -149,7 +149,8 @@ class DeviceWindowPlan:
         self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", 4 * self.chunk))   # shots per staged piece (>= 2 chunks: the pipelined driver)
         self.device = _current_device()      # graphs, decoders and workspaces were created on this device
         import threading
-        self._lock = threading.Lock()        # one decode_host at a time per plan: staging buffers, side streams and workspaces are per plan
+        self._lock = threading.RLock()       # one decode_host at a time per plan (staging buffers, side streams and workspaces are per plan);
+                                             # re-entrant, and the plan cache takes it (non-blocking) before releasing an idle plan's workspaces
 
     def release_workspaces(self):
         """Hand the decoders' device workspaces and the staging buffers back (the plan itself -- graphs, decoders, matrices --
@@ -213,6 +214,7 @@ class DeviceWindowPlan:
             raise RuntimeError("this plan was built on cuda:%d but the current device is cuda:%d (plans are per device; the plan "
                                "cache keys on the current device)" % (self.device, torch.cuda.current_device()))
         with self._lock:
+            self._ws_live = True                 # (a concurrent cache lookup may have released them since this plan was handed out)
             return self._decode_host_locked(zcheck_samples)
 
     def _decode_host_locked(self, zcheck_samples):
@@ -392,27 +394,18 @@ def _kwargs_for_device(d, cls):
 # (0.4 s for the headline window, 15 s for the QLP [[1020,136]] circuit).  Plans are kept, least recently used first out, keyed on
 # everything they depend on: the circuit (hash of its text), hz, W, F, the number of rounds, both plug-in classes and both option
 # dicts -- and the CUDA device that is current, because graphs, decoders and workspaces are bound to the device they were built on.
-# QD_PLAN_CACHE = number of plans kept (default 8, 0 = off).  The cache is PER THREAD: a plan carries mutable state
-# (staging buffers, side streams, decoder workspaces), so two threads never share one; within a thread the plan's own lock orders
-# re-entrant use.  Releasing the idle plans' workspaces therefore only ever touches plans of the calling thread.
+# QD_PLAN_CACHE = number of plans kept (default 8, 0 = off).  ONE cache per process (the per-thread caches of round 5 rebuilt
+# the plan and kept a second set of graphs, decoders and workspaces per calling thread), guarded by a module lock; a plan carries mutable
+# state (staging buffers, side streams, decoder workspaces), so its USE is serialised by the plan's own re-entrant lock
+# (DeviceWindowPlan.decode_host): two threads calling with the same arguments share one plan and take turns, threads with different
+# arguments run different plans side by side.  Only plans that are in use keep device workspaces: a lookup releases the workspaces of
+# every other cached plan whose lock is free (whatever thread used it last); a plan that another thread is decoding with is left alone.
 import threading as _threading
+from collections import OrderedDict as _OrderedDict
 
-_TLS = _threading.local()
-
-
-def _tls_cache(create=False):
-    c = getattr(_TLS, "cache", None)
-    if c is None and create:
-        from collections import OrderedDict
-        c = _TLS.cache = OrderedDict()
-    return c
-
-
-def _tls_stats():
-    st = getattr(_TLS, "stats", None)
-    if st is None:
-        st = _TLS.stats = {"hits": 0, "misses": 0}
-    return st
+_CACHE = _OrderedDict()
+_CACHE_LOCK = _threading.RLock()
+_CACHE_STATS = {"hits": 0, "misses": 0}
 
 
 def _freeze(v):
@@ -468,44 +461,53 @@ def _plan_cache_size():
 
 
 def cached_plan(key, build):
-    """The plan stored under `key` in the calling thread's cache, built with build() on a miss."""
+    """The plan stored under `key` in the process-wide cache, built with build() on a miss (under the cache lock: two threads asking for
+    the same new plan build it once)."""
     cap = _plan_cache_size()
-    stats = _tls_stats()
-    if cap == 0:
-        stats["misses"] += 1
-        return build()
-    cache = _tls_cache(create=True)
-    plan = cache.get(key)
-    # only the plan in use keeps device workspaces (the per-edge BP kernel sizes its message planes for tens of GB): the
-    # others keep their graphs and decoders and size their workspaces again when they are used next
-    for k, other in cache.items():
-        if k != key and hasattr(other, "release_workspaces") and getattr(other, "_ws_live", True):
-            other.release_workspaces()
-            other._ws_live = False
-    if plan is not None:
-        cache.move_to_end(key)
-        stats["hits"] += 1
-    else:
-        stats["misses"] += 1
-        plan = build()
-        cache[key] = plan
-        while len(cache) > cap:
-            cache.popitem(last=False)
-    try:
-        plan._ws_live = True
-    except AttributeError:
-        pass
-    return plan
+    with _CACHE_LOCK:
+        if cap == 0:
+            _CACHE_STATS["misses"] += 1
+            return build()
+        plan = _CACHE.get(key)
+        # only plans in use keep device workspaces (the per-edge BP kernel sizes its message planes for tens of GB): the others keep
+        # their graphs and decoders and size their workspaces again when they are used next
+        for k, other in _CACHE.items():
+            if k != key and hasattr(other, "release_workspaces") and getattr(other, "_ws_live", True):
+                lock = getattr(other, "_lock", None)
+                if lock is None:
+                    other.release_workspaces()
+                    other._ws_live = False
+                elif lock.acquire(blocking=False):           # (busy in another thread: leave it)
+                    try:
+                        other.release_workspaces()
+                        other._ws_live = False
+                    finally:
+                        lock.release()
+        if plan is not None:
+            _CACHE.move_to_end(key)
+            _CACHE_STATS["hits"] += 1
+        else:
+            _CACHE_STATS["misses"] += 1
+            plan = build()
+            _CACHE[key] = plan
+            while len(_CACHE) > cap:
+                _CACHE.popitem(last=False)
+        try:
+            plan._ws_live = True
+        except AttributeError:
+            pass
+        return plan
 
 
 def plan_cache_info():
-    c = _tls_cache()
-    return {"size": 0 if c is None else len(c), "capacity": _plan_cache_size(), **_tls_stats()}
+    with _CACHE_LOCK:
+        return {"size": len(_CACHE), "capacity": _plan_cache_size(), **_CACHE_STATS}
 
 
 def plan_cache_clear():
-    _TLS.cache = None
-    _TLS.stats = {"hits": 0, "misses": 0}
+    with _CACHE_LOCK:
+        _CACHE.clear()
+        _CACHE_STATS.update(hits=0, misses=0)
 
 
 def build_circuit_plan(circuit, hz, W, F, num_rounds, dict1, dict2, decoder1=None, decoder2=None):

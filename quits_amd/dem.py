@@ -24,6 +24,7 @@ from __future__ import annotations
 import hashlib
 import math
 import os
+import threading
 from collections import OrderedDict
 from typing import Dict, List, Tuple
 
@@ -109,6 +110,7 @@ _NOISE = ("X_ERROR", "Z_ERROR", "DEPOLARIZE1", "DEPOLARIZE2")
 # the same floating-point numbers as the full pass, bit for bit.  QD_DEM_STRUCT_CACHE = structures kept (default 4, 0 = off).
 _STRUCT_CACHE: "OrderedDict[str, dict]" = OrderedDict()
 _STRUCT_STATS = {"hits": 0, "misses": 0}
+_STRUCT_LOCK = threading.Lock()        # get / move_to_end / insert / evict / statistics under it; entries are never edited after insertion
 
 
 def _struct_cap() -> int:
@@ -119,13 +121,15 @@ def _struct_cap() -> int:
 
 
 def dem_struct_cache_info() -> dict:
-    return {"size": len(_STRUCT_CACHE), "capacity": _struct_cap(), **_STRUCT_STATS}
+    with _STRUCT_LOCK:
+        return {"size": len(_STRUCT_CACHE), "capacity": _struct_cap(), **_STRUCT_STATS}
 
 
 def dem_struct_cache_clear() -> None:
-    _STRUCT_CACHE.clear()
-    _STRUCT_STATS["hits"] = 0
-    _STRUCT_STATS["misses"] = 0
+    with _STRUCT_LOCK:
+        _STRUCT_CACHE.clear()
+        _STRUCT_STATS["hits"] = 0
+        _STRUCT_STATS["misses"] = 0
 
 
 def _structure_key(ops, num_meas, num_det, num_obs) -> str:
@@ -203,16 +207,21 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
     ops, num_meas, num_det, num_obs = flatten(text)
     cap = _struct_cap()
     skey = _structure_key(ops, num_meas, num_det, num_obs) if cap > 0 else None
-    if skey is not None and skey in _STRUCT_CACHE:
-        st = _STRUCT_CACHE[skey]
-        _STRUCT_CACHE.move_to_end(skey)
-        _STRUCT_STATS["hits"] += 1
+    st = None
+    if skey is not None:
+        with _STRUCT_LOCK:
+            st = _STRUCT_CACHE.get(skey)
+            if st is not None:
+                _STRUCT_CACHE.move_to_end(skey)
+                _STRUCT_STATS["hits"] += 1
+    if st is not None:
         prob = _replay_probabilities(st, ops)
         errors = [(float(prob[i]), d, o) for i, (d, o) in enumerate(st["rows"])]
         dem = DetectorErrorModel(errors, num_det, num_obs)
         dem.structure_key = skey
         return dem
-    _STRUCT_STATS["misses"] += 1
+    with _STRUCT_LOCK:
+        _STRUCT_STATS["misses"] += 1
     # A symptom is the frozenset of the detectors (d) and observables (num_det + o) an error flips; XOR is the symmetric difference.
     # (Sets of a handful of integers hash and combine in ~100 ns; the 10^4-bit integer masks of rounds 1-3 cost a microsecond per
     # dictionary access on the QLP circuit: 10.4 -> 4-6 s there, the same output on every fixture; small circuits are unchanged.)
@@ -315,10 +324,12 @@ def circuit_to_dem(text: str) -> DetectorErrorModel:
     dem = DetectorErrorModel(errors, num_det, num_obs)
     if skey is not None:
         steps = fold_steps([contrib[r[3]] for r in rows])
-        _STRUCT_CACHE[skey] = {"rows": [(r[0], r[1]) for r in rows], "nsym": len(rows), "steps": steps,
-                               "noise_ops": [i for i, op in enumerate(ops) if op.name in _NOISE and op.arg > 0.0]}
-        while len(_STRUCT_CACHE) > cap:
-            _STRUCT_CACHE.popitem(last=False)
+        entry = {"rows": [(r[0], r[1]) for r in rows], "nsym": len(rows), "steps": steps,
+                 "noise_ops": [i for i, op in enumerate(ops) if op.name in _NOISE and op.arg > 0.0]}
+        with _STRUCT_LOCK:
+            _STRUCT_CACHE[skey] = entry
+            while len(_STRUCT_CACHE) > cap:
+                _STRUCT_CACHE.popitem(last=False)
         dem.structure_key = skey
     return dem
 

@@ -177,9 +177,8 @@ def test_product_path_does_not_import_the_oracle():
                 assert "import oracle" not in txt and "liboracle" not in txt and "qd_oracle" not in txt.replace("oracle/qd_oracle.c", ""), f
 
 
-def test_osd_sr_kernel_instantiations_use_no_scratch(tmp_path):
-    """qd_osd0_sr_kernel keeps ~100 spilled scalar registers in lanes of vector registers; that is only safe while no vector
-    register is spilled (a spill-heavy build faulted on the GPU): every instantiation must report ScratchSize 0."""
+def _resource_usage(tmp_path, src):
+    """(kernel name, ScratchSize bytes per lane) for every kernel hipcc compiles from quits_amd/csrc/<src> with the Makefile's flags."""
     import re
     import subprocess
     cs = os.path.join(ROOT, "quits_amd", "csrc")
@@ -187,36 +186,42 @@ def test_osd_sr_kernel_instantiations_use_no_scratch(tmp_path):
     flags = re.search(r"^FLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split()
     flags = [f for f in flags if f != "-shared"]
     out = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", "-o",
-                          str(tmp_path / "osd_sr.o"), os.path.join(cs, "osd_sr.hip")], capture_output=True, text=True)
+                          str(tmp_path / (src + ".o")), os.path.join(cs, src)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     names = re.findall(r"Function Name: (\S+)", out.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-    kern = [(n, sc) for n, sc in zip(names, scratch) if "qd_osd0_sr_kernel" in n]
-    assert len(kern) >= 8 and all(sc == 0 for _, sc in kern), kern
+    assert len(names) == len(scratch)
+    return list(zip(names, scratch))
 
 
-def test_osdcs_kernel_instantiations_use_no_scratch(tmp_path):
-    """the rebuilt OSD-CS / OSD-E kernel (osd_cs.hip, qd_osdcs_kernel) -- the reference wrapper's default post-processor
-    (bposd.py:54 osd_method='osd_cs') -- reports ScratchSize 0 in all three instantiations (the kernel it replaces spilled 648-684 bytes
-    per lane)."""
-    import re
-    import subprocess
-    cs = os.path.join(ROOT, "quits_amd", "csrc")
-    mk = open(os.path.join(cs, "Makefile")).read()
-    flags = re.search(r"^FLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split()
-    flags = [f for f in flags if f != "-shared"]
-    out = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", "-o",
-                          str(tmp_path / "osd_cs.o"), os.path.join(cs, "osd_cs.hip")], capture_output=True, text=True)
-    assert out.returncode == 0, out.stderr[-2000:]
-    names = re.findall(r"Function Name: (\S+)", out.stderr)
-    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-    kern = [(n, sc) for n, sc in zip(names, scratch) if "qd_osdcs_kernel" in n]
-    assert len(kern) == 3 and all(sc == 0 for _, sc in kern), kern
+# every kernel a default plan can launch -- and every fall-back behind it -- stays out of scratch.  (file, kernel-name filter, how many
+# instantiations the filter must find, why.)  The full-rank row form qd_osd0_reg_kernel<., ., true> (OSD-CS / OSD-E on windows of more than
+# 1408 detectors, which no BASELINE config has) is the one kernel left that spills, and the test says so by excluding it by name.
+_NO_SCRATCH = [
+    ("osd_sr.hip", "qd_osd0_sr_kernel", 8, "keeps ~100 spilled scalar registers in lanes of vector registers: only safe while no vector register "
+                                           "is spilled (a spill-heavy build faulted on the GPU, DESIGN.md K2s)"),
+    ("osd_cs.hip", "qd_osdcs_kernel", 3, "OSD-CS / OSD-E, the reference wrapper's default post-processor (bposd.py:54); the kernel it replaced spilled 648-684 B"),
+    ("bp_scatter_wide.hip", "qd_bp_scatter_wide_kernel", 6, "flooding min-sum, the headline's BP kernel"),
+    ("bp_scatter.hip", "qd_bp_scatter_kernel", 3, "flooding min-sum, one check per lane"),
+    ("bp_kernels.hip", "qd_bp_minsum_kernel", 36, "the recheck / coarse-grid pass behind the scatter kernels (VERDICT r5 weak 9: 96 instantiations with 12-16 B each)"),
+    ("osd_kernels.hip", "Lb0E", 8, "qd_osd0_reg_kernel<., ., false>: the shots qd_osd0_sr_kernel hands over (VERDICT r5 weak 9: 88-144 B)"),
+    ("gf2_kernels.hip", "qd_", 6, "acc ^= L e, U e, the sampler, unpack, mismatch count"),
+    ("lsd_kernels.hip", "qd_lsd", 4, "BP-LSD"),
+]
 
 
-def test_plan_cache_is_per_thread_and_keyed_on_the_device(monkeypatch):
-    """a cached plan carries mutable state (staging buffers, side streams, decoder workspaces) and is bound to the
-    device it was built on -- so the key holds the current device and every thread has its own cache."""
+@pytest.mark.parametrize("src,pattern,count,why", _NO_SCRATCH, ids=[x[0] + ":" + x[1] for x in _NO_SCRATCH])
+def test_kernels_use_no_scratch(tmp_path, src, pattern, count, why):
+    kern = [(n, sc) for n, sc in _resource_usage(tmp_path, src) if pattern in n]
+    assert len(kern) == count, (len(kern), [n for n, _ in kern])
+    assert all(sc == 0 for _, sc in kern), [k for k in kern if k[1]]
+
+
+def test_plan_cache_is_process_wide_locked_and_keyed_on_the_device(monkeypatch):
+    """a cached plan is bound to the device it was built on -- the key holds the current device -- and carries
+    mutable state (staging buffers, side streams, decoder workspaces): ONE cache per process under a module lock, use serialised by
+    the plan's own re-entrant lock; a lookup releases the workspaces of every other cached plan that is idle, whatever thread used it
+    last, and leaves alone a plan another thread holds."""
     import threading
     from quits_amd.decoder import BpOsdDecoder
     from quits_amd.decoder import sliding_window as sw
@@ -227,21 +232,57 @@ def test_plan_cache_is_per_thread_and_keyed_on_the_device(monkeypatch):
     monkeypatch.setattr(sw, "_current_device", lambda: 5)
     k5 = sw.plan_key("circuit", "H 0\nM 0\n", hz, None, 3, 1, 6, BpOsdDecoder, BpOsdDecoder, d, d)
     assert k5 != k0 and ("device", 5) in k5
+
+    class FakePlan:
+        def __init__(self, name):
+            self.name, self._lock, self.released = name, threading.RLock(), 0
+
+        def release_workspaces(self):
+            self.released += 1
+
     sw.plan_cache_clear()
-    sw.cached_plan("x", lambda: "main-thread plan")
+    px = sw.cached_plan("x", lambda: FakePlan("x"))
     seen = {}
 
     def other():
-        seen["info_before"] = sw.plan_cache_info()
-        seen["plan"] = sw.cached_plan("x", lambda: "worker plan")
-        seen["info_after"] = sw.plan_cache_info()
+        seen["same"] = sw.cached_plan("x", lambda: FakePlan("worker's x"))            # shared, not rebuilt
+        seen["info"] = sw.plan_cache_info()
+        seen["y"] = sw.cached_plan("y", lambda: FakePlan("y"))                       # idle x loses its workspaces
 
     t = threading.Thread(target=other)
     t.start()
     t.join()
-    assert seen["info_before"]["size"] == 0 and seen["plan"] == "worker plan" and seen["info_after"]["misses"] == 1
-    assert sw.cached_plan("x", lambda: "rebuilt") == "main-thread plan"
+    assert seen["same"] is px and seen["info"]["hits"] == 1 and seen["info"]["misses"] == 1 and seen["info"]["size"] == 1
+    assert px.released == 1 and px._ws_live is False and seen["y"].released == 0
+    # a plan that is in use in another thread keeps its workspaces
+    assert sw.cached_plan("x", lambda: None) is px and seen["y"].released == 1
+    held, go = threading.Event(), threading.Event()
+
+    def holder():
+        with px._lock:
+            held.set()
+            go.wait(10)
+
+    t = threading.Thread(target=holder)
+    t.start()
+    held.wait(10)
+    sw.cached_plan("y", lambda: None)
+    assert px.released == 1                    # busy: left alone
+    go.set()
+    t.join()
+    sw.cached_plan("y", lambda: None)
+    assert px.released == 2
+    # concurrent misses on one key build once
+    built = []
+    def build():
+        built.append(1)
+        return FakePlan("z")
+    ts = [threading.Thread(target=lambda: sw.cached_plan("z", build)) for _ in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert len(built) == 1
     sw.plan_cache_clear()
+    assert sw.plan_cache_info() == {"size": 0, "capacity": 8, "hits": 0, "misses": 0}
 
 
 def test_env_switches_parse_loosely(monkeypatch):

@@ -306,3 +306,23 @@ def test_structure_cache_keys_on_the_derived_probability_and_hands_out_copies(mo
     base._MATRIX_CACHE.clear()
     base.detector_error_model_to_matrix(dem.Circuit(text))
     assert len(base._MATRIX_CACHE) == 0
+
+
+@pytest.mark.parametrize("name,max_row,min_row", [("hgp225_cardinal_r3_p0.01", 52, 21), ("bb72_custom_r6_p0.003", 35, 16),
+                                                   ("bb144_custom_r12_p0.003", 35, 16)])
+def test_row_weights_against_an_independent_forward_census(name, max_row, min_row):
+    """SURVEY.md Appendix B quotes a maximum row weight of 53 for the HGP [[225,9,6]] R=3 DEM, the build's matrix has
+    52 (same shape, non-zeros and sum of priors).  tests/dem_forward.py pushes every fault component of every noise instruction FORWARD
+    through the circuit text (bit-packed Pauli frames, all components at once; nothing shared with the backward extractor but the
+    parser) and counts the distinct detector sets: columns, non-zeros and the weight of EVERY row equal the build's -- 52 it is; the
+    survey's throw-away probe mis-reported the digit.  (The QLP [[1020,136]] DEM, 3.2 M components, takes four minutes: run once,
+    profiles/r06_dem_forward_census.txt -- rows 25..78 there, where Appendix B says 26..77.)"""
+    import dem_forward
+    from scipy.sparse import csr_matrix
+    H, _, _ = helpers.dem_matrices(name)
+    c = dem_forward.census(helpers.circuit_text(name))
+    rw = np.diff(csr_matrix(H).indptr)
+    assert c["columns"] == H.shape[1] and c["nnz"] == H.nnz
+    assert np.array_equal(c["row_weights"], rw)
+    assert np.array_equal(np.sort(c["col_weights"]), np.sort(np.diff(H.tocsc().indptr)))
+    assert rw.max() == max_row and rw.min() == min_row

@@ -544,7 +544,7 @@ def test_public_call_plan_cache_and_streamed_host_samples(gpu, monkeypatch):
     info = sw.plan_cache_info()
     assert info["misses"] == 1 and info["hits"] == 5 and info["size"] == 1
     # pieces of 1024 shots through the staging buffers (3000 = 1024 + 1024 + 952)
-    plan = next(iter(sw._tls_cache().values()))
+    plan = next(iter(sw._CACHE.values()))
     plan.chunk, plan.host_piece, plan._stage = 1024, 1024, None
     assert np.array_equal(plan.decode_host(det_h.astype(np.bool_)), ref)
     assert np.array_equal(plan.decode_host(det_h[:10]), ref[:10]) and plan.decode_host(det_h[:0]).shape == (0, ref.shape[1])
