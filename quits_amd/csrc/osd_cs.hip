@@ -15,8 +15,11 @@
 //     image of each pivot broadcast through SCALAR registers (one 16-lane LDS read + v_readlane per word instead of a 16-word LDS
 //     read per thread): the old kernel paid two workgroup barriers and 64 KB of LDS reads per pivot.
 //     Three barriers per BATCH (~130 batches per headline shot) instead of two per PIVOT (~1000) plus five per batch.
-//     Round 6: two barriers per batch, and the batches are pipelined -- wavefront 0 finds batch b's pivots while the others scatter and push
-//     batch b + 1 and apply batch b's pivots; batch b + 1's panel takes batch b's pivots afterwards, eight lanes per column (see the loop).
+//     Round 6: the pivot step of phase [B] uses the ballot as the execution mask of the XOR (499 -> 409 ticks per batch); the transformed syndrome is
+//     carried by wavefront 1, not by the searching wavefront; wavefront 0 keeps its priority to the batch's last barrier; the next batch's rows are
+//     requested two barriers ahead; publish / poll are release / acquire at workgroup scope.  Restructurings of the batch sequence (pipelined
+//     batches, a register-built panel pulled from an L2 mirror, a Q update carried into the next batch, other ownership maps of the Q columns) were
+//     measured and NOT kept: profiles/r06_osdcs_steps.txt.
 //   * The candidate sweep sums the signed pivot weights four rows at a time (a 16-entry table per nibble of rows, built once per
 //     shot) instead of one set bit at a time, and breaks ties on the sorted position instead of re-deriving the key.
 //   * One kernel body, every loop that touches the Q columns unrolled over compile-time bounds: ScratchSize 0 in every instantiation
@@ -33,14 +36,6 @@
 // sub-phase timers of a -DQD_OSD_TIMING build: -DQD_CS_SUB=1 (default) panel phase, 2 the sort, 3 the sweep (tools/osdcs_timing.py)
 #ifndef QD_CS_SUB
 #define QD_CS_SUB 1
-#endif
-// -DQD_CS_BFAST=0: round 5's form of the pivot step in phase [B] (A/B builds)
-#ifndef QD_CS_BFAST
-#define QD_CS_BFAST 1
-#endif
-// unroll factor of the slot loop inside phase [B]'s pivot search (1 = rolled; NSLOT = round 5's 28 copies of the step)
-#ifndef QD_CS_QUNROLL
-#define QD_CS_QUNROLL 8     // (>= the largest slot count: unrolled.  Rolled (1) measured 419 -> 513 ticks per batch in phase [B]: profiles/r06_osdcs_steps.txt)
 #endif
 #ifdef QD_OSD_TIMING
 #define QD_SUBT(mode, slot) if constexpr (QD_CS_SUB == mode) { const unsigned long long n2_ = wall_clock64(); acc_[slot] += n2_ - sub_; sub_ = n2_; }
@@ -192,8 +187,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
     uint64_t *sb = reinterpret_cast<uint64_t *>(smem);                                   // [n] sort buffer (the sort phase owns all of LDS)
     uint16_t *order = reinterpret_cast<uint16_t *>(smem + a.o_order);                    // [n] faults in sorted order
     uint64_t *Pbuf = reinterpret_cast<uint64_t *>(smem + L::o_p);                        // [2][64][PSTR] panel: images of the batch's columns, by row
-    uint64_t *needb = reinterpret_cast<uint64_t *>(smem + L::o_need);                    // [NPIV] pivot order -> columns of the next batch that contain its row
-    uint16_t *rbuf = reinterpret_cast<uint16_t *>(smem + L::o_need + NPIV * 8);          // [64 << dlog <= 1024] rows of the next batch's columns (the second half of the need area)
+    uint64_t *needb = reinterpret_cast<uint64_t *>(smem + L::o_need);                    // [2][NPIV] pivot order -> batch columns that contain its row
     uint64_t *Tp = reinterpret_cast<uint64_t *>(smem + L::o_tp);                         // [64][NWD] images of the batch's pivot columns (without the pivot bit)
     uint64_t *sv = reinterpret_cast<uint64_t *>(smem + L::o_sv);                         // [NWD] transformed syndrome
     uint64_t *unpm = reinterpret_cast<uint64_t *>(smem + L::o_unp);                      // [NWD] rows that are not pivot rows yet
@@ -345,48 +339,41 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             if (upd && r < a.upd_rows) sbit ^= upd[r] & 1u;
             if (sbit) atomicOr(reinterpret_cast<unsigned long long *>(&sv[r >> 6]), 1ull << (r & 63));
         }
-        // scatter of batch `base`: raw columns by row into the panel, and for every pivot the batch columns that contain its row; entry
-        // `first`, `first + stride`, ... of the batch's 64 << dlog (column, incidence) pairs
-        auto scatter = [&](int base, uint64_t *Pd, uint64_t *nd, int first, int stride) {
+        // scatter of batch `b0`: raw columns by row into the panel, and for every pivot the batch columns that contain its row
+        auto scatter = [&](int base, uint64_t *Pc, uint64_t *nd) {
             const int nb = min(64, n - base);
-            for (int x = first; x < (64 << dlog); x += stride) {
+            for (int x = tid; x < (64 << dlog); x += T) {
                 const int c = x >> dlog, q = x & (ellw - 1);
                 if (c < nb) {
                     const uint32_t col = order[base + c];
                     const uint32_t r = a.csc_ell[((size_t)col << dlog) + q];
                     if (r != 0xFFFFu) {
-                        atomicXor(reinterpret_cast<unsigned long long *>(&Pd[c * PSTR + (r >> 6)]), 1ull << (r & 63));
+                        atomicXor(reinterpret_cast<unsigned long long *>(&Pc[c * PSTR + (r >> 6)]), 1ull << (r & 63));
                         const int k = rowpiv[r];
                         if (k >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&nd[k]), 1ull << c);
                     }
                 }
             }
         };
-        scatter(0, Pbuf, needb, tid, T);
+        scatter(0, Pbuf, needb);
         __syncthreads();
 
         // Which Q columns a thread owns.  Wavefront 0 -- the one that finds the pivots -- owns the HIGHEST pivot orders, which only exist in the last
-        // batches of a shot; the other wavefronts share the rest.
+        // batches of a shot; the other wavefronts share the rest.  So while wavefront 0 works on a panel the others apply each pivot to their columns
+        // as soon as it is published (phase [B] below), and wavefront 0 itself has nothing to update until late in the shot.
         auto kown = [&](int c) -> int { return wave == 0 ? NPIV - 64 * CPT + c * 64 + lane : (tid - 64) + c * (T - 64); };
         const int kmin_wave = wave == 0 ? NPIV - 64 * CPT : (wave - 1) * 64;       // the lowest pivot order any lane of this wavefront owns
-        uint64_t *live64 = reinterpret_cast<uint64_t *>(misc + 10);               // live columns of the panel about to be worked on (set in [Y], taken in [B])
-        // Round 6: the batches are PIPELINED.  One trip of the loop below = batch bi, two barriers:
-        //   [Y] every wavefront: the panel of batch bi -- scattered and pushed during the previous trip, i.e. the images of its columns under the
-        //       pivots found BEFORE batch bi - 1 -- takes the pivots of batch bi - 1 (8 lanes per column, the pivot row's bit handed round by a
-        //       ballot), and the columns that are still non-zero on an unpivoted row are marked live; the other panel buffer and the need words
-        //       are cleared;
-        //   [X] wavefront 0 finds the pivots of batch bi on its panel ([B], as in round 5) WHILE the others scatter batch bi + 1 into the other
-        //       buffer, push their Q columns (as of the end of batch bi - 1) into it, and then apply batch bi's pivots to their Q columns as they
-        //       are published ([C]).
-        // Round 5 ran scatter -> push -> barrier -> [B] / [C] -> barrier in sequence: wavefront 0 -- the chain everything waits for -- spent 190 of
-        // every 840 ticks waiting for the pushes (LDS-atomic bound) and 150 behind [C] and the next scatter; now its chain is [Y] + [B].
-        int npiv = 0, gprev = 0;
-        for (int base = 0, bi = 0;; base += 64, ++bi) {
+        // Round 6: the transformed syndrome lives in a register of wavefront 1 during the elimination (lane w holds word w) and takes the pivots
+        // with the Q columns; wavefront 0 used to carry it through phase [B], one more vector to update per pivot on the chain everything waits for
+        uint64_t svx = (wave == 1 && lane < NWD) ? sv[lane] : 0ull;
+        int npiv = 0;
+        for (int base = 0, bi = 0; base < n; base += 64, ++bi) {
+            const int nb = min(64, n - base);
             uint64_t *Pc = Pbuf + (bi & 1) * 64 * PSTR, *Pn = Pbuf + ((bi & 1) ^ 1) * 64 * PSTR;
-            const bool more = base + 64 < n;
-            // The incidences of the NEXT batch's columns (two or three per thread of wavefronts 1..) are requested here, a barrier and a panel phase
-            // before they are scattered, and parked in LDS at the end of [Y]: the L2 round trip is off the other wavefronts' chain in [X] (it was
-            // ~100 ticks of it) and overlaps the work below.
+            uint64_t *ndc = needb + (bi & 1) * NPIV, *ndn = needb + ((bi & 1) ^ 1) * NPIV;
+            // The rows of the NEXT batch's columns (two or three (column, incidence) pairs per thread of wavefronts 1..) are requested here, two barriers
+            // before they are scattered, and stay in registers: round 5 scattered by loading them behind the Q update, an L2 round trip on the
+            // other wavefronts' way to the barrier.
             uint32_t rpre[SPT];
             int tid_y = tid;
             asm volatile("" : "+v"(tid_y));                           // (opaque per batch: the addresses below are invariant in the batch loop, and hoisted out of it they were kept in scratch)
@@ -394,73 +381,24 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             for (int j = 0; j < SPT; ++j) {
                 rpre[j] = 0xFFFFu;
                 const int x = (tid_y - 64) + j * (T - 64);
-                if (more && wave != 0 && x < (64 << dlog)) {
-                    const int c = x >> dlog, q = x & (ellw - 1);
-                    if (base + 64 + c < n) rpre[j] = (uint32_t)a.csc_ell[((size_t)order[base + 64 + c] << dlog) + q];
-                }
+                if (wave != 0 && x < (64 << dlog) && base + 64 + (x >> dlog) < n)
+                    rpre[j] = (uint32_t)a.csc_ell[((size_t)order[base + 64 + (x >> dlog)] << dlog) + (x & (ellw - 1))];
             }
-            // ---- [Y] the panel takes the previous batch's pivots, in order: x ^= image_g if x has bit p_g (the image is stored without that bit).
-            // Lane (c, sub) holds words sub * WPL2 .. of column c; the lane that holds word p_g >> 6 tests the bit, a ballot and three scalar
-            // instructions turn the eight columns' bits into the execution mask of the XOR.
-            {
-                constexpr int WPL2 = (NWD + 7) / 8;
-                const int sub = lane & 7;
-                for (int cb = wave * 8; cb < 64; cb += NW * 8) {
-                    const int c = cb + (lane >> 3);
-                    uint64_t x[WPL2];
+            // ---- [A] images: the owner of Q column k adds it to the batch columns that contain pivot row k; the other buffers are cleared
 #pragma unroll
-                    for (int u = 0; u < WPL2; ++u) x[u] = (sub * WPL2 + u < NWD) ? Pc[c * PSTR + sub * WPL2 + u] : 0ull;
-                    // (the records of all pivots in one LDS read, a lane each, handed out by v_readlane; the image rows one pivot ahead of their use:
-                    //  the chain of a pivot is the bit test -> ballot -> mask -> XOR, no LDS round trip inside it)
-                    const uint32_t pjv = lane < gprev ? pivp[lane] : 0u;
-                    uint64_t tqn[WPL2];
+            for (int i = 0; i < CPT; ++i) {
+                const int k = kown(i);
+                if (k < npiv)
+                    for (uint64_t bits = ndc[k]; bits; bits &= bits - 1ull) {
+                        const int c = (int)__builtin_ctzll(bits);
 #pragma unroll
-                    for (int u = 0; u < WPL2; ++u) tqn[u] = (gprev > 0 && sub * WPL2 + u < NWD) ? Tp[sub * WPL2 + u] : 0ull;
-                    for (int g = 0; g < gprev; ++g) {
-                        const uint32_t pj = (uint32_t)__builtin_amdgcn_readlane((int)pjv, g);
-                        const int p = (int)(pj & 0xFFFFu), w0 = p >> 6, pbit = p & 63;
-                        const int sub0 = w0 / WPL2, u0 = w0 - sub0 * WPL2;
-                        uint64_t tq[WPL2];
-#pragma unroll
-                        for (int u = 0; u < WPL2; ++u) {
-                            tq[u] = tqn[u];
-                            tqn[u] = (g + 1 < gprev && sub * WPL2 + u < NWD) ? Tp[(g + 1) * NWD + sub * WPL2 + u] : 0ull;
-                        }
-                        uint64_t xs = x[0];
-#pragma unroll
-                        for (int u = 1; u < WPL2; ++u) xs = (u0 == u) ? x[u] : xs;
-                        const unsigned long long bal = __ballot(sub == sub0 && ((xs >> pbit) & 1ull) != 0ull);
-                        const unsigned long long mb = (bal >> sub0) & 0x0101010101010101ull;      // bit 8 c' = column c' of this wavefront holds row p
-                        const unsigned long long M = (unsigned long long)((uint32_t)mb * 0xFFu) | ((unsigned long long)((uint32_t)(mb >> 32) * 0xFFu) << 32);
-                        if (__builtin_amdgcn_inverse_ballot_w64(M)) {
-#pragma unroll
-                            for (int u = 0; u < WPL2; ++u) x[u] ^= tq[u];
-                        }
+                        for (int w = 0; w < NWD; ++w)
+                            atomicXor(reinterpret_cast<unsigned long long *>(&Pc[c * PSTR + w]), (unsigned long long)mycol[i][w]);
                     }
-                    uint64_t acc = 0ull;
-#pragma unroll
-                    for (int u = 0; u < WPL2; ++u) {
-                        if (sub * WPL2 + u < NWD) {
-                            acc |= x[u] & unpm[sub * WPL2 + u];
-                            if (gprev > 0) Pc[c * PSTR + sub * WPL2 + u] = x[u];
-                        }
-                    }
-                    // a column is live when one of its eight lanes holds a one on an unpivoted row: fold the bytes of the ballot to their lowest bits
-                    unsigned long long bl = __ballot(acc != 0ull);
-                    bl |= bl >> 4; bl |= bl >> 2; bl |= bl >> 1;
-                    bl &= 0x0101010101010101ull;
-                    const unsigned long long lm = (bl * 0x0102040810204080ull) >> 56;             // bit c' = byte c' was non-zero
-                    if (lane == 0 && lm != 0ull) atomicOr(reinterpret_cast<unsigned long long *>(live64), lm << cb);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < SPT; ++j) {                            // (the rows requested at the head of this phase have arrived: parked in LDS until the scatter)
-                const int x = (tid_y - 64) + j * (T - 64);
-                if (more && wave != 0 && x < (64 << dlog)) rbuf[x] = (uint16_t)rpre[j];
             }
             for (int x = tid; x < 64 * PSTR; x += T) Pn[x] = 0ull;
-            for (int x = tid; x < NPIV; x += T) needb[x] = 0ull;
-            if (tid == 0) { misc[6] = 0u; misc[7] = 0u; misc[8] = 0u; }   // pivots published / panel finished / wavefronts that have scattered
+            for (int x = tid; x < NPIV; x += T) ndn[x] = 0ull;
+            if (tid == 0) { misc[6] = 0u; misc[7] = 0u; }              // pivots published / panel finished (phase [B])
 #ifdef QD_OSD_TIMING
             ++acc_[10];
 #endif
@@ -473,23 +411,21 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             // from the lane of its word --, the syndrome and the unpivoted-row mask stay in registers for the whole batch, and a chunk
             // loaded later first takes the batch's earlier pivots (only the columns that hold one of their rows at all).
             if (wave == 0) {
-#if QD_CS_BFAST
                 __builtin_amdgcn_s_setprio(3);                         // the one wavefront everybody waits for
                 const int w = lane & (LPS - 1), s = lane / LPS;
                 const bool wv = w < NWD;
                 uint64_t unp = wv ? unpm[w] : 0ull;
-                uint64_t svr = wv ? sv[w] : 0ull;
                 uint64_t bm = 0ull;                                    // rows that became pivot rows in this batch
                 QD_SUBT0(1)
-                // batch columns with a one on a row that is not a pivot row: marked by [Y] (the columns beyond the end of the order are zero)
-                uint64_t live;
+                // liveness, one lane per column: OR over the words of (column & unpivoted rows); the padded column stride keeps the 64
+                // lanes' reads of one word on different banks
+                uint64_t live;                                         // batch columns with a one on a row that is not a pivot row
                 {
-                    const uint64_t lv = *reinterpret_cast<volatile uint64_t *>(live64);        // (every lane the same word: made scalar, or the
-                    live = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lv >> 32)) << 32)    //  pivot counter below becomes a vector)
-                           | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lv);
+                    uint64_t acc = 0ull;
+#pragma unroll
+                    for (int ww = 0; ww < NWD; ++ww) acc |= Pc[lane * PSTR + ww] & unpm[ww];
+                    live = __ballot(acc != 0ull && lane < nb);
                 }
-                QD_WAVE_SYNC();
-                if (lane == 0) *reinterpret_cast<volatile uint64_t *>(live64) = 0ull;
                 QD_SUBT(1, 11)
                 // rank -> column table of the live columns (chunks are consecutive rank ranges; a pivot's record keeps the rank)
                 uint32_t *tab = misc + 192;                            // [64]
@@ -548,9 +484,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     QD_SUBT(1, 12)
 #pragma unroll
                     for (int r = 0; r < NR; ++r) {
-                        // (the slot loop stays unrolled: rolled up -- 28 copies of the pivot step are 33 KB of code that every batch streams through once,
-                        //  next to three other workgroups on the two CUs that share a 64 KB instruction cache -- it was SLOWER, 419 -> 513 ticks per batch)
-#pragma unroll QD_CS_QUNROLL
+                        // (the slot loop stays unrolled -- 28 copies of the pivot step: rolled up it was slower, 419 -> 513 ticks per batch, profiles/r06_osdcs_steps.txt)
                         for (int q = 0; q < NSLOT; ++q) {
                             if (c0 + r * NSLOT + q >= nlive || g >= room) break;
                             const uint64_t y = x[r] & unp;
@@ -587,7 +521,6 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                             }
                             if (lane == 0) pivp[g] = (uint32_t)p | ((uint32_t)(c0 + r * NSLOT + q) << 16);
                             unp &= ~pm; bm |= pm;
-                            apply_row(svr, tq, pm, w0);
 #pragma unroll
                             for (int r2 = r; r2 < NR; ++r2)
                                 if (c0 + r2 * NSLOT < nlive) apply_row(x[r2], tq, pm, w0);  // (columns already passed are dead: harmless)
@@ -596,7 +529,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                     }
                     QD_SUBT(1, 13)
                 }
-                if (s == 0 && wv) { unpm[w] = unp; sv[w] = svr; }
+                if (s == 0 && wv) unpm[w] = unp;                        // (the transformed syndrome is wavefront 1's: it takes the pivots with the Q columns)
                 if (lane == 0) misc[0] = (uint32_t)g;
                 QD_WAVE_SYNC();
                 if (lane < g) {                                        // the pivots' records, one lane each (pivp: same wavefront, LDS in order)
@@ -611,181 +544,27 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                 if (lane == 0) {                                       // the panel is finished: the last image(s), the count, the records -- then the flag
                     __hip_atomic_store(&misc[6], (uint32_t)g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     __hip_atomic_store(&misc[7], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                __builtin_amdgcn_s_setprio(0);
-#else
-                __builtin_amdgcn_s_setprio(3);                         // the one wavefront everybody waits for
-                const int w = lane & (LPS - 1), s = lane / LPS;
-                const bool wv = w < NWD;
-                uint64_t unp = wv ? unpm[w] : 0ull;
-                uint64_t svr = wv ? sv[w] : 0ull;
-                uint64_t bm = 0ull;                                    // rows that became pivot rows in this batch
-                QD_SUBT0(1)
-                // batch columns with a one on a row that is not a pivot row: marked by [Y] (the columns beyond the end of the order are zero)
-                uint64_t live;
-                {
-                    const uint64_t lv = *reinterpret_cast<volatile uint64_t *>(live64);        // (every lane the same word: made scalar, or the
-                    live = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lv >> 32)) << 32)    //  pivot counter below becomes a vector)
-                           | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lv);
-                }
-                QD_WAVE_SYNC();
-                if (lane == 0) *reinterpret_cast<volatile uint64_t *>(live64) = 0ull;
-                QD_SUBT(1, 11)
-                // rank -> column table of the live columns (chunks are consecutive rank ranges; a pivot's record keeps the rank)
-                uint32_t *tab = misc + 192;                            // [64]
-                const int nlive = (int)__popcll(live);
-                if ((live >> lane) & 1ull) tab[__builtin_amdgcn_mbcnt_hi((uint32_t)(live >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live, 0u))] = (uint32_t)lane;   // (rank = set bits below my lane)
-                QD_WAVE_SYNC();
-                // A chunk = NR registers x NSLOT slots: the column of rank c0 + r * NSLOT + q has word w in lane (q * LPS + w) of x[r].  A pivot's
-                // image goes through Tp (it has to be stored there anyway) back into every slot; whether a register's columns hold the
-                // pivot row is one ballot per register: the bit sits in lane (slot * LPS + w0).
-                constexpr int NR = NWD <= 8 ? 4 : (NWD <= 16 ? 7 : 8), CHC = NR * NSLOT;   // (7, not 8, at 16 words: the eighth row costs the 128-register instantiation its zero scratch)
-                int g = 0;
-                const int room = a.rank - npiv;
-                for (int c0 = 0; c0 < nlive && g < room; c0 += CHC) {
-                    uint64_t x[NR];
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        const int rank = c0 + r * NSLOT + s;
-                        const bool ok = wv && rank < nlive;
-                        const uint32_t c = ok ? tab[rank] : 0u;
-                        x[r] = ok ? Pc[c * PSTR + w] : 0ull;
-                    }
-                    // adds `tq` to the columns of `v` that hold row (64 w0 + pbit); sh = w0 + LPS * slot, isw = (w == w0)
-                    auto apply_row = [&](uint64_t &v, uint64_t tq, int pbit, int sh, bool isw) {
-                        const uint32_t half = (pbit & 32) ? (uint32_t)(v >> 32) : (uint32_t)v;
-                        const unsigned long long bal = __ballot(isw && ((half >> (pbit & 31)) & 1u) != 0u);
-                        if ((bal >> sh) & 1ull) v ^= tq;
-                    };
-                    if (g > 0) {
-                        QD_WAVE_SYNC();
-                        uint32_t flag = 0u;
-#pragma unroll
-                        for (int r = 0; r < NR; ++r)
-                            if (__ballot((x[r] & bm) != 0ull) != 0ull) flag |= 1u << r;
-                        if (flag != 0u)
-                            for (int i = 0; i < g; ++i) {
-                                const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pivp[i]);
-                                const int p = (int)(pj & 0xFFFFu), w0 = p >> 6, pbit = p & 63;
-                                const uint64_t tq = wv ? Tp[i * NWD + w] : 0ull;
-                                const int sh = w0 + LPS * s;
-                                const bool isw = w == w0;
-#pragma unroll
-                                for (int r = 0; r < NR; ++r)
-                                    if ((flag >> r) & 1u) apply_row(x[r], tq, pbit, sh, isw);
-                            }
-                    }
-                    QD_SUBT(1, 12)
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) {
-                        for (int q = 0; q < NSLOT; ++q) {
-                            if (c0 + r * NSLOT + q >= nlive || g >= room) break;
-                            const uint64_t y = x[r] & unp;
-                            const unsigned long long nz = (__ballot(y != 0ull) >> (q * LPS)) & LPSMASK;
-                            if (nz == 0ull) continue;                  // the pivots of this batch made it dependent
-                            const int w0 = (int)__builtin_ctzll(nz), src = q * LPS + w0;
-                            const uint32_t ylo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)y, src);
-                            const uint32_t yhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(y >> 32), src);
-                            const int pbit = ylo ? (int)__builtin_ctz(ylo) : 32 + (int)__builtin_ctz(yhi);
-                            const int p = w0 * 64 + pbit;
-                            const uint64_t pb = 1ull << pbit;
-                            const bool isw = w == w0;
-                            // the image without bit p: stored for phase [C], and copied from slot q into every slot -- by two lane-swap
-                            // instructions per half (rows of 16 lanes, halves of 32), no LDS round trip; 8-lane slots go through LDS
-                            uint64_t tq = x[r] ^ (isw ? pb : 0ull);
-                            if (s == q && wv) Tp[g * NWD + w] = tq;
-                            if constexpr (LPS == 8) { QD_WAVE_SYNC(); tq = wv ? Tp[g * NWD + w] : 0ull; }
-                            else {
-                                uint32_t lo = (uint32_t)tq, hi = (uint32_t)(tq >> 32);
-                                if constexpr (LPS == 16) {
-                                    const auto a1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-                                    const auto a2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-                                    lo = (q & 1) ? a1[1] : a1[0];
-                                    hi = (q & 1) ? a2[1] : a2[0];
-                                }
-                                const int qh = LPS == 16 ? (q >> 1) : q;
-                                const auto b1 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-                                const auto b2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-                                lo = qh ? b1[1] : b1[0];
-                                hi = qh ? b2[1] : b2[0];
-                                tq = ((uint64_t)hi << 32) | (uint64_t)lo;
-                            }
-                            if (lane == 0) pivp[g] = (uint32_t)p | ((uint32_t)(c0 + r * NSLOT + q) << 16);
-                            if (isw) { unp &= ~pb; bm |= pb; }
-                            const int sh = w0 + LPS * s;
-                            apply_row(svr, tq, pbit, sh, isw);
-#pragma unroll
-                            for (int r2 = r; r2 < NR; ++r2)
-                                if (c0 + r2 * NSLOT < nlive) apply_row(x[r2], tq, pbit, sh, isw);  // (columns already passed are dead: harmless)
-                            ++g;
-                            // published: the other wavefronts may apply pivot g - 1 now.  Release at workgroup scope: the image in Tp and
-                            // the record in pivp are complete in LDS before the count says so -- one s_waitcnt per publish
-                            if (lane == 0) __hip_atomic_store(&misc[6], (uint32_t)g, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        }
-                    }
-                    QD_SUBT(1, 13)
-                }
-                if (s == 0 && wv) { unpm[w] = unp; sv[w] = svr; }
-                if (lane == 0) misc[0] = (uint32_t)g;
-                QD_WAVE_SYNC();
-                if (lane < g) {                                        // the pivots' records, one lane each (pivp: same wavefront, LDS in order)
-                    const uint32_t pj = pivp[lane];
-                    const int p = (int)(pj & 0xFFFFu), K = npiv + lane;
-                    const uint32_t cb = tab[pj >> 16];                 // rank among the live columns -> column of the batch
-                    const uint32_t pc = order[base + (int)cb];
-                    rowpiv[p] = (int16_t)K; prow[K] = (uint16_t)p; pcol[K] = (uint16_t)pc;
-                    atomicOr(&pivmask[pc >> 5], 1u << (pc & 31u));
-                }
-                QD_SUBT(1, 14)
-                if (lane == 0) __hip_atomic_store(&misc[7], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);     // the panel is finished: count final, records written
-                __builtin_amdgcn_s_setprio(0);
+#ifdef QD_OSD_TIMING
+                    if constexpr (QD_CS_SUB == 5) { const unsigned long long tf_ = wall_clock64(); misc[20] = (uint32_t)tf_; misc[21] = (uint32_t)(tf_ >> 32); }
 #endif
-            } else if (more) {
-                // ---- beside [B]: the next batch's raw columns and need words.  (rowpiv may already name a pivot of THIS batch -- wavefront 0 writes the
-                // records at the end of [B] --: its need bit is set and never used, the push below stops at the pivots before this batch; [Y] applies these)
-                QD_SUBT0(4)
-#pragma unroll
-                for (int j = 0; j < SPT; ++j) {
-                    const int x = (tid_y - 64) + j * (T - 64);
-                    const uint32_t r = x < (64 << dlog) ? (uint32_t)rbuf[x] : 0xFFFFu;
-                    if (r != 0xFFFFu) {
-                        const int c = x >> dlog;
-                        atomicXor(reinterpret_cast<unsigned long long *>(&Pn[c * PSTR + (r >> 6)]), 1ull << (r & 63));
-                        const int k = rowpiv[r];
-                        if (k >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&needb[k]), 1ull << c);
-                    }
                 }
-                if (lane == 0) __hip_atomic_fetch_add(&misc[8], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                QD_SUBT(4, 11)
             }
             QD_TICK(2)
-            // ---- push: the owner of Q column k adds it to the columns of the NEXT batch that contain pivot row k (need[k]) -- every other wavefront
-            // has to have scattered first: the need bits come from all of them.  The Q columns are those of the end of the previous batch.
-            if (more && kmin_wave < npiv) {
-                while (__hip_atomic_load(&misc[8], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(NW - 1)) __builtin_amdgcn_s_sleep(1);
-                QD_SUBT(4, 12)
-#pragma unroll
-                for (int i = 0; i < CPT; ++i) {
-                    const int k = kown(i);
-                    if (k < npiv)
-                        for (uint64_t bits = needb[k]; bits; bits &= bits - 1ull) {
-                            const int c = (int)__builtin_ctzll(bits);
-#pragma unroll
-                            for (int w = 0; w < NWD; ++w)
-                                atomicXor(reinterpret_cast<unsigned long long *>(&Pn[c * PSTR + w]), (unsigned long long)mycol[i][w]);
-                        }
-                }
-            }
             // ---- [C] every Q column takes the batch's pivots, in order: a column that has bit p set gets the pivot's image added (bit p stays: the
             // image is stored without it); column K, all zero until now, becomes that image.  Wavefronts 1.. do this WHILE wavefront 0 is still
-            // at work on the panel: they poll the published count (an LDS read, then a short sleep) and apply what has arrived; wavefront 0
+            // at work on the panel: they poll the published count (two LDS reads, then a short sleep) and apply what has arrived; wavefront 0
             // applies the batch to its own columns afterwards, which exist in the last batches of a shot only.
             auto apply_pivot = [&](int i) {
                 const int K = npiv + i;
-                if (kmin_wave > K) return;                             // none of this wavefront's columns exists yet (uniform)
+                if (kmin_wave > K && wave != 1) return;               // none of this wavefront's columns exists yet (uniform)
                 const uint32_t pj = (uint32_t)__builtin_amdgcn_readfirstlane((int)pivp[i]);
                 const int p = (int)(pj & 0xFFFFu), pw = p >> 6;
                 const uint64_t pb = 1ull << (p & 63);
+                if (wave == 1) {
+                    // the syndrome takes the pivot like any column: the lane of the pivot row's word tests, every lane adds its word of the image
+                    if (__ballot(lane == pw && (svx & pb) != 0ull) != 0ull && lane < NWD) svx ^= Tp[i * NWD + lane];
+                    if (kmin_wave > K) return;
+                }
                 uint64_t sel[CPT];
 #pragma unroll
                 for (int c = 0; c < CPT; ++c) sel[c] = 0ull;
@@ -820,27 +599,46 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
                         }
                 }
             };
-            QD_SUBT(4, 13)
-            {
-                int g = 0;                                             // (one call site of apply_pivot: wavefront 0 arrives here with its panel finished)
-                for (;;) {
-                    // acquire at workgroup scope: what is read after these loads -- images, records -- is at least as new as the count.
-                    // `finished` is read before the count: finished => the count is final
-                    const uint32_t fin = __hip_atomic_load(&misc[7], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int avail = (int)__hip_atomic_load(&misc[6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    for (; g < avail; ++g) apply_pivot(g);
-                    if (fin) break;
-                    __builtin_amdgcn_s_sleep(2);
+            int g = 0;                                                 // (one call site of apply_pivot: wavefront 0 arrives here with its panel finished)
+            for (;;) {
+                // acquire at workgroup scope: what is read after these loads -- images, records -- is at least as new as the count.
+                // `finished` is read before the count: finished => the count is final
+                const uint32_t fin = __hip_atomic_load(&misc[7], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int avail = (int)__hip_atomic_load(&misc[6], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (; g < avail; ++g) apply_pivot(g);
+                if (fin) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            npiv += g;
+            const bool done = npiv >= a.rank || base + 64 >= n;
+            if (!done && wave != 0) {
+                // the next batch's raw columns and need words, from the rows requested before this batch's panel phase (rowpiv includes this batch's records)
+#pragma unroll
+                for (int j = 0; j < SPT; ++j) {
+                    const uint32_t r = rpre[j];
+                    if (r != 0xFFFFu) {
+                        const int c = ((tid_y - 64) + j * (T - 64)) >> dlog;
+                        atomicXor(reinterpret_cast<unsigned long long *>(&Pn[c * PSTR + (r >> 6)]), 1ull << (r & 63));
+                        const int k = rowpiv[r];
+                        if (k >= 0) atomicOr(reinterpret_cast<unsigned long long *>(&ndn[k]), 1ull << c);
+                    }
                 }
             }
-            QD_SUBT(4, 14)
+#ifdef QD_OSD_TIMING
+            if constexpr (QD_CS_SUB == 5) {                            // how long after the panel was finished does each wavefront reach the batch's last barrier?
+                const unsigned long long tf_ = ((unsigned long long)misc[21] << 32) | misc[20];
+                const int sl_ = wave == 1 ? 11 : (wave == 4 ? 12 : (wave == 2 ? 13 : (wave == 7 ? 14 : -1)));
+                if (sl_ >= 0) acc_[sl_] += wall_clock64() - tf_;
+            }
+#endif
+            if (wave == 0) __builtin_amdgcn_s_setprio(0);             // (held since the head of [B]: at priority 0 its few instructions between [B] and this barrier took ~100 ticks beside the others' Q update)
             QD_TICK(3)
             __syncthreads();
             QD_TICK(7)
-            gprev = (int)misc[0];
-            npiv += gprev;
-            if (npiv >= a.rank || !more) break;
+            if (done) break;
         }
+        if (wave == 1 && lane < NWD) sv[lane] = svx;                   // the syndrome back where the sweep reads it
+        __syncthreads();
         asm volatile("" : "+v"(tid));                                  // (what the loops below derive from the thread index is not shared with -- kept live since -- the head of the shot)
         // ================================================================== OSD-0 solution, then the candidate sweep
         // residual on a non-pivot row <=> syndrome outside the column space (the answer is still the oracle's: same pivot rule)
@@ -1091,9 +889,11 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
         if (tid == 0) {
             for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], acc_[i]);
             atomicAdd(&a.dbg[8], 1ull); atomicAdd(&a.dbg[9], (unsigned long long)npiv); atomicAdd(&a.dbg[10], acc_[10]);
-            if constexpr (QD_CS_SUB != 4) for (int i = 11; i < 15; ++i) atomicAdd(&a.dbg[i], acc_[i]);
+            if constexpr (QD_CS_SUB != 5) for (int i = 11; i < 15; ++i) atomicAdd(&a.dbg[i], acc_[i]);
         }
-        if constexpr (QD_CS_SUB == 4) { if (tid == 64) for (int i = 11; i < 15; ++i) atomicAdd(&a.dbg[i], acc_[i]); }   // wavefront 1's view of phase [X]
+        if constexpr (QD_CS_SUB == 5) {
+            if (lane == 0 && (wave == 1 || wave == 4 || wave == 2 || wave == 7)) { const int sl_ = wave == 1 ? 11 : (wave == 4 ? 12 : (wave == 2 ? 13 : 14)); atomicAdd(&a.dbg[sl_], acc_[sl_]); }
+        }
 #endif
         __syncthreads();   // LDS is recycled by the next shot
     }

@@ -22,19 +22,17 @@ assert d.info()["post_kernel"] == "qd_osdcs_kernel", d.info()
 d.decode(det); torch.cuda.synchronize(); d.debug_counters()
 d.set_profiling(True); d.decode(det); torch.cuda.synchronize()
 c = d.debug_counters(); pr = d.profile()
-# round 6 (pipelined batches): [Y] = the panel takes the previous batch's pivots + liveness + clears, [B] = wavefront 0's pivot search (the others
-# scatter and push the next batch and apply this batch's pivots meanwhile), then wavefront 0's own push / update, two barriers per batch
-names = ["sort (column order)", "[Y] previous pivots into the panel, liveness, clears", "[B] panel pivots (wavefront 0)", "wavefront 0's own push + Q update", "sweep + output",
-         "barrier after Y", "(unused)", "barrier after X"]
+names = ["sort (column order)", "[A] push images + clear", "[B] panel pivots (wavefront 0)", "[C] Q update + next scatter", "sweep + output",
+         "barrier after A", "barrier after B", "barrier after C"]
 shots = max(c[8], 1)
 tot = sum(c[:8]) or 1
 print("fixture %s  window %s  %d x %d" % (name, os.environ.get("WINDOW", "whole"), H.shape[0], H.shape[1]))
 print("osd kernel ms %.2f, shots in OSD %d, mean pivots %.1f, batches per shot %.1f, ticks per shot %.0f (100 MHz)" % (pr["osd_ms"], c[8], c[9] / shots, c[10] / shots, tot / shots))
 for i, nme in enumerate(names):
     print("%-34s %6.1f %%   %8.0f ticks/shot   %7.1f ticks/batch" % (nme, 100.0 * c[i] / tot, c[i] / shots, c[i] / max(c[10], 1)))
-SUB = {"1": ((11, "[B] live mask"), (12, "[B] chunk load + earlier pivots"), (13, "[B] chunk columns in order"), (14, "[B] write-back + records")),
+SUB = {"1": ((11, "[B] liveness sweep"), (12, "[B] chunk load + earlier pivots"), (13, "[B] chunk columns in order"), (14, "[B] write-back + records")),
        "2": ((11, "sort: samples + splitters"), (12, "sort: bucket numbers + counts"), (13, "sort: scan + scatter"), (14, "sort: bucket sorts")),
-       "4": ((11, "[X] wavefront 1: scatter of the next batch"), (12, "[X] wavefront 1: waits for the other scatters"), (13, "[X] wavefront 1: push"), (14, "[X] wavefront 1: Q update until the panel is finished")),
+       "5": ((11, "panel finished -> last barrier: wavefront 1"), (12, "... wavefront 4 (shares wavefront 0's SIMD)"), (13, "... wavefront 2"), (14, "... wavefront 7")),
        "3": ((11, "sweep: residual, Q dump, weight tables"), (12, "sweep: single columns"), (13, "sweep: patterns"), (14, "sweep: winner + output"))}
 for i, nme in SUB[os.environ.get("QD_CS_SUB", "1")]:
     print("%-34s %6.1f %%   %8.0f ticks/shot   %7.1f ticks/batch" % (nme, 100.0 * c[i] / tot, c[i] / shots, c[i] / max(c[10], 1)))

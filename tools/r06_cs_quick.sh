@@ -29,7 +29,9 @@ if [ -f build_ablate/lib_cstiming1.so ]; then
   QD_CS_SUB=1 QUITS_AMD_LIB=$PWD/build_ablate/lib_cstiming1.so FIXTURE=qlp1020_cardinal_r20_p0.003 WINDOW=3,1,5 SHOTS=2048 timeout 300 python tools/osdcs_timing.py 2>&1 | grep -v amdgpu.ids > $O/phase_qlp_sub1.txt
   cat $O/phase_headline_sub1.txt
 fi
-if [ -f build_ablate/lib_cstiming4.so ]; then
-  QD_CS_SUB=4 QUITS_AMD_LIB=$PWD/build_ablate/lib_cstiming4.so timeout 300 python tools/osdcs_timing.py 2>&1 | grep -v amdgpu.ids > $O/phase_headline_sub4.txt
-  tail -4 $O/phase_headline_sub4.txt
+for sub in 4 5; do
+if [ -f build_ablate/lib_cstiming$sub.so ]; then
+  QD_CS_SUB=$sub QUITS_AMD_LIB=$PWD/build_ablate/lib_cstiming$sub.so timeout 300 python tools/osdcs_timing.py 2>&1 | grep -v amdgpu.ids > $O/phase_headline_sub$sub.txt
+  tail -4 $O/phase_headline_sub$sub.txt
 fi
+done
