@@ -7,18 +7,24 @@
 #define QD_MAX_COL_DEG 16      // bit-side sign copy is a uint16 per fault
 #define QD_MAX_ROW_DEG 255     // edge position inside a check is a byte
 #define QD_LDS_BYTES (160 * 1024)
+#ifndef QD_SR_KWR
+#define QD_SR_KWR 4            // Q planes (64 pivots each) qd_osd0_sr_kernel keeps in registers (variant builds: -DQD_SR_KWR=8 -DQD_SR_WPS12=3)
+#endif
+#ifndef QD_SR_WPS12
+#define QD_SR_WPS12 4          // wavefronts per SIMD the register budget of its one- and two-rows-per-thread shapes is cut for
+#endif
 #ifndef QD_SR_KWR_OF
-#define QD_SR_KWR_OF(rpt) 4
+#define QD_SR_KWR_OF(rpt) QD_SR_KWR
 #endif
 #ifndef QD_SR_WPS_OF
-#define QD_SR_WPS_OF(rpt) ((rpt) <= 2 ? 4 : 2)   // wavefronts per SIMD its register budget is cut for: 128 / 256 registers -- no instantiation may
+#define QD_SR_WPS_OF(rpt) ((rpt) <= 2 ? QD_SR_WPS12 : 2)   // wavefronts per SIMD its register budget is cut for: 128 / 256 registers -- no instantiation may
                                                  // spill vector registers (scalar registers it cannot keep live in lanes of vector registers)
 #endif
 #ifndef QD_SR_TSMALL
 #define QD_SR_TSMALL 512       // its workgroup size for windows of <= 1024 detectors
 #endif
 //      QD_SR_KWR_OF(rpt)       // Q planes (64 pivots each) the many-pivots-per-round OSD-0 kernel keeps in registers at rpt rows per thread (osd_sr.hip)
-#define QD_SR_KWR_MAX 4
+#define QD_SR_KWR_MAX (QD_SR_KWR > 4 ? QD_SR_KWR : 4)
 
 // One window's Tanner graph as the BP kernel wants it.
 //   check slots: checks sorted by degree (descending); bit slots: faults sorted by degree (descending), so that a

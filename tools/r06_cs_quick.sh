@@ -5,15 +5,15 @@ TAG=${1:-r06cs}
 O=gpurun_out/$TAG
 mkdir -p $O
 make -C oracle -s 2>&1 | tail -2
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "higher_order_osd or other_postprocessors or config4_qlp_sliding_window_bit_exact or osdw_panel or osd_alone or productsum_serial_osdcs" > $O/tests.txt 2>&1
+timeout 400 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "higher_order_osd or other_postprocessors or config4_qlp_sliding_window_bit_exact or osdw_panel or osd_alone or productsum_serial_osdcs" > $O/tests.txt 2>&1
 tail -4 $O/tests.txt
-timeout 600 python tools/stress_parity.py ${2:-300} 606 > $O/stress.txt 2>&1
+timeout 400 python tools/stress_parity.py ${2:-300} 606 > $O/stress.txt 2>&1
 tail -3 $O/stress.txt
 B="--steps 3 --warmup 1 --no-cpu --no-api --no-other-configs"
-python bench.py --osd-method osd_cs --osd-order 1 --shots 131072 $B > $O/headline_osdcs1.json 2>> $O/err.txt
-python bench.py --code qlp1020 --window 3 1 --p-override 0.001 --osd-method osd_cs --osd-order 1 --shots 8192 --steps 2 --warmup 1 --no-cpu --no-api --no-other-configs > $O/qlp_w3f1_osdcs1.json 2>> $O/err.txt
-python bench.py --window 5 3 --bp-method product_sum --schedule serial --max-iter 10 --osd-method osd_cs --osd-order 1 --shots 163840 $B > $O/refsettings_w5f3.json 2>> $O/err.txt
-python bench.py --osd-method osd_e --osd-order 8 --shots 131072 $B > $O/headline_osde8.json 2>> $O/err.txt
+timeout 300 python bench.py --osd-method osd_cs --osd-order 1 --shots 131072 $B > $O/headline_osdcs1.json 2>> $O/err.txt
+timeout 300 python bench.py --code qlp1020 --window 3 1 --p-override 0.001 --osd-method osd_cs --osd-order 1 --shots 8192 --steps 2 --warmup 1 --no-cpu --no-api --no-other-configs > $O/qlp_w3f1_osdcs1.json 2>> $O/err.txt
+timeout 300 python bench.py --window 5 3 --bp-method product_sum --schedule serial --max-iter 10 --osd-method osd_cs --osd-order 1 --shots 163840 $B > $O/refsettings_w5f3.json 2>> $O/err.txt
+timeout 300 python bench.py --osd-method osd_e --osd-order 8 --shots 131072 $B > $O/headline_osde8.json 2>> $O/err.txt
 python - <<PY | tee $O/summary.txt
 import json, glob
 print("%-28s %12s %10s %10s %10s  %s" % ("workload", "shots/s", "LER", "BP ms", "post ms", "post kernel"))
