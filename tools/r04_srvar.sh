@@ -6,7 +6,7 @@ for rep in 1 2; do
 for v in "$@"; do
   for p in 0.003 0.006; do
     if [ $v = main ]; then unset QUITS_AMD_LIB; else export QUITS_AMD_LIB=$PWD/build_ablate/lib_sr_$v.so; fi
-    QD_NO_PIPELINE=1 timeout 300 python bench.py --p $p --steps 3 --warmup 1 --no-cpu --no-api 2>/dev/null | tail -1 | python -c "
+    QD_NO_PIPELINE=1 timeout 300 python bench.py --p $p --shots 262144 --steps 3 --warmup 1 --no-cpu --no-api --no-other-configs 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline']; print('$v p=$p', round(d['value']), 'bp', round(r['avg_launch_ms'],2), 'osd', round(r['osd_kernel_ms_per_launch'],2), d.get('logical_error_rate'))
 " | tee -a $O/bench.txt
