@@ -37,6 +37,10 @@
 #ifndef QD_CS_SUB
 #define QD_CS_SUB 1
 #endif
+// priority of wavefront 0 from the head of phase [B] to the batch's last barrier (1 and 2 measured no different: profiles/r06_osdcs_steps.txt)
+#ifndef QD_CS_B_PRIO
+#define QD_CS_B_PRIO 3
+#endif
 #ifdef QD_OSD_TIMING
 #define QD_SUBT(mode, slot) if constexpr (QD_CS_SUB == mode) { const unsigned long long n2_ = wall_clock64(); acc_[slot] += n2_ - sub_; sub_ = n2_; }
 #define QD_SUBT0(mode) if constexpr (QD_CS_SUB == mode) { sub_ = wall_clock64(); }
@@ -411,7 +415,7 @@ __global__ void __launch_bounds__(T, WPS) qd_osdcs_kernel(OsdCsArgs a)
             // from the lane of its word --, the syndrome and the unpivoted-row mask stay in registers for the whole batch, and a chunk
             // loaded later first takes the batch's earlier pivots (only the columns that hold one of their rows at all).
             if (wave == 0) {
-                __builtin_amdgcn_s_setprio(3);                         // the one wavefront everybody waits for
+                __builtin_amdgcn_s_setprio(QD_CS_B_PRIO);              // the one wavefront everybody waits for
                 const int w = lane & (LPS - 1), s = lane / LPS;
                 const bool wv = w < NWD;
                 uint64_t unp = wv ? unpm[w] : 0ull;
