@@ -146,7 +146,7 @@ class DeviceWindowPlan:
         self.pipeline = not _env_flag("QD_NO_PIPELINE") and (_env_flag("QD_PIPELINE_EDGE") or not any(d.info()["edge_kernel"] for d in decs))
         self._side = None
         self._stage = None
-        self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", 4 * self.chunk))   # shots per staged piece (>= 2 chunks: the pipelined driver)
+        self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", 2 * self.chunk))   # shots per staged piece (>= 2 chunks: the pipelined driver)
         self.device = _current_device()      # graphs, decoders and workspaces were created on this device
         import threading
         self._lock = threading.RLock()       # one decode_host at a time per plan (staging buffers, side streams and workspaces are per plan);
@@ -247,31 +247,58 @@ class DeviceWindowPlan:
         out = st["out"]
         cur = torch.cuda.current_stream()
         h2d_done, dec_done = [None, None], [None, None]
+        # calls of two or more chunks: the pieces go through the pipelined driver as ONE chain (round 6): the two lanes carry over from piece to piece, a piece's
+        # BP starts behind its own host-to-device copy, its predictions leave on the post stream; the caller's stream only waits at the very end
+        chained = self.pipeline and not _env_flag("QD_NO_HOST_CHAIN") and N >= 2 * self.chunk
+        chain = {} if chained else None
+        res = np.empty((N, self.nobs), dtype=np.int64)
+        span = [None, None]                                        # the rows of `out` that the piece in flight on a lane will fill
         try:
             for i, lo in enumerate(range(0, N, st["piece"])):
                 hi = min(N, lo + st["piece"])
                 b = i & 1
                 if h2d_done[b] is not None:
                     h2d_done[b].synchronize()                      # the staging buffer has left for the GPU
-                np.copyto(st["pin"][b][:hi - lo].numpy(), as_u8(a[lo:hi]))
                 if dec_done[b] is not None:
-                    st["copy"].wait_event(dec_done[b])             # the device buffer has been decoded
-                with torch.cuda.stream(st["copy"]):
-                    st["dev"][b][:hi - lo].copy_(st["pin"][b][:hi - lo], non_blocking=True)
-                    h2d_done[b] = torch.cuda.Event()
-                    h2d_done[b].record(st["copy"])
-                cur.wait_event(h2d_done[b])
-                pred = self.decode(st["dev"][b][:hi - lo])
-                out[lo:hi].copy_(pred, non_blocking=True)
-                dec_done[b] = torch.cuda.Event()
-                dec_done[b].record(cur)
+                    dec_done[b].synchronize()                      # the device buffer has been decoded, its predictions are in `out`:
+                    res[span[b][0]:span[b][1]] = out[span[b][0]:span[b][1]].numpy()     # widened here, beside the decoding of the next piece
+                span[b] = (lo, hi)
+                ready = []
+                with torch.cuda.stream(st["copy"]):                # chunk by chunk: the first chunk's BP starts behind ITS copy, not the piece's
+                    for c0 in range(0, hi - lo, self.chunk):
+                        c1 = min(hi - lo, c0 + self.chunk)
+                        np.copyto(st["pin"][b][c0:c1].numpy(), as_u8(a[lo + c0:lo + c1]))
+                        st["dev"][b][c0:c1].copy_(st["pin"][b][c0:c1], non_blocking=True)
+                        ready.append(torch.cuda.Event())
+                        ready[-1].record(st["copy"])
+                h2d_done[b] = ready[-1]
+                if chained:                                        # (a ragged last piece too, whatever its size: it runs beside the piece before it)
+                    chain["ready"] = ready
+                    pred = _decode_pipelined_impl(self, st["dev"][b][:hi - lo], None, chain)
+                    with torch.cuda.stream(chain["s_post"]):       # (in order behind the piece's post stages)
+                        out[lo:hi].copy_(pred, non_blocking=True)
+                        dec_done[b] = torch.cuda.Event()
+                        dec_done[b].record(chain["s_post"])
+                else:
+                    cur.wait_event(h2d_done[b])
+                    pred = self.decode(st["dev"][b][:hi - lo])
+                    out[lo:hi].copy_(pred, non_blocking=True)
+                    dec_done[b] = torch.cuda.Event()
+                    dec_done[b].record(cur)
         finally:
+            if chain:
+                for key in ("s_bp", "s_post"):
+                    if key in chain:
+                        chain[key].synchronize()
             cur.synchronize()
             st["copy"].synchronize()
-        return out[:N].numpy().astype(np.int64)
+        for b in (0, 1):
+            if span[b] is not None:
+                res[span[b][0]:span[b][1]] = out[span[b][0]:span[b][1]].numpy()
+        return res
 
 
-def _decode_pipelined_impl(plan, det, stats):
+def _decode_pipelined_impl(plan, det, stats, chain=None):
     """Calls of two or more chunks: the BP stages run on one side stream, the post-processing (OSD / LSD over the shots BP
     parked, acc ^= L e, the hand-off U e) on a second one, so that a chunk's post-processing runs beside the BP of the other
     chunk of its pair -- the post-processors are chains of dependent steps that leave most issue slots of a CU idle, BP fills
@@ -284,7 +311,12 @@ def _decode_pipelined_impl(plan, det, stats):
     BP(X, k) waits for post(X, k - 1) (its syndrome needs that hand-off; it also frees the lane's buffers and decoder), post(X, k)
     for BP(X, k); both streams are in order.  Both start after everything queued on the caller's stream so far (inputs, the
     zeroed accumulator); the caller's stream resumes after the last post stage, which by stream order is after all the others.
-    Every buffer is allocated on the caller's stream before the side streams start and none is released before that point."""
+    Every buffer is allocated on the caller's stream before the side streams start and none is released before that point.
+
+    `chain` (decode_host, round 6): a dict that carries the two lanes from one call to the next -- the lane buffers, the lanes' last post-stage
+    events, every buffer handed out -- so that the BP stream of piece i + 1 starts behind its INPUT (chain["ready"], one event per chunk of the
+    piece's host-to-device copy) and the lanes, not behind piece i's last post stage: the caller's stream is not made to wait at all, the caller synchronises the side
+    streams itself when it has queued everything (profiles/r06_host_chain_ab.txt)."""
     import torch
     from .device import BatchDecoder
     if plan._side is None:
@@ -310,14 +342,21 @@ def _decode_pipelined_impl(plan, det, stats):
     cur = torch.cuda.current_stream()
     pred = torch.zeros((N, plan.nobs), dtype=torch.uint8, device=dev)
     words = max(w["graph"].words for w in plan.windows)
-    err_l = [torch.empty((C * words,), dtype=torch.int32, device=dev) for _ in range(2)]
-    upd_l = [torch.empty((C, plan.nz), dtype=torch.uint8, device=dev) for _ in range(2)] if nwin > 1 else [None, None]
-    st_all = torch.empty((nwin if stats is not None else 1, (N if stats is not None else 2 * C)), dtype=torch.int32, device=dev)
+    if chain is not None and "err_l" in chain:
+        err_l, upd_l, st_all = chain["err_l"], chain["upd_l"], chain["st_all"]
+    else:
+        err_l = [torch.empty((C * words,), dtype=torch.int32, device=dev) for _ in range(2)]
+        upd_l = [torch.empty((C, plan.nz), dtype=torch.uint8, device=dev) for _ in range(2)] if nwin > 1 else [None, None]
+        st_all = torch.empty((nwin if stats is not None else 1, (N if stats is not None else 2 * C)), dtype=torch.int32, device=dev)
+        if chain is not None:
+            chain.update(err_l=err_l, upd_l=upd_l, st_all=st_all)
     start = torch.cuda.Event()
-    start.record(cur)
+    start.record(cur)                      # (the zeroed accumulator, the buffers)
     s_bp.wait_event(start)
     s_post.wait_event(start)
-    post_done = [None, None]
+    if chain is not None:
+        chain.setdefault("keep", []).append(pred)              # nothing handed out may go back to the allocator before the caller has synchronised
+    post_done = list(chain.get("post_done", [None, None])) if chain is not None else [None, None]
     try:
         for p0 in range(0, N, 2 * C):
             lanes = [(lane, c0) for lane, c0 in enumerate((p0, p0 + C)) if c0 < N]
@@ -331,6 +370,8 @@ def _decode_pipelined_impl(plan, det, stats):
                     upd = upd_l[lane][:B] if k > 0 else None
                     if post_done[lane] is not None:
                         s_bp.wait_event(post_done[lane])
+                    if chain is not None and k == 0:
+                        s_bp.wait_event(chain["ready"][c0 // C])   # (the post stream follows through bp_done)
                     d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=1, stream=s_bp)
                     bp_done = torch.cuda.Event()
                     bp_done.record(s_bp)
@@ -350,6 +391,11 @@ def _decode_pipelined_impl(plan, det, stats):
         s_bp.synchronize()
         s_post.synchronize()
         raise
+    if chain is not None:
+        chain["post_done"] = post_done
+        chain["s_post"] = s_post
+        chain["s_bp"] = s_bp
+        return pred                        # (not joined: the caller queues its copy on the post stream and synchronises the side streams at the end)
     for e in post_done:
         if e is not None:
             cur.wait_event(e)

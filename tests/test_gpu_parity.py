@@ -548,6 +548,18 @@ def test_public_call_plan_cache_and_streamed_host_samples(gpu, monkeypatch):
     plan.chunk, plan.host_piece, plan._stage = 1024, 1024, None
     assert np.array_equal(plan.decode_host(det_h.astype(np.bool_)), ref)
     assert np.array_equal(plan.decode_host(det_h[:10]), ref[:10]) and plan.decode_host(det_h[:0]).shape == (0, ref.shape[1])
+    # pieces of two or more chunks: ONE chain of the two-lane pipeline across the pieces (3000 = 4 x 256 | 4 x 256 | 3 x 256 + 184;
+    # 2900 and 2400 leave a last piece of less than two chunks / less than one, chained like the others), and the same with the chain switched off
+    assert plan.pipeline
+    plan.chunk, plan.host_piece, plan._stage = 256, 1024, None
+    assert np.array_equal(plan.decode_host(det_h), ref)
+    plan.chunk, plan.host_piece, plan._stage = 500, 1000, None
+    assert np.array_equal(plan.decode_host(det_h[:2900]), ref[:2900])
+    assert np.array_equal(plan.decode_host(det_h[:2400]), ref[:2400])
+    monkeypatch.setenv("QD_NO_HOST_CHAIN", "1")
+    assert np.array_equal(plan.decode_host(det_h[:2900]), ref[:2900])
+    monkeypatch.delenv("QD_NO_HOST_CHAIN")
+    assert np.array_equal(plan.decode(det).cpu().numpy().astype(np.int64), ref)          # (the plan's device-resident call after a chain)
     # another option / another window shape / another circuit: misses
     sliding_window_bposd_circuit_mem(det_h, circ, hz, lz, 3, 1, **dict(kw, max_iter=21))
     sliding_window_bposd_circuit_mem(det_h, circ, hz, lz, 5, 3, **kw)
