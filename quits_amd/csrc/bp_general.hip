@@ -76,15 +76,19 @@ __global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8
                                                             const int32_t *__restrict__ cp, const int32_t *__restrict__ ri,
                                                             const int32_t *__restrict__ c2r, const float *__restrict__ llr0,
                                                             const uint32_t *__restrict__ srec,
-                                                            DecodeArgs a, GenWs w, int64_t shot0, int nshots)
+                                                            DecodeArgs a, GenWs w, int64_t shot0, int nshots, GenStage st)
 {
     __shared__ uint32_t red[G][64];
+    if (st.in_count) nshots = *st.in_count;                          // a later launch of the staged serial schedule: the survivors of the one before
+    if ((int)blockIdx.x * 64 >= nshots) return;
     extern __shared__ float pls[];                                   // [nslots][64]  (LP)
     const int lane = threadIdx.x & 63;
     const int wv = G > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;    // which rows / columns this wavefront takes
     const int ls = blockIdx.x * 64 + lane;                           // shot inside this chunk = column of the workspace
     bool active = ls < nshots;
-    const int64_t shot = shot0 + (active ? ls : 0);
+    // (the shot index is worked out where it is used, at the two ends: held across the sweeps it costs the registers that decide whether five
+    //  workgroups fit a CU or four -- 93 -> 97 registers measured 55 -> 76 ms per launch)
+#define QD_GEN_SHOT (st.in_shot ? (int64_t)st.in_shot[lsc] : shot0 + lsc)
     // workspace: [index][S shots] -- wavefronts advance through the graph at nearly the same pace, so at any moment they
     // touch the same few index planes: the pages in use are shared by all of them.  (A per-wavefront tiling
     // [tile][index][64] keeps each wavefront's data contiguous but multiplies the pages in flight by the number of
@@ -100,6 +104,9 @@ __global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8
     const float BIG = 3.402823466e+38f;
 
     // ---- window syndrome (sliding_window.py:168-169)
+    if (active && wv == 0) w.slot[ls] = -1;
+    if (st.it0 == 0) {               // (a later launch finds syndrome and messages in its planes)
+    const int64_t shot = shot0 + lsc;
     const uint8_t *det = a.det + shot * a.det_stride + a.det_offset;
     const uint8_t *upd = a.upd ? a.upd + shot * a.upd_stride : nullptr;
     uint32_t any = 0;
@@ -111,16 +118,14 @@ __global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8
             any |= s;
         }
     any = qd_lanes_or<G>(any, red, wv, lane);
-    uint32_t *out = a.err_bits + shot * g.out_words;
-    if (active && wv == 0) w.slot[ls] = -1;
     if (active && !any) {   // bposd_decoder.pyx: an all-zero syndrome returns the zero vector without running BP
         if (wv == 0) {
+            uint32_t *out = a.err_bits + shot * g.out_words;
             for (int x = 0; x < g.out_words; ++x) out[x] = 0u;
             a.status[shot] = (1 << 16) | (1 << 19);
         }
         active = false;
     }
-    const bool ran = active;
 
     // ---- every bit->check message starts as the prior LLR
     if (active)
@@ -133,9 +138,11 @@ __global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8
             }
         }
     if (G > 1) __syncthreads();
+    }
+    const bool ran = active;
 
     int iters = 0, converged = 0;
-    for (int it = 1; it <= a.max_iter; ++it) {
+    for (int it = st.it0 + 1; it <= st.it_end; ++it) {
         if (G > 1) { if (!__syncthreads_or(active ? 1 : 0)) break; }
         else if (!active) break;
         const float alpha = (a.ms_scale == 0.f) ? (1.0f - ldexpf(1.0f, -it)) : a.ms_scale;
@@ -396,8 +403,48 @@ __global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8
         }
     }
 
+    // ---- not the last launch: the shots still running move on, packed (GenStage)
+    if (SCHED == QD_SCHEDULE_SERIAL && !st.last) {
+        const unsigned long long sb = __ballot(active);              // (the same in every wavefront of the workgroup: they share the 64 shots)
+        uint32_t base = 0u;
+        if (G > 1) {
+            if (threadIdx.x == 0) red[0][0] = sb ? (uint32_t)atomicAdd(st.out_count, (int)__popcll(sb)) : 0u;
+            __syncthreads();
+            base = red[0][0];
+        } else {
+            if (lane == 0 && sb) base = (uint32_t)atomicAdd(st.out_count, (int)__popcll(sb));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        }
+        if (sb) {
+            const size_t dcol = (size_t)base + (size_t)__popcll(sb & ((1ull << lane) - 1ull));
+            const size_t S2 = (size_t)st.next.S;
+            const float *__restrict__ src = (METHOD == QD_BP_PRODUCT_SUM ? w.th : w.b2c) + lsc;
+            float *__restrict__ dst = (METHOD == QD_BP_PRODUCT_SUM ? st.next.th : st.next.b2c) + dcol;
+            int e = wv;
+            for (; e + 7 * G < g.nnz; e += 8 * G) {                  // whole lines in, the survivors' part of them out: eight loads in flight
+                float v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(e + k * G) * S];
+                if (active) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dst[(size_t)(e + k * G) * S2] = v[k];
+                }
+            }
+            for (; e < g.nnz; e += G) {
+                const float v = src[(size_t)e * S];
+                if (active) dst[(size_t)e * S2] = v;
+            }
+            for (int i = wv; i < g.m; i += G) {
+                const uint8_t v = syn[(size_t)i * S];
+                if (active) st.next.syn[(size_t)i * S2 + dcol] = v;
+            }
+            if (active && wv == 0) st.out_shot[dcol] = (int32_t)QD_GEN_SHOT;
+        }
+    }
     // ---- hard decision, packed by fault index
-    if (!ran) return;
+    if (!ran || (!st.last && active)) return;
+    const int64_t shot = QD_GEN_SHOT;
+    uint32_t *out = a.err_bits + shot * g.out_words;
     for (int x = wv; x < g.out_words; x += G) {
         uint32_t word = 0u;
         const int j1 = min(g.n, 32 * x + 32);
@@ -641,12 +688,14 @@ hipError_t qd_launch_bp_ps_lds(const GenGraphDev &g, const BpGraphDev &bg, const
 // Posteriors of the shots BP could not finish, from [fault][shot] to the OSD workspace's [fail slot][bit slot] rows.
 // 64 x 64 tiles through LDS so that both sides move whole lines.
 __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__restrict__ llr, const int32_t *__restrict__ slot,
-                                                             int64_t S, int nshots, int n, int n_pad,
+                                                             int64_t S, int nshots, const int32_t *__restrict__ count, int n, int n_pad,
                                                              const uint32_t *__restrict__ bit_orig, float *__restrict__ llr_ws)
 {
     __shared__ float tile[64][65];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int sb0 = blockIdx.x * 64, sh0 = blockIdx.y * 64;
+    if (count) nshots = *count;                                       // (staged serial schedule: the columns of the last launch)
+    if (sh0 >= nshots) return;
     for (int r = ty; r < 64; r += 4) {
         const int sb = sb0 + r;                                       // bit slot (uniform across the wavefront)
         float v = 0.f;
@@ -665,44 +714,77 @@ __global__ void __launch_bounds__(256) qd_publish_llr_kernel(const float *__rest
 #define QD_GEN_G 8            // wavefronts per 64 shots in the flooding schedule
 
 template <int METHOD, int SCHED, int G, int D>
-static hipError_t launch_kd(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
+static hipError_t launch_kd(const GenGraphDev &g, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, const GenStage &st, hipStream_t s)
 {
     const dim3 grid((unsigned)((nshots + 63) / 64)), block(64 * G);
     if (SCHED == QD_SCHEDULE_SERIAL && g.nslots > 0)
         hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D, SCHED == QD_SCHEDULE_SERIAL>), grid, block, (size_t)g.nslots * 256, s, g, g.rp, g.ci,
-                           g.cp, g.ri, g.c2r, g.llr0, g.srec, a, w, shot0, nshots);
+                           g.cp, g.ri, g.c2r, g.llr0, g.srec, a, w, shot0, nshots, st);
     else
         hipLaunchKernelGGL((qd_bp_edge_kernel<METHOD, SCHED, G, D, false>), grid, block, 0, s, g, g.rp, g.ci,
-                           g.cp, g.ri, g.c2r, g.llr0, g.srec, a, w, shot0, nshots);
+                           g.cp, g.ri, g.c2r, g.llr0, g.srec, a, w, shot0, nshots, st);
     return hipGetLastError();
 }
 
 template <int METHOD, int SCHED, int G>
-static hipError_t launch_k(const GenGraphDev &g, int max_cdeg, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, hipStream_t s)
+static hipError_t launch_k(const GenGraphDev &g, int max_cdeg, const DecodeArgs &a, const GenWs &w, int64_t shot0, int nshots, const GenStage &st, hipStream_t s)
 {
     switch (qd_gen_unroll(max_cdeg)) {
-    case 4: return launch_kd<METHOD, SCHED, G, 4>(g, a, w, shot0, nshots, s);
+    case 4: return launch_kd<METHOD, SCHED, G, 4>(g, a, w, shot0, nshots, st, s);
 #if QD_GEN_D6
-    case 6: return launch_kd<METHOD, SCHED, G, 6>(g, a, w, shot0, nshots, s);
+    case 6: return launch_kd<METHOD, SCHED, G, 6>(g, a, w, shot0, nshots, st, s);
 #endif
-    case 8: return launch_kd<METHOD, SCHED, G, 8>(g, a, w, shot0, nshots, s);
-    default: return launch_kd<METHOD, SCHED, G, QD_MAX_COL_DEG>(g, a, w, shot0, nshots, s);
+    case 8: return launch_kd<METHOD, SCHED, G, 8>(g, a, w, shot0, nshots, st, s);
+    default: return launch_kd<METHOD, SCHED, G, QD_MAX_COL_DEG>(g, a, w, shot0, nshots, st, s);
     }
 }
 
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
-                                int schedule, int64_t shot0, int nshots, hipStream_t s)
+                                int schedule, int64_t shot0, int nshots, hipStream_t s, GenStagePlan *plan)
 {
-    hipError_t e;
-    const int cd = bg.max_cdeg;
-    if (bp_method == QD_BP_PRODUCT_SUM)
-        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, cd, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, cd, a, w, shot0, nshots, s);
-    else
-        e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, cd, a, w, shot0, nshots, s)
-                                             : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, cd, a, w, shot0, nshots, s);
-    if (e != hipSuccess || !a.want_llr) return e;
+    // the staged serial schedule (GenStage): launches over iterations (0, b0], (b0, b1], ... (b_last, max_iter], workspaces w / plan->w2 in turn
+    int nb = (plan && schedule == QD_SCHEDULE_SERIAL) ? plan->nbounds : 0;
+    if (nb > 0) {
+        if (plan->pending && hipEventQuery(plan->counts_ready) == hipSuccess) {      // what an earlier staged call packed (never waited for)
+            plan->pending = 0;
+            const int left = plan->host_counts[plan->pending_nb - 1];                  // shots that went into its last launch
+            if (plan->pending_shots >= 4096 && (double)left > 0.85 * (double)plan->pending_shots) plan->one_launch_calls = QD_GEN_PROBE;
+        }
+        if (plan->one_launch_calls > 0) { --plan->one_launch_calls; nb = 0; }
+    }
+    if (nb > 0) {
+        hipError_t e0 = hipMemsetAsync(plan->counts, 0, sizeof(int32_t) * (size_t)(nb + 1), s);
+        if (e0 != hipSuccess) return e0;
+    }
+    const GenWs *wsv[2] = {&w, plan ? &plan->w2 : &w};
+    for (int k = 0; k <= nb; ++k) {
+        GenStage st{};
+        st.it0 = k ? plan->bounds[k - 1] : 0;
+        st.it_end = k < nb ? plan->bounds[k] : a.max_iter;
+        st.last = k == nb;
+        if (k) { st.in_shot = plan->lists[(k - 1) & 1]; st.in_count = plan->counts + (k - 1); }
+        if (k < nb) { st.out_shot = plan->lists[k & 1]; st.out_count = plan->counts + k; st.next = *wsv[(k + 1) & 1]; }
+        const GenWs &wk = *wsv[k & 1];
+        hipError_t e;
+        const int cd = bg.max_cdeg;
+        if (bp_method == QD_BP_PRODUCT_SUM)
+            e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, cd, a, wk, shot0, nshots, st, s)
+                                                 : launch_k<QD_BP_PRODUCT_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, cd, a, wk, shot0, nshots, st, s);
+        else
+            e = schedule == QD_SCHEDULE_PARALLEL ? launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_PARALLEL, QD_GEN_G>(g, cd, a, wk, shot0, nshots, st, s)
+                                                 : launch_k<QD_BP_MINIMUM_SUM, QD_SCHEDULE_SERIAL, QD_GEN_GS>(g, cd, a, wk, shot0, nshots, st, s);
+        if (e != hipSuccess) return e;
+    }
+    if (nb > 0 && !plan->pending) {
+        hipError_t e1 = hipMemcpyAsync(plan->host_counts, plan->counts, sizeof(int32_t) * (size_t)(nb + 1), hipMemcpyDeviceToHost, s);
+        if (e1 == hipSuccess) e1 = hipEventRecord(plan->counts_ready, s);
+        if (e1 != hipSuccess) return e1;
+        plan->pending = 1; plan->pending_shots = nshots; plan->pending_nb = nb;
+    }
+    if (!a.want_llr) return hipSuccess;
+    // BP failures exist in the last launch only (a shot fails by reaching max_iter): their posteriors are in ITS workspace, by ITS columns
+    const GenWs &wl = *wsv[nb & 1];
     hipLaunchKernelGGL(qd_publish_llr_kernel, dim3((unsigned)((g.n + 63) / 64), (unsigned)((nshots + 63) / 64)), dim3(256), 0, s,
-                       w.llr, w.slot, w.S, nshots, g.n, bg.n_pad, bg.bit_orig, a.llr_ws);
+                       wl.llr, wl.slot, wl.S, nshots, nb ? plan->counts + (nb - 1) : nullptr, g.n, bg.n_pad, bg.bit_orig, a.llr_ws);
     return hipGetLastError();
 }

@@ -17,7 +17,7 @@ hipError_t qd_launch_bp(const BpGraphDev &g, const DecodeArgs &a, int64_t B, hip
 hipError_t qd_launch_bp_scatter(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
-                                int schedule, int64_t shot0, int nshots, hipStream_t s);
+                                int schedule, int64_t shot0, int nshots, hipStream_t s, GenStagePlan *plan);
 int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg);
 hipError_t qd_launch_bp_ps_lds(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
@@ -123,6 +123,7 @@ struct qd_decoder {
     uint64_t *lsd_ws = nullptr; // [lsd_blocks][mw][m_pad] Q planes, then the work counter
     int64_t gen_ws_limit = 0;   // bytes; 0 = default
     GenWs gws{};
+    GenStagePlan gsp{};         // serial schedule: the launches' iteration bounds, the second workspace, the survivor lists (nbounds = 0: one launch)
     // ---- LLR grid (flooding min-sum, ms_scaling 1): decoder-owned prior arrays on the fine and the coarse grid
     int grid_k = -1, grid_kc = -1, grid_floor = 0;   // grid_floor: the fine grid is the 2^-10 floor, not the rule's: any number of shots may need the redo pass
     BpGraphDev bp_fine{}, bp_coarse{};         // copies of g->bp with their own bit_rec
@@ -1101,6 +1102,14 @@ static void free_ws(qd_decoder *d)
     if (d->gws.syn) (void)hipFree(d->gws.syn);
     if (d->gws.slot) (void)hipFree(d->gws.slot);
     d->gws = GenWs{};
+    if (d->gsp.msg2) (void)hipFree(d->gsp.msg2);
+    if (d->gsp.syn2) (void)hipFree(d->gsp.syn2);
+    if (d->gsp.host_counts) (void)hipHostFree(d->gsp.host_counts);
+    if (d->gsp.counts_ready) (void)hipEventDestroy(d->gsp.counts_ready);
+    if (d->gsp.lists[0]) (void)hipFree(d->gsp.lists[0]);
+    if (d->gsp.lists[1]) (void)hipFree(d->gsp.lists[1]);
+    if (d->gsp.counts) (void)hipFree(d->gsp.counts);
+    d->gsp = GenStagePlan{};
     if (d->hard_list) (void)hipFree(d->hard_list);
     if (d->hard_list2) (void)hipFree(d->hard_list2);
     if (d->redo_list) (void)hipFree(d->redo_list);
@@ -1209,12 +1218,39 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         // edge planes: flooding b2c + c2b (+ th for product-sum); serial: messages (th or b2c) + suffixes (the c2b plane), and a row plane
         const int planes = serial ? 2 : (ps ? 3 : 2);
         const bool pre_plane = serial && g->gen.nslots == 0;       // the rows' running prefixes: LDS slots when the graph allows
-        const size_t per_shot = ((size_t)g->nnz * planes + g->n + (pre_plane ? g->m : 0)) * sizeof(float) + g->m + sizeof(int32_t);
+        // Serial schedule in several launches with the survivors packed in between (GenStage): bounds after iterations 3, 6, 10, 14, 20, ...
+        // (x ~1.4) while at least two iterations remain; QD_GEN_STAGES="3,6" sets them, QD_GEN_STAGES=0 = one launch.  Costs a second workspace.
+        GenStagePlan &sp = d->gsp;
+        sp = GenStagePlan{};
+        if (serial) {
+            static const int dflt[] = {3, 6, 10, 14, 20, 28, 40, 56, 80, 112};     // (max_iter 10: "3,6" 50.5 ms, "3,5,7" 51.4, "4" 51.4, one launch 56.0: profiles/r06_k1g_staged_ab.txt)
+            std::vector<int> bnd(dflt, dflt + sizeof(dflt) / sizeof(dflt[0]));
+            if (const char *ev = std::getenv("QD_GEN_STAGES")) {
+                bnd.clear();
+                for (const char *q = ev; *q;) {
+                    char *end = nullptr;
+                    const long v = std::strtol(q, &end, 10);
+                    if (end == q) break;
+                    if (v > 0) bnd.push_back((int)v);
+                    q = *end ? end + 1 : end;
+                }
+            }
+            int prev = 0;
+            for (int b : bnd)
+                if (b > prev && b + 2 <= d->prm.max_iter && sp.nbounds < QD_GEN_MAX_STAGES - 1) { sp.bounds[sp.nbounds++] = b; prev = b; }
+        }
+        // (the launches alternate between two message planes and two syndrome planes; suffixes, prefixes, posteriors and fail slots are scratch of
+        //  ONE launch and shared.  If the second message plane would push the batch into more workspace chunks, the schedule stays in one launch:
+        //  a chunk more costs a whole dependency chain, more than packing returns -- W = 3 windows, ten decoders in a 96 GB budget: 98 -> 128 ms)
+        const size_t per_shot1 = ((size_t)g->nnz * planes + g->n + (pre_plane ? g->m : 0)) * sizeof(float) + g->m + sizeof(int32_t);
+        size_t per_shot = per_shot1 + (sp.nbounds > 0 ? (size_t)g->nnz * sizeof(float) + g->m + 2 * sizeof(int32_t) : 0);
         // Default budget 48 GB of the 288: the kernel is latency-bound (one wavefront per 64 shots), so a launch costs about
         // the same for 8 K or 64 K shots and chunks should be as large as memory allows -- and of equal size.
         double budget_gb = 48.0;
         if (const char *ev = std::getenv("QD_GENERAL_WS_GB")) budget_gb = std::max(0.001, std::atof(ev));
         if (d->gen_ws_limit > 0) budget_gb = (double)d->gen_ws_limit / 1073741824.0;
+        const auto chunks_for = [&](size_t ps) { const int64_t s_ = std::max<int64_t>(256, (int64_t)(budget_gb * 1073741824.0 / (double)ps) & ~(int64_t)255); return (max_batch + s_ - 1) / s_; };
+        if (sp.nbounds > 0 && chunks_for(per_shot) > chunks_for(per_shot1)) { sp.nbounds = 0; per_shot = per_shot1; }
         int64_t S = (int64_t)(budget_gb * 1073741824.0 / (double)per_shot) & ~(int64_t)255;
         S = std::max<int64_t>(256, S);
         const int64_t nchunks = (max_batch + S - 1) / S;
@@ -1228,6 +1264,18 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
         HIP_TRY(hipMalloc((void **)&w.llr, sizeof(float) * (size_t)g->n * S));
         HIP_TRY(hipMalloc((void **)&w.syn, (size_t)g->m * S));
         HIP_TRY(hipMalloc((void **)&w.slot, sizeof(int32_t) * (size_t)S));
+        if (sp.nbounds > 0) {
+            HIP_TRY(hipMalloc((void **)&sp.msg2, sizeof(float) * (size_t)g->nnz * S));
+            HIP_TRY(hipMalloc((void **)&sp.syn2, (size_t)g->m * S));
+            sp.w2 = w;
+            (ps ? sp.w2.th : sp.w2.b2c) = sp.msg2;
+            sp.w2.syn = sp.syn2;
+            HIP_TRY(hipMalloc((void **)&sp.lists[0], sizeof(int32_t) * (size_t)S));
+            HIP_TRY(hipMalloc((void **)&sp.lists[1], sizeof(int32_t) * (size_t)S));
+            HIP_TRY(hipMalloc((void **)&sp.counts, sizeof(int32_t) * (QD_GEN_MAX_STAGES + 1)));
+            HIP_TRY(hipHostMalloc((void **)&sp.host_counts, sizeof(int32_t) * (QD_GEN_MAX_STAGES + 1)));
+            HIP_TRY(hipEventCreateWithFlags(&sp.counts_ready, hipEventDisableTiming));
+        }
     }
     d->cap = max_batch;
     return QD_OK;
@@ -1328,7 +1376,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
             gg.llr0 = d->llr0_q;
             for (int64_t b0 = 0; b0 < B; b0 += d->gws.S)
                 HIP_TRY(qd_launch_bp_general(gg, d->g->bp, a, d->gws, d->prm.bp_method, d->prm.schedule, b0,
-                                             (int)std::min<int64_t>(d->gws.S, B - b0), s));
+                                             (int)std::min<int64_t>(d->gws.S, B - b0), s, d->gsp.nbounds > 0 ? &d->gsp : nullptr));
         } else if (d->grid_k >= 0) {
             // grid arithmetic: first pass on the fine grid parks the shots whose exactness bound tripped; they are decoded
             // again on the coarse grid by a second launch (one workgroup per parked shot; the others exit at once)

@@ -132,6 +132,37 @@ struct GenWs {
     int32_t *slot;                  // [S]  fail-list slot of a shot BP could not finish, else -1
     int64_t S;
 };
+// One launch of the serial schedule = iterations it0 + 1 .. it_end of the shots in its columns.  A launch that is not the last hands the
+// shots that have not converged on, PACKED: their state between two sweeps is the message plane and the syndrome plane, nothing else (suffixes,
+// prefixes and posteriors are rebuilt by every sweep), so the survivors' columns of those two planes are copied to consecutive columns of `next`
+// and the next launch runs on full wavefronts (bp.hpp's shot loop has no such problem: one shot, one thread; here a lane that has converged
+// idles until the slowest of its 64 shots is done -- 31 % of the lanes of the reference-settings windows, profiles/r05_k1g_load_curve.txt).
+#define QD_GEN_MAX_STAGES 12
+struct GenStagePlan;
+struct GenStage {
+    const int32_t *in_shot;     // [columns] the shot (index into the batch) of each column; nullptr: column c holds shot shot0 + c (first launch)
+    const int32_t *in_count;    // columns in use (device); nullptr: nshots
+    int32_t *out_shot;          // the survivors' shots, by column of `next`
+    int32_t *out_count;
+    int it0, it_end, last;      // last: it_end is max_iter -- shots still running are BP failures, there is no next launch
+    GenWs next;
+};
+struct GenStagePlan {           // host side: the iteration bounds between the launches and what they hand over
+    int nbounds;
+    int bounds[QD_GEN_MAX_STAGES];
+    GenWs w2;                   // the workspace of the odd launches: its own message and syndrome planes (msg2, syn2), everything else shared with the first
+    float *msg2;
+    uint8_t *syn2;
+    int32_t *lists[2];          // [S] each
+    int32_t *counts;            // [QD_GEN_MAX_STAGES + 1]
+    // what the last staged call packed, read back without waiting (pinned copy + event): a decoder whose shots do not converge -- a window far above
+    // threshold -- gains nothing from packing and pays the copies; it then runs in one launch and tries again every QD_GEN_PROBE calls.  Same results either way.
+    int32_t *host_counts;
+    hipEvent_t counts_ready;
+    int pending, pending_shots, pending_nb;
+    int one_launch_calls;
+};
+#define QD_GEN_PROBE 16
 
 // Elimination (OSD) view: original indexing.
 struct OsdGraphDev {

@@ -217,6 +217,27 @@ def test_kernels_use_no_scratch(tmp_path, src, pattern, count, why):
     assert all(sc == 0 for _, sc in kern), [k for k in kern if k[1]]
 
 
+def test_serial_edge_kernel_keeps_five_workgroups_per_cu(tmp_path):
+    """qd_bp_edge_kernel, serial schedule, column weight <= 8 (the reference wrapper's default BP on every BASELINE window): at most 96 vector
+    registers and no scratch, so that five workgroups of four wavefronts share a CU.  97 registers = four workgroups: 55 -> 76 ms per launch on
+    the W = 5 windows (profiles/r06_k1g_staged_ab.txt) -- a shot index held across the sweeps was enough."""
+    import re
+    import subprocess
+    cs = os.path.join(ROOT, "quits_amd", "csrc")
+    mk = open(os.path.join(cs, "Makefile")).read()
+    flags = [f for f in re.search(r"^FLAGS := (.*)$", mk, re.M).group(1).replace("$(ARCH)", "gfx950").split() if f != "-shared"]
+    out = subprocess.run(["/opt/rocm/bin/hipcc"] + flags + ["-Rpass-analysis=kernel-resource-usage", "--cuda-device-only", "-c", "-o",
+                          str(tmp_path / "g.o"), os.path.join(cs, "bp_general.hip")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    vgprs = [int(x) for x in re.findall(r"VGPRs: (\d+)", out.stderr)]
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(vgprs) == len(scratch)
+    serial = [(n, v, sc) for n, v, sc in zip(names, vgprs, scratch) if re.search(r"qd_bp_edge_kernelILi[01]ELi1ELi4ELi[48]E", n)]
+    assert len(serial) == 8, [n for n, _, _ in serial]          # 2 methods x column weight 4 / 8 x prefixes in LDS or not
+    assert all(v <= 96 and sc == 0 for _, v, sc in serial), serial
+
+
 def test_plan_cache_is_process_wide_locked_and_keyed_on_the_device(monkeypatch):
     """a cached plan is bound to the device it was built on -- the key holds the current device -- and carries
     mutable state (staging buffers, side streams, decoder workspaces): ONE cache per process under a module lock, use serialised by

@@ -341,6 +341,8 @@ def _gpu_decode_general(H, pri, synd, method, schedule, max_iter, osd="osd_off",
     ("hgp225_cardinal_r3_p0.01", 130, "product_sum", "serial", 3, 1.0),
     ("hgp225_cardinal_r3_p0.01", 130, "product_sum", "parallel", 10, 1.0),
     ("bb144_custom_r12_p0.003", 70, "product_sum", "serial", 2, 1.0),      # the reference wrapper's defaults (bposd.py:54)
+    ("bb72_custom_r6_p0.003", 300, "product_sum", "serial", 12, 1.0),      # serial schedule in four launches (bounds 3, 6, 10), survivors packed in between
+    ("bb72_custom_r6_p0.003", 300, "minimum_sum", "serial", 12, 0.0),      # ... with the iteration-dependent scaling carried across the launches
 ])
 def test_general_bp_bit_exact(gpu, name, shots, method, schedule, max_iter, alpha):
     H, L, pri = helpers.dem_matrices(name)
@@ -375,6 +377,55 @@ def test_general_bposd_bit_exact(gpu, method, schedule, osd, order, max_iter):
     assert np.array_equal(used_osd, 1 - flags[:, 0])
     assert used_osd.sum() > 10, "test does not exercise OSD"
     assert np.array_equal(err, ref)
+
+
+def test_general_serial_staged_launches_equal_one_launch(gpu, monkeypatch):
+    """The serial schedule in several launches (GenStage: the shots still running are packed into full wavefronts after iterations 3, 6, 10, ...)
+    returns what ONE launch returns -- decisions, iteration counts, flags, and the OSD results of the shots BP could not finish (their posteriors
+    come from the last launch's workspace, by its columns) -- for other bounds too, for a batch decoded in several workspace chunks, and equals the oracle."""
+    import torch
+    from quits_amd.decoder.device import BatchDecoder, DemSampler, WindowGraph
+    H, L, pri = helpers.dem_matrices("bb72_custom_r6_p0.003")
+    det, _ = DemSampler(H, L, pri).sample(1500, seed=18)
+    det[5] = 0
+    g = WindowGraph(H, pri)
+    for method, osd, order in (("product_sum", "osd_cs", 2), ("minimum_sum", "osd_0", 0)):
+        kw = dict(bp_method=method, schedule="serial", max_iter=9, osd_method=osd, osd_order=order, edge_messages=True)
+        monkeypatch.setenv("QD_GEN_STAGES", "0")
+        one = BatchDecoder(g, **kw)
+        bits_1, st_1 = one.decode(det)
+        assert ((st_1 >> 17) & 1).sum() > 20, "test does not exercise the hand-over to OSD"
+        for stages in (None, "1,2,3,4,5,6,7", "4"):
+            if stages is None:
+                monkeypatch.delenv("QD_GEN_STAGES")
+            else:
+                monkeypatch.setenv("QD_GEN_STAGES", stages)
+            d = BatchDecoder(g, **kw)
+            bits, st = d.decode(det)
+            assert torch.equal(bits, bits_1) and torch.equal(st, st_1), (method, stages)
+        # shots that do not converge (random syndromes): packing returns nothing, the decoder notices from the counts of its first call and runs
+        # the next ones in one launch -- same results before and after the switch
+        bad = (torch.rand((4352, det.shape[1]), device=det.device) < 0.25).to(torch.uint8)
+        bits_b, st_b = one.decode(bad)
+        for rep in range(3):
+            bits, st = d.decode(bad)
+            torch.cuda.synchronize()
+            assert torch.equal(bits, bits_b) and torch.equal(st, st_b), (method, "no convergence", rep)
+        bits, st = d.decode(det)
+        assert torch.equal(bits, bits_1) and torch.equal(st, st_1), (method, "after the switch")
+        monkeypatch.setenv("QD_GENERAL_WS_GB", "0.02")          # ~ 256-shot chunks (two message planes of them)
+        monkeypatch.delenv("QD_GEN_STAGES", raising=False)
+        d = BatchDecoder(g, **kw)
+        bits, st = d.decode(det)
+        assert torch.equal(bits, bits_1) and torch.equal(st, st_1), (method, "chunks")
+        monkeypatch.delenv("QD_GENERAL_WS_GB")
+        from quits_amd.decoder.device import unpack_bits
+        synd = det[:200].cpu().numpy()
+        go, form = orc.device_arithmetic(H, pri, method, "serial", 9, 1.0)
+        form = orc.FORM_LDPC_F32 if form == orc.FORM_COMPRESSED_F32 else form
+        ref, flags = go.decode_batch(synd, orc.make_params(method, "serial", 9, osd, order, 1.0, form))
+        assert np.array_equal(unpack_bits(bits_1[:200], g.n).cpu().numpy(), ref)
+        assert np.array_equal((st_1[:200].cpu().numpy() >> 16) & 1, flags[:, 0])
 
 
 def test_general_chunking_and_compressed_agreement(gpu, monkeypatch):
