@@ -38,6 +38,11 @@
 #ifndef QSW_GPRIO
 #define QSW_GPRIO 1
 #endif
+// QSW_PRIO_BASE: added to every priority this kernel sets (gather rounds 0 / 1 / 2, scatter pass QS_PRIO, 0 in between): above 0 the wavefronts of a
+// kernel running beside this one at the default priority (the pipelined driver's post-processing) only issue when these do not
+#ifndef QSW_PRIO_BASE
+#define QSW_PRIO_BASE 0
+#endif
 
 __device__ __forceinline__ uint4 qs_reuse4(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); return v; }   // (QS_ABL_NOADJ: opaque, so that the reads it feeds stay in the loops)
 
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             float a1 = FLT_MAX, a2 = FLT_MAX;
             uint32_t kst = 0u;
 #if QSW_GPRIO       /* the later gather rounds of a wavefront run at a higher priority (see QSW_GPRIO above) */
-            if (j == 0) __builtin_amdgcn_s_setprio(0); else if (j == CPL - 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+            if (j == 0) __builtin_amdgcn_s_setprio(QSW_PRIO_BASE); else if (j == CPL - 1) __builtin_amdgcn_s_setprio((QSW_PRIO_BASE + 2) & 3); else __builtin_amdgcn_s_setprio((QSW_PRIO_BASE + 1) & 3);
 #endif
             if (act[j]) {
                 // (the round's loop bounds are re-derived from one scalar every pass: hoisted out of the iteration loop they, and everything computed
@@ -228,7 +233,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
             A1[j] = a1; A2[j] = a2; KST[j] = kst;
         }
 #if QSW_GPRIO
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(QSW_PRIO_BASE);
 #endif
         if (QSW_PREFETCH) pf = QS_ADJ_FIRST;              // for the scatter pass behind the barrier
         {
@@ -249,7 +254,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
 #endif
         if (t == a.max_iter) break;
         // ---- scatter pass, in place: each edge's accumulator moves by (new message) - (message sent last time)
-        __builtin_amdgcn_s_setprio(QS_PRIO);
+        __builtin_amdgcn_s_setprio((QSW_PRIO_BASE + QS_PRIO) & 3);
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
 #ifdef QSW_STATS
@@ -362,7 +367,7 @@ __global__ void __launch_bounds__(T, MW) qd_bp_scatter_wide_kernel(BpGraphDev g,
 #pragma unroll
             for (int w = 0; w < NSW; ++w) O[j][w] = Q[j][w];
         }
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(QSW_PRIO_BASE);
         if (QSW_PREFETCH) pf = QS_ADJ_FIRST;              // for the next gather pass
         __syncthreads();
         ++t;

@@ -64,6 +64,9 @@ template <int T, int RPT, int KWR>
 __global__ void __launch_bounds__(T, QD_SR_WPS_OF(RPT)) qd_osd0_sr_kernel(OsdSrArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+#if QD_SR_PRIO
+    __builtin_amdgcn_s_setprio(QD_SR_PRIO);              // (see QD_SR_PRIO in qd_internal.h)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     constexpr int NW = T / 64;
     static_assert(NW <= 16 && T >= 256, "key / flag records hold 16 wavefronts; the tier drawing wants >= 256 threads");

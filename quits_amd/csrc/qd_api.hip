@@ -104,7 +104,14 @@ struct qd_decoder {
     int64_t cap = 0;
     int osd_blocks = 0;
     float *llr_ws = nullptr;
-    int32_t *fail_list = nullptr, *fail_count = nullptr;
+    int32_t *fail_list = nullptr, *fail_count = nullptr;     // fail_count: the counter set of the call in flight = ctr_base + 64 * cset
+    // Two sets of counters (fail / hard / redo / recheck counts), used by alternate calls.  A call's BP stage needs its set at zero; the set is zeroed by
+    // the post-processing stage of the call BEFORE, on ITS stream (that set was last used two calls ago) -- not by fills at the head of the BP stage: in the
+    // pipelined driver those fills sat between two BP kernels and each chunk lost ~2 ms there (a 4-byte fill launched the moment the other stream's OSD
+    // kernel starts takes 1.9-2.1 ms, profiles/r06_bp_stream_bubble.txt).  set_clean: the set has been zeroed by an operation already queued.
+    int32_t *ctr_base = nullptr;
+    int cset = 0;
+    bool set_clean[2] = {false, false};
     uint16_t *order_ws = nullptr;
     uint64_t *q_spill = nullptr, *q_spill_fast = nullptr, *mt_ws = nullptr;
     uint64_t *q_spill_sr = nullptr;
@@ -1083,7 +1090,8 @@ static void free_ws(qd_decoder *d)
 {
     if (d->llr_ws) (void)hipFree(d->llr_ws);
     if (d->fail_list) (void)hipFree(d->fail_list);
-    if (d->fail_count) (void)hipFree(d->fail_count);
+    if (d->ctr_base) (void)hipFree(d->ctr_base);
+    d->ctr_base = nullptr;
     if (d->order_ws) (void)hipFree(d->order_ws);
     if (d->q_spill) (void)hipFree(d->q_spill);
     if (d->q_spill_fast) (void)hipFree(d->q_spill_fast);
@@ -1142,8 +1150,9 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
     free_ws(d);
     const qd_graph *g = d->g;
     const bool osd = d->prm.osd_method != QD_OSD_OFF;
-    HIP_TRY(hipMalloc((void **)&d->fail_count, 256));
-    HIP_TRY(hipMemset(d->fail_count, 0, 256));
+    HIP_TRY(hipMalloc((void **)&d->ctr_base, 512));
+    HIP_TRY(hipMemset(d->ctr_base, 0, 512));
+    d->fail_count = d->ctr_base; d->cset = 0; d->set_clean[0] = d->set_clean[1] = true;
     if (d->grid_k >= 0 && !d->general) {
         d->redo_cap = (int)(d->grid_floor ? max_batch : std::min<int64_t>(max_batch, 4096));
         HIP_TRY(hipMalloc((void **)&d->redo_list, sizeof(int32_t) * (size_t)d->redo_cap));
@@ -1344,6 +1353,15 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool osd = d->prm.osd_method != QD_OSD_OFF;
+    if (stage & 1) {                                     // a new call: the other counter set (see qd_decoder::ctr_base)
+        d->cset ^= 1;
+        d->fail_count = d->ctr_base + 64 * d->cset;
+        if (!d->set_clean[d->cset] || std::getenv("QD_COUNTER_FILLS")) {
+            HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
+            HIP_TRY(hipMemsetAsync(d->fail_count + 40, 0, 2 * sizeof(int32_t), s));
+        }
+        d->set_clean[d->cset] = false;
+    }
     DecodeArgs a{};
     a.det = d_det; a.det_stride = det_stride; a.det_offset = det_offset;
     a.upd = d_upd; a.upd_stride = upd_stride; a.upd_rows = d_upd ? upd_rows : 0;
@@ -1352,7 +1370,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
     a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.q_spill_sr = d->q_spill_sr; a.mt_ws = d->mt_ws;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
-    a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;   // bytes 16..143 of the counter block
+    a.dbg = reinterpret_cast<unsigned long long *>(d->ctr_base) + 2;   // bytes 16..143 of the counter block (first set, never zeroed by a call)
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
     auto span = [&](int kind, hipEvent_t &t0) -> int {
         if (!d->profiling) return QD_OK;
@@ -1363,8 +1381,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         return QD_OK;
     };
     if (stage & 1) {
-        int32_t *redo_count = d->fail_count + 40;       // bytes 160..163 of the counter block (16..143 are the debug counters)
-        HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
+        int32_t *redo_count = d->fail_count + 40;       // bytes 160..163 of the counter set (16..143 of the first set are the debug counters)
         hipEvent_t t0 = nullptr;
         if (int rc = span(0, t0)) return rc;
         if (d->lds_edge) {
@@ -1380,7 +1397,6 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         } else if (d->grid_k >= 0) {
             // grid arithmetic: first pass on the fine grid parks the shots whose exactness bound tripped; they are decoded
             // again on the coarse grid by a second launch (one workgroup per parked shot; the others exit at once)
-            HIP_TRY(hipMemsetAsync(redo_count, 0, sizeof(int32_t), s));
             DecodeArgs a1 = a;
             a1.s_limit = std::ldexp(1.0f, 23 - d->grid_k);
             a1.redo_list = d->redo_list; a1.redo_count = redo_count; a1.redo_cap = d->redo_cap;
@@ -1388,7 +1404,6 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
                 // scatter kernel first; the shots its (looser) bound cannot certify are decoded again by the gather kernel,
                 // which carries the per-fault bound the coarse-grid rule is stated on
                 int32_t *recheck_count = d->fail_count + 41;
-                HIP_TRY(hipMemsetAsync(recheck_count, 0, sizeof(int32_t), s));
                 ScatArgs x{};
                 x.prior_g = d->prior_g; x.grid_inv = std::ldexp(1.0f, -d->grid_k); x.m2_limit = d->m2_limit;
                 x.recheck_list = d->recheck_list; x.recheck_count = recheck_count; x.recheck_cap = d->recheck_cap;
@@ -1427,6 +1442,12 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
                                    (int)std::min<int64_t>(B, d->osd_blocks), s));
         if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
         if (std::getenv("QD_DEBUG_SYNC")) { std::fprintf(stderr, "[qd] post-processing stage queued (B = %lld)\n", (long long)B); HIP_TRY(hipStreamSynchronize(s)); std::fprintf(stderr, "[qd] post-processing stage done\n"); }
+    }
+    if ((stage & 2) && !d->set_clean[d->cset ^ 1]) {     // the next call's counters, zeroed behind this call's last stage (nothing waits for these fills)
+        int32_t *other = d->ctr_base + 64 * (d->cset ^ 1);
+        HIP_TRY(hipMemsetAsync(other, 0, 3 * sizeof(int32_t), s));
+        HIP_TRY(hipMemsetAsync(other + 40, 0, 2 * sizeof(int32_t), s));
+        d->set_clean[d->cset ^ 1] = true;
     }
     return QD_OK;
 }
@@ -1470,9 +1491,10 @@ extern "C" int qd_osd0_batch(qd_decoder *d, const uint8_t *d_det, int64_t det_st
     a.llr_ws = d->llr_ws; a.fail_list = d->fail_list; a.fail_count = d->fail_count;
     a.order_ws = d->order_ws; a.q_spill = d->q_spill; a.q_spill_fast = d->q_spill_fast; a.q_spill_sr = d->q_spill_sr; a.mt_ws = d->mt_ws;
     a.hard_list = d->hard_list; a.hard_list2 = d->hard_list2; a.hard_count = d->fail_count + 1;
-    a.dbg = reinterpret_cast<unsigned long long *>(d->fail_count) + 2;
+    a.dbg = reinterpret_cast<unsigned long long *>(d->ctr_base) + 2;
     a.osd_w = d->osd_w; a.osd_order = d->prm.osd_order; a.rank = d->g->rank;
     HIP_TRY(hipMemsetAsync(d->fail_count, 0, 3 * sizeof(int32_t), s));
+    d->set_clean[d->cset] = false;
     HIP_TRY(qd_launch_stage_llr(d_llr, d->g->n, d->g->bp.n_pad, d->g->bp.bit_orig, B, d->llr_ws, d->fail_list, d->fail_count,
                                 d_status, s));
     if (lsd_only)
@@ -1496,8 +1518,8 @@ extern "C" int qd_decoder_debug_counters(qd_decoder *d, uint64_t *out16)
     if (!d || !out16 || !d->fail_count) return fail(QD_EINVAL, "no workspace yet");
     HIP_TRY(hipSetDevice(d->g->device));
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out16, reinterpret_cast<char *>(d->fail_count) + 16, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(reinterpret_cast<char *>(d->fail_count) + 16, 0, 16 * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpy(out16, reinterpret_cast<char *>(d->ctr_base) + 16, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(reinterpret_cast<char *>(d->ctr_base) + 16, 0, 16 * sizeof(uint64_t)));
     return QD_OK;
 }
 

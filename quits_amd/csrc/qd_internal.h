@@ -137,6 +137,11 @@ struct GenWs {
 // prefixes and posteriors are rebuilt by every sweep), so the survivors' columns of those two planes are copied to consecutive columns of `next`
 // and the next launch runs on full wavefronts (bp.hpp's shot loop has no such problem: one shot, one thread; here a lane that has converged
 // idles until the slowest of its 64 shots is done -- 31 % of the lanes of the reference-settings windows, profiles/r05_k1g_load_curve.txt).
+// Wavefront priority of qd_osd0_sr_kernel.  In the pipelined driver it runs beside the BP kernel of the other lane, whose workgroups fill every wavefront
+// slot: an OSD workgroup takes the place of one BP workgroup on its CU for as long as it lives, and at equal priority it lives 2-5 times longer than alone.
+#ifndef QD_SR_PRIO
+#define QD_SR_PRIO 0
+#endif
 #define QD_GEN_MAX_STAGES 12
 struct GenStagePlan;
 struct GenStage {
