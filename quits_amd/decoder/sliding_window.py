@@ -144,9 +144,13 @@ class DeviceWindowPlan:
         # per-edge kernel: HBM-bound, it loses more to the co-running post-processor than the overlap returns (W = 5 / F = 3
         # windows with the reference's settings 219 k -> 209 k shots/s, profiles/r03x_pipelined_driver_multiwindow_ab.txt)
         self.pipeline = not _env_flag("QD_NO_PIPELINE") and (_env_flag("QD_PIPELINE_EDGE") or not any(d.info()["edge_kernel"] for d in decs))
+        # lanes of the pipelined driver: 2; 3 for plans of several windows -- a lane's next BP stage waits for its last post stage, which
+        # runs beside the BP of the NEXT lane and, starved of wavefront slots by it, ends ~0.4 ms after it: with two lanes the BP stream
+        # waits that long before every stage, with three the post stage has one more BP stage's time (profiles/r06_three_lanes_ab.txt)
+        self.lanes = max(2, _env_int("QD_PIPELINE_LANES", 3 if nwin > 1 else 2))
         self._side = None
         self._stage = None
-        self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", 2 * self.chunk))   # shots per staged piece (>= 2 chunks: the pipelined driver)
+        self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", self.lanes * self.chunk))   # shots per staged piece (one group of the pipelined driver's lanes)
         self.device = _current_device()      # graphs, decoders and workspaces were created on this device
         import threading
         self._lock = threading.RLock()       # one decode_host at a time per plan (staging buffers, side streams and workspaces are per plan);
@@ -156,9 +160,8 @@ class DeviceWindowPlan:
         """Hand the decoders' device workspaces and the staging buffers back (the plan itself -- graphs, decoders, matrices --
         stays): cached plans that are not the one in use hold no large allocations."""
         for w in self.windows:
-            for key in ("dec", "dec2"):
-                if key in w:
-                    w[key].release_workspace()
+            for d in w.get("lane_decs", [w["dec"]]):
+                d.release_workspace()
         self._stage = None
 
     def window_matrices(self):
@@ -319,18 +322,21 @@ def _decode_pipelined_impl(plan, det, stats, chain=None):
     streams itself when it has queued everything (profiles/r06_host_chain_ab.txt)."""
     import torch
     from .device import BatchDecoder
-    if plan._side is None:
+    NL = int(plan.lanes)
+    if any(len(w.get("lane_decs", ())) < NL for w in plan.windows):
         import os
-        second = {}
+        by_first = {}                                 # windows that share a decoder share its lanes' decoders (each with its own workspaces)
         for w in plan.windows:
-            if id(w["dec"]) not in second:
-                second[id(w["dec"])] = BatchDecoder(w["graph"], **w["kw"])
-            w["dec2"] = second[id(w["dec"])]
+            lst = by_first.setdefault(id(w["dec"]), list(w.get("lane_decs", [w["dec"]])))
+            while len(lst) < NL:
+                lst.append(BatchDecoder(w["graph"], **w["kw"]))
+            w["lane_decs"] = lst
         if any(d.info()["edge_kernel"] for d in plan.decoders()):
             budget = float(os.environ.get("QD_GENERAL_WS_GB", "96")) * (1 << 30)
-            both = plan.decoders() + list(second.values())
-            for d in both:
-                d.set_workspace_limit(max(1 << 28, int(budget / len(both))))
+            every = [d for lst in by_first.values() for d in lst]
+            for d in every:
+                d.set_workspace_limit(max(1 << 28, int(budget / len(every))))
+    if plan._side is None:
         # (a high-priority post-processing stream, QD_POST_STREAM_PRIORITY=-1, measured no different: profiles/r03x_post_stream_priority_ab.txt)
         plan._side = {}
     if det.device not in plan._side:              # (streams live on the device of the data, one pair per device)
@@ -345,9 +351,9 @@ def _decode_pipelined_impl(plan, det, stats, chain=None):
     if chain is not None and "err_l" in chain:
         err_l, upd_l, st_all = chain["err_l"], chain["upd_l"], chain["st_all"]
     else:
-        err_l = [torch.empty((C * words,), dtype=torch.int32, device=dev) for _ in range(2)]
-        upd_l = [torch.empty((C, plan.nz), dtype=torch.uint8, device=dev) for _ in range(2)] if nwin > 1 else [None, None]
-        st_all = torch.empty((nwin if stats is not None else 1, (N if stats is not None else 2 * C)), dtype=torch.int32, device=dev)
+        err_l = [torch.empty((C * words,), dtype=torch.int32, device=dev) for _ in range(NL)]
+        upd_l = [torch.empty((C, plan.nz), dtype=torch.uint8, device=dev) for _ in range(NL)] if nwin > 1 else [None] * NL
+        st_all = torch.empty((nwin if stats is not None else 1, (N if stats is not None else NL * C)), dtype=torch.int32, device=dev)
         if chain is not None:
             chain.update(err_l=err_l, upd_l=upd_l, st_all=st_all)
     start = torch.cuda.Event()
@@ -356,13 +362,19 @@ def _decode_pipelined_impl(plan, det, stats, chain=None):
     s_post.wait_event(start)
     if chain is not None:
         chain.setdefault("keep", []).append(pred)              # nothing handed out may go back to the allocator before the caller has synchronised
-    post_done = list(chain.get("post_done", [None, None])) if chain is not None else [None, None]
+    post_done = list(chain.get("post_done", [None] * NL)) if chain is not None else [None] * NL
+    # chunks are taken in groups of up to NL, the groups as even as they come (4 chunks on three lanes: 2 + 2, not 3 + 1 -- a chunk alone overlaps nothing)
+    nch = (N + C - 1) // C
+    ngrp = (nch + NL - 1) // NL
+    sizes = [nch // ngrp + (1 if g < nch % ngrp else 0) for g in range(ngrp)]
     try:
-        for p0 in range(0, N, 2 * C):
-            lanes = [(lane, c0) for lane, c0 in enumerate((p0, p0 + C)) if c0 < N]
+        ch0 = 0
+        for gsz in sizes:
+            lanes = [(lane, (ch0 + lane) * C) for lane in range(gsz)]
+            ch0 += gsz
             for k, w in enumerate(plan.windows):
                 for lane, c0 in lanes:
-                    d = w["dec"] if lane == 0 else w["dec2"]
+                    d = w["lane_decs"][lane]
                     chunk, acc = det[c0:c0 + C], pred[c0:c0 + C]
                     B = chunk.shape[0]
                     err = err_l[lane][:B * w["graph"].words].view(B, w["graph"].words)

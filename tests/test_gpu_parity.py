@@ -562,6 +562,12 @@ def test_pipelined_chunks_equal_single_stream(gpu, W, F, opts):
             assert torch.equal(by_p[k], by_s[k]), k
         frac_post = float(((by_p[0] >> 17) & 1).float().mean())
         assert 0.005 < frac_post < 0.98, frac_post          # the post-processor is exercised
+    # several groups of lanes (plans of more than one window run three lanes: groups of 3 + 3 + 3 + 2 chunks here, 2 + 2 + ... on two lanes)
+    assert plan.lanes == (2 if W == 8 else 3)
+    plan.chunk //= 5
+    pred_p = plan.decode(det)
+    plan.pipeline = False
+    assert torch.equal(pred_p, plan.decode(det)) and torch.equal(pred_p, pred_s)
 
 
 def test_public_call_plan_cache_and_streamed_host_samples(gpu, monkeypatch):
