@@ -73,7 +73,7 @@ typedef struct qd_params {
     double ms_scaling_factor;   /* not exposed by the reference wrapper -> ldpc default 1.0; 0 = 1-2^-it */
 } qd_params;
 
-int qd_version(void);                 /* 102 (101: qd_graph_info wrote 12 entries; 102: 10 again + qd_graph_info_ex) */
+int qd_version(void);                 /* 103 (103: qd_decoder_post_head_start; 101: qd_graph_info wrote 12 entries; 102: 10 again + qd_graph_info_ex) */
 const char *qd_last_error(void);
 /* Number of visible HIP devices (0 if none): lets a host fail loudly before building anything. */
 int qd_device_count(void);
@@ -164,6 +164,14 @@ int qd_decoder_failed_llr(qd_decoder *d, int64_t b, float *d_out, void *stream);
 /* Diagnostic: 16 cycle counters the OSD kernels accumulate per phase when the library is built with -DQD_OSD_TIMING
  * (all zero otherwise); reading clears them.  Synchronises. */
 int qd_decoder_debug_counters(qd_decoder *d, uint64_t *out16);
+
+/* Two-stream drivers (qd_decode_stage 1 on one stream, 2 on another; no counterpart in the reference, whose shot loop is sequential,
+ * sliding_window.py:162-186): call this on the BP stream right after a stage-1 call.  If that batch's post-processing is heavy (OSD-CS / OSD-E, BP-LSD, or
+ * OSD-0 over at least three quarters of the batch -- launched only when an earlier call's failure count, read back without waiting, says so, then decided on the
+ * device from the batch's own count) the stream is held for
+ * `microseconds` (< 0: the default, 50; at most 5000), so that the post-processor started on the other stream at that moment is on the CUs before the next
+ * BP kernel fills them; otherwise it costs one empty launch.  Changes no result. */
+int qd_decoder_post_head_start(qd_decoder *d, int32_t microseconds, void *stream);
 
 /* Per-kernel device time of this decoder accumulated between calls (milliseconds, HIP events on `stream`):
  * out[0] BP kernel, out[1] OSD kernel, out[2] number of BP launches, out[3] number of OSD launches.

@@ -42,7 +42,7 @@ _lib = None
 EXPORTS = [
     "qd_version", "qd_last_error", "qd_device_count", "qd_graph_create", "qd_graph_destroy", "qd_graph_info", "qd_graph_info_ex",
     "qd_decoder_create", "qd_decoder_info", "qd_decoder_postproc_kernel", "qd_decoder_destroy", "qd_decoder_reserve", "qd_decoder_set_workspace_limit", "qd_decoder_release_workspace", "qd_decode_batch", "qd_decode_stage", "qd_osd0_batch", "qd_decoder_failed_llr",
-    "qd_decoder_set_profiling", "qd_decoder_profile", "qd_decoder_debug_counters", "qd_spmat_create", "qd_spmat_destroy", "qd_gf2_spmv_batch",
+    "qd_decoder_set_profiling", "qd_decoder_profile", "qd_decoder_post_head_start", "qd_decoder_debug_counters", "qd_spmat_create", "qd_spmat_destroy", "qd_gf2_spmv_batch",
     "qd_unpack_bits", "qd_count_mismatch", "qd_sample_dem",
 ]
 
@@ -66,8 +66,8 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
     L.qd_version.restype = C.c_int
-    if L.qd_version() < 102:              # 102: qd_graph_info_ex (this package's WindowGraph.info) and the 10-entry qd_graph_info
-        raise RuntimeError("quits_amd: %s is version %d, this package needs >= 102 -- rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)"
+    if L.qd_version() < 103:              # 103: qd_decoder_post_head_start (the pipelined driver); 102: qd_graph_info_ex and the 10-entry qd_graph_info
+        raise RuntimeError("quits_amd: %s is version %d, this package needs >= 103 -- rebuild it (`python -c 'import __graft_entry__ as g; g.build()'`)"
                            % (LIB_PATH, L.qd_version()))
     L.qd_last_error.restype = C.c_char_p
     L.qd_device_count.restype = C.c_int
@@ -90,6 +90,7 @@ def load():
     L.qd_osd0_batch.argtypes = [vp, vp, i64, i64, vp, i64, i32, i64, vp, vp, vp, vp]
     L.qd_decoder_failed_llr.argtypes = [vp, i64, vp, vp]
     L.qd_decoder_set_profiling.argtypes = [vp, i32]
+    L.qd_decoder_post_head_start.argtypes = [vp, i32, vp]
     L.qd_decoder_profile.argtypes = [vp, vp, i32]
     L.qd_decoder_debug_counters.argtypes = [vp, vp]
     L.qd_spmat_create.argtypes = [i32, i32, vp, vp, i32, C.POINTER(vp)]

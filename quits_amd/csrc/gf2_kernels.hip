@@ -183,6 +183,22 @@ hipError_t qd_launch_unpack(const uint32_t *bits, int64_t stride_words, int nbit
     return hipGetLastError();
 }
 
+// One wavefront that holds its stream for `ticks` of the 100 MHz wall clock if *count >= threshold (count == nullptr: always).  Bounded: it waits for
+// nobody.  The pipelined driver puts it behind a BP stage whose post-processing is heavy, so that the post-processor -- starting on the other stream at
+// that moment -- gets onto the CUs before the next BP kernel fills every wavefront slot (qd_decoder_post_head_start).
+__global__ void qd_hold_kernel(const int32_t *__restrict__ count, int threshold, unsigned long long ticks)
+{
+    if (count && *count < threshold) return;
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+hipError_t qd_launch_hold(const int32_t *count, int threshold, int microseconds, hipStream_t s)
+{
+    hipLaunchKernelGGL(qd_hold_kernel, dim3(1), dim3(64), 0, s, count, threshold, (unsigned long long)microseconds * 100ull);
+    return hipGetLastError();
+}
+
 hipError_t qd_launch_count(const uint8_t *pred, const uint8_t *obs, int k, int64_t B, int64_t *count, hipStream_t s)
 {
     if (B == 0) return hipSuccess;

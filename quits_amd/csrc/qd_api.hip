@@ -18,6 +18,7 @@ hipError_t qd_launch_bp_scatter(const BpGraphDev &g, const ScatGraphDev &sg, con
 hipError_t qd_launch_bp_scatter_wide(const BpGraphDev &g, const ScatGraphDev &sg, const DecodeArgs &a, const ScatArgs &x, int64_t B, hipStream_t s);
 hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, const GenWs &w, int bp_method,
                                 int schedule, int64_t shot0, int nshots, hipStream_t s, GenStagePlan *plan);
+hipError_t qd_launch_hold(const int32_t *count, int threshold, int microseconds, hipStream_t s);
 int qd_bp_ps_lds_bytes(const GenGraphDev &g, int max_rdeg);
 hipError_t qd_launch_bp_ps_lds(const GenGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int64_t B, hipStream_t s);
 hipError_t qd_launch_osd0(const OsdGraphDev &g, const BpGraphDev &bg, const DecodeArgs &a, int blocks_fast,
@@ -112,6 +113,14 @@ struct qd_decoder {
     int32_t *ctr_base = nullptr;
     int cset = 0;
     bool set_clean[2] = {false, false};
+    int64_t last_B = 0;         // batch size of the last BP stage (qd_decoder_post_head_start prices its failure count against it)
+    // the failure count of an earlier call, read back without waiting (pinned copy + event queued behind a post-processing stage): OSD-0 decoders launch the
+    // hold of qd_decoder_post_head_start only when that says "heavy" -- even an empty launch between two BP kernels costs the headline 0.8 %
+    int32_t *host_fail = nullptr;
+    hipEvent_t fail_ready = nullptr;
+    bool fail_pending = false;
+    int64_t fail_pending_B = 0;
+    double fail_frac_hint = -1.0;
     uint16_t *order_ws = nullptr;
     uint64_t *q_spill = nullptr, *q_spill_fast = nullptr, *mt_ws = nullptr;
     uint64_t *q_spill_sr = nullptr;
@@ -309,7 +318,7 @@ static void scatter_walk(int m, const int32_t *row_ptr, const int32_t *col_idx, 
     }
 }
 
-extern "C" int qd_version(void) { return 102; }      // 102: qd_graph_info fills 10 entries again, qd_graph_info_ex(g, info, n) the rest; 101: qd_decoder_postproc_kernel
+extern "C" int qd_version(void) { return 103; }      // 103: qd_decoder_post_head_start; 102: qd_graph_info fills 10 entries again, qd_graph_info_ex(g, info, n) the rest; 101: qd_decoder_postproc_kernel
 extern "C" const char *qd_last_error(void) { return g_err; }
 extern "C" int qd_device_count(void)
 {
@@ -1092,6 +1101,9 @@ static void free_ws(qd_decoder *d)
     if (d->fail_list) (void)hipFree(d->fail_list);
     if (d->ctr_base) (void)hipFree(d->ctr_base);
     d->ctr_base = nullptr;
+    if (d->host_fail) (void)hipHostFree(d->host_fail);
+    if (d->fail_ready) (void)hipEventDestroy(d->fail_ready);
+    d->host_fail = nullptr; d->fail_ready = nullptr; d->fail_pending = false;
     if (d->order_ws) (void)hipFree(d->order_ws);
     if (d->q_spill) (void)hipFree(d->q_spill);
     if (d->q_spill_fast) (void)hipFree(d->q_spill_fast);
@@ -1153,6 +1165,8 @@ extern "C" int qd_decoder_reserve(qd_decoder *d, int64_t max_batch)
     HIP_TRY(hipMalloc((void **)&d->ctr_base, 512));
     HIP_TRY(hipMemset(d->ctr_base, 0, 512));
     d->fail_count = d->ctr_base; d->cset = 0; d->set_clean[0] = d->set_clean[1] = true;
+    HIP_TRY(hipHostMalloc((void **)&d->host_fail, 2 * sizeof(int32_t)));
+    HIP_TRY(hipEventCreateWithFlags(&d->fail_ready, hipEventDisableTiming));
     if (d->grid_k >= 0 && !d->general) {
         d->redo_cap = (int)(d->grid_floor ? max_batch : std::min<int64_t>(max_batch, 4096));
         HIP_TRY(hipMalloc((void **)&d->redo_list, sizeof(int32_t) * (size_t)d->redo_cap));
@@ -1361,6 +1375,7 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
             HIP_TRY(hipMemsetAsync(d->fail_count + 40, 0, 2 * sizeof(int32_t), s));
         }
         d->set_clean[d->cset] = false;
+        d->last_B = B;
     }
     DecodeArgs a{};
     a.det = d_det; a.det_stride = det_stride; a.det_offset = det_offset;
@@ -1443,12 +1458,44 @@ static int decode_impl(qd_decoder *d, const uint8_t *d_det, int64_t det_stride, 
         if (d->profiling) HIP_TRY(hipEventRecord(d->ev.back().t1, s));
         if (std::getenv("QD_DEBUG_SYNC")) { std::fprintf(stderr, "[qd] post-processing stage queued (B = %lld)\n", (long long)B); HIP_TRY(hipStreamSynchronize(s)); std::fprintf(stderr, "[qd] post-processing stage done\n"); }
     }
+    if ((stage & 2) && osd && !d->fail_pending && d->host_fail) {      // (see qd_decoder::host_fail)
+        HIP_TRY(hipMemcpyAsync(d->host_fail, d->fail_count, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(d->fail_ready, s));
+        d->fail_pending = true; d->fail_pending_B = d->last_B;
+    }
     if ((stage & 2) && !d->set_clean[d->cset ^ 1]) {     // the next call's counters, zeroed behind this call's last stage (nothing waits for these fills)
         int32_t *other = d->ctr_base + 64 * (d->cset ^ 1);
         HIP_TRY(hipMemsetAsync(other, 0, 3 * sizeof(int32_t), s));
         HIP_TRY(hipMemsetAsync(other + 40, 0, 2 * sizeof(int32_t), s));
         d->set_clean[d->cset ^ 1] = true;
     }
+    return QD_OK;
+}
+
+// See include/quits_amd.h.  Heavy = the post-processor will want whole CUs for about as long as a BP stage or longer: OSD-CS / OSD-E (two workgroups of
+// 78 KB of LDS per CU), BP-LSD, and OSD-0 when at least QD_POST_HEAD_FRAC (0.75) of the batch failed (headline p = 3e-3: 48 %, p = 5e-3: 95 %).  Measured, same box, 30 us
+// against none: OSD-CS(1) 361 -> 482 k shots/s, lsd_cs(1) 888 -> 940 k, p = 6e-3 488 -> 569 k, W = 5 / F = 3 1.125 -> 1.153 M; the headline (OSD-0 over
+// 48 % of the shots, 4.4 ms beside 40 ms of BP) is the one that loses, 1.552 -> 1.539 M -- even to an EMPTY launch at this point of the BP stream, so an
+// OSD-0 decoder launches nothing unless an earlier call's failure count (qd_decoder::host_fail) says "heavy" (profiles/r06_post_head_start.txt).
+extern "C" int qd_decoder_post_head_start(qd_decoder *d, int32_t microseconds, void *stream)
+{
+    if (!d) return fail(QD_EINVAL, "null decoder");
+    if (microseconds < 0) microseconds = 50;
+    if (const char *ev = std::getenv("QD_POST_HEAD_START_US")) microseconds = std::atoi(ev);
+    if (microseconds <= 0 || d->prm.osd_method == QD_OSD_OFF || !d->ctr_base || d->last_B <= 0) return QD_OK;
+    microseconds = std::min(microseconds, 5000);
+    HIP_TRY(hipSetDevice(d->g->device));
+    const bool always = d->lsd || d->osd_blocks_cs > 0;
+    double frac = 0.75;
+    if (const char *ev = std::getenv("QD_POST_HEAD_FRAC")) frac = std::atof(ev);
+    if (d->fail_pending && hipEventQuery(d->fail_ready) == hipSuccess) {
+        d->fail_pending = false;
+        if (d->fail_pending_B > 0) d->fail_frac_hint = (double)d->host_fail[0] / (double)d->fail_pending_B;
+    }
+    if (std::getenv("QD_DEBUG_HEAD")) std::fprintf(stderr, "[qd] head start: decoder %p always %d hint %.3f host_fail %d pending_B %lld last_B %lld\n", (void *)d, (int)always, d->fail_frac_hint, d->host_fail ? d->host_fail[0] : -1, (long long)d->fail_pending_B, (long long)d->last_B);
+    if (!always && d->fail_frac_hint < 0.8 * frac) return QD_OK;        // OSD-0 over a minority of the shots (or nothing known yet): no launch at all
+    const int threshold = (int)std::min<double>(2147483647.0, std::max(1.0, frac * (double)d->last_B));
+    HIP_TRY(qd_launch_hold(always ? nullptr : d->fail_count, threshold, microseconds, reinterpret_cast<hipStream_t>(stream)));
     return QD_OK;
 }
 

@@ -127,6 +127,10 @@ class BatchDecoder:
                                            _ptr(err_bits), _ptr(status), int(stage), sp))
         return err_bits, status
 
+    def post_head_start(self, stream, microseconds: int = -1):
+        """Two-stream drivers: behind a stage-1 call on `stream`, hold that stream briefly if this batch's post-processing is heavy (qd_decoder_post_head_start)."""
+        _lib.check(self._L.qd_decoder_post_head_start(self._h, int(microseconds), C.c_void_p(stream.cuda_stream)))
+
     def osd0(self, det, llr, det_offset: int = 0, upd=None):
         """OSD-0 alone on caller-supplied posteriors llr: cuda float32 [B, n] (fault order).  Returns (err_bits, status)."""
         torch = _torch()

@@ -387,6 +387,7 @@ def _decode_pipelined_impl(plan, det, stats, chain=None):
                     d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=1, stream=s_bp)
                     bp_done = torch.cuda.Event()
                     bp_done.record(s_bp)
+                    d.post_head_start(s_bp)            # (heavy post-processing gets onto the CUs before the next BP kernel fills them; decided on the device)
                     s_post.wait_event(bp_done)
                     d.decode(chunk, w["row0"], upd, err_bits=err, status=st, stage=2, stream=s_post)
                     w["L"].xor_apply(err, acc, accumulate=True, stream=s_post)
