@@ -287,9 +287,9 @@ def main():
 OTHER_CONFIGS = [
     # name, overrides
     ("configs[1] bb72 single window", dict(code="bb72", shots=262144, steps=3, warmup=1)),
-    ("configs[1] bb72 W=3 F=1", dict(code="bb72", window=[3, 1], shots=262144, steps=3, warmup=1)),
-    ("configs[2] bb144 W=3 F=1", dict(window=[3, 1], shots=262144, steps=3, warmup=1)),
-    ("configs[2] bb144 W=5 F=3", dict(window=[5, 3], shots=262144, steps=3, warmup=1)),
+    ("configs[1] bb72 W=3 F=1", dict(code="bb72", window=[3, 1], shots=393216, steps=2, warmup=1)),       # (six chunks: two groups of the driver's three lanes)
+    ("configs[2] bb144 W=3 F=1", dict(window=[3, 1], shots=393216, steps=2, warmup=1)),
+    ("configs[2] bb144 W=5 F=3", dict(window=[5, 3], shots=393216, steps=2, warmup=1)),
     ("configs[3] bb144 p=1e-3", dict(p=0.001, shots=262144, steps=3, warmup=1)),
     ("configs[3] bb144 p=6e-3", dict(p=0.006, shots=262144, steps=3, warmup=1)),
     ("configs[2] bb144 headline window, osd_cs(1)", dict(osd_method="osd_cs", osd_order=1, shots=131072, steps=2, warmup=1)),
