@@ -39,6 +39,7 @@ def test_no_compute_without_gpu_but_argument_checks_work():
     assert rc == -1 and b"empty" in L.qd_last_error()
     with pytest.raises(RuntimeError, match="no HIP device"):
         _lib.require_gpu()
+    assert L.qd_decoder_post_head_start(None, 50, None) == -1 and b"null decoder" in L.qd_last_error()      # (C-ABI 103: argument check, no launch)
 
 
 def test_package_surface_mirrors_reference():
