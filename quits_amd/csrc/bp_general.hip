@@ -339,7 +339,11 @@ __global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8
                                                        ((uint32_t)syn[(size_t)(rw & 0x7FFFFFu) * S] << 31));
                             else P[k] = pls[(rw >> 24) * 64 + lane];
                         } else P[k] = rpre[(size_t)cur[2 + k] * S];
+#if defined(QD_GEN_ABL_NOX)      /* timing experiment only (wrong results): the suffix does not come from memory -- what a perfect prefetch of it could return */
+                        X[k] = __uint_as_float(0x3f000000u | (cur[2 + D + k] & 0xFFu));
+#else
                         X[k] = suf[(size_t)cur[2 + D + k] * S];
+#endif
                     }
 #pragma unroll
                 for (int k = 0; k < D; ++k)
