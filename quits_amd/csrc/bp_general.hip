@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(64 * G, (SCHED == QD_SCHEDULE_SERIAL && D <= 8
                         }
                     }
                 }
-                if (G > 1 && (head >> 31)) __syncthreads();
+                if (G > 1 && (head >> 31)) __syncthreads();        // (a barrier that orders LDS only -- no wait for the level's global stores -- measured no different: r06_k1g_staged_ab.txt (6))
             }
             }
         }
