@@ -64,7 +64,7 @@ def run(trials=200, seed=1):
         osd, order = [("osd_0", 0), ("osd_off", 0), ("osd_cs", int(rng.integers(0, 6))), ("osd_e", int(rng.integers(0, 5))), ("osd_0", 0),
                       ("lsd_0", 0), ("osd_cs", int(rng.integers(1, 12))), ("lsd_cs", int(rng.integers(1, 9))), ("lsd_e", int(rng.integers(1, 7))),
                       ("lsd_cs", 1)][int(rng.integers(0, 10))]
-        max_iter = int(rng.integers(1, 25)) if sched == "parallel" else int(rng.integers(1, 6))
+        max_iter = int(rng.integers(1, 25)) if sched == "parallel" else int(rng.integers(1, 13))     # (serial: up to 12, so that the staged launches -- bounds 3, 6, 10 -- are drawn)
         alpha = float(rng.choice([1.0, 1.0, 0.0, 0.625]))
         try:
             wg = WindowGraph(H, pri)
