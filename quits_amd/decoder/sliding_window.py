@@ -301,6 +301,15 @@ class DeviceWindowPlan:
         return res
 
 
+def lane_groups(nchunks, lanes):
+    """Chunks of a call dealt to groups of at most `lanes`, as few groups as possible and as even as they come: 4 chunks on three lanes are 2 + 2,
+    not 3 + 1 (a chunk alone overlaps nothing), 16 on three are 3 + 3 + 3 + 3 + 2 + 2."""
+    if nchunks <= 0:
+        return []
+    ngrp = (nchunks + lanes - 1) // lanes
+    return [nchunks // ngrp + (1 if g < nchunks % ngrp else 0) for g in range(ngrp)]
+
+
 def _decode_pipelined_impl(plan, det, stats, chain=None):
     """Calls of two or more chunks: the BP stages run on one side stream, the post-processing (OSD / LSD over the shots BP
     parked, acc ^= L e, the hand-off U e) on a second one, so that a chunk's post-processing runs beside the BP of the other
@@ -364,9 +373,7 @@ def _decode_pipelined_impl(plan, det, stats, chain=None):
         chain.setdefault("keep", []).append(pred)              # nothing handed out may go back to the allocator before the caller has synchronised
     post_done = list(chain.get("post_done", [None] * NL)) if chain is not None else [None] * NL
     # chunks are taken in groups of up to NL, the groups as even as they come (4 chunks on three lanes: 2 + 2, not 3 + 1 -- a chunk alone overlaps nothing)
-    nch = (N + C - 1) // C
-    ngrp = (nch + NL - 1) // NL
-    sizes = [nch // ngrp + (1 if g < nch % ngrp else 0) for g in range(ngrp)]
+    sizes = lane_groups((N + C - 1) // C, NL)
     try:
         ch0 = 0
         for gsz in sizes:

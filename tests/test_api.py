@@ -239,6 +239,18 @@ def test_serial_edge_kernel_keeps_five_workgroups_per_cu(tmp_path):
     assert all(v <= 96 and sc == 0 for _, v, sc in serial), serial
 
 
+def test_lane_groups_of_the_pipelined_driver():
+    """Chunks are dealt to the driver's lanes in as few groups as possible, as even as they come, in order."""
+    from quits_amd.decoder.sliding_window import lane_groups
+    assert lane_groups(0, 3) == [] and lane_groups(1, 2) == [1] and lane_groups(2, 3) == [2] and lane_groups(3, 3) == [3]
+    assert lane_groups(4, 3) == [2, 2] and lane_groups(5, 3) == [3, 2] and lane_groups(7, 3) == [3, 2, 2] and lane_groups(16, 3) == [3, 3, 3, 3, 2, 2]
+    assert lane_groups(16, 2) == [2] * 8 and lane_groups(3, 2) == [2, 1]
+    for n in range(1, 40):
+        for lanes in (2, 3, 4):
+            g = lane_groups(n, lanes)
+            assert sum(g) == n and max(g) <= lanes and max(g) - min(g) <= 1 and len(g) == -(-n // lanes) and g == sorted(g, reverse=True)
+
+
 def test_plan_cache_is_process_wide_locked_and_keyed_on_the_device(monkeypatch):
     """a cached plan is bound to the device it was built on -- the key holds the current device -- and carries
     mutable state (staging buffers, side streams, decoder workspaces): ONE cache per process under a module lock, use serialised by
