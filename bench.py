@@ -294,7 +294,7 @@ OTHER_CONFIGS = [
     ("configs[3] bb144 p=6e-3", dict(p=0.006, shots=262144, steps=3, warmup=1)),
     ("configs[2] bb144 headline window, osd_cs(1)", dict(osd_method="osd_cs", osd_order=1, shots=131072, steps=2, warmup=1)),
     ("configs[2] bb144 headline window, bp-lsd lsd_cs(1)", dict(osd_method="lsd_cs", osd_order=1, shots=262144, steps=2, warmup=1)),
-    ("configs[4] qlp1020 W=3 F=1 p=1e-3 osd_0", dict(code="qlp1020", window=[3, 1], p_override=0.001, shots=32768, steps=2, warmup=1)),     # (8192 shots: 21.5 k, 32 768: 22.7 k, 65 536: 23.0 k shots/s -- launch tails)
+    ("configs[4] qlp1020 W=3 F=1 p=1e-3 osd_0", dict(code="qlp1020", window=[3, 1], p_override=0.001, shots=65536, steps=2, warmup=1)),     # (8192 shots per step: 21.5 k, 32 768: 22.7 k, 65 536 = two chunks of 32 768 through the two-stream driver: 23.5 k shots/s)
     ("configs[4] qlp1020 W=3 F=1 p=1e-3 osd_cs(1)", dict(code="qlp1020", window=[3, 1], p_override=0.001, osd_method="osd_cs", osd_order=1,
                                                         shots=8192, steps=2, warmup=1)),
     ("configs[4] qlp1020 W=3 F=1 p=3e-3 (fixture p) osd_0", dict(code="qlp1020", window=[3, 1], shots=8192, steps=2, warmup=1)),

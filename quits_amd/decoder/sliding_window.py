@@ -148,6 +148,12 @@ class DeviceWindowPlan:
         # runs beside the BP of the NEXT lane and, starved of wavefront slots by it, ends ~0.4 ms after it: with two lanes the BP stream
         # waits that long before every stage, with three the post stage has one more BP stage's time (profiles/r06_three_lanes_ab.txt)
         self.lanes = max(2, _env_int("QD_PIPELINE_LANES", 3 if nwin > 1 else 2))
+        # every lane has its own decoders and every decoder its own posterior workspace (4 bytes per fault and shot of a chunk): a plan of many
+        # large windows -- QLP [[1020,136]] W = 3: 18 decoders x 18 900 faults = 1.36 MB per shot and lane -- would not fit three lanes of
+        # 65 536 shots (268 GB).  Lanes first, then the chunk, give way until the estimate fits QD_POST_WS_GB (default 160 of the 288 GB).
+        if self.pipeline and not os.environ.get("QD_CHUNK_SHOTS"):
+            per_shot = sum(4 * ((d.graph.n + 63) // 64 * 64) + 64 for d in decs)
+            self.lanes, self.chunk = fit_lanes_and_chunk(per_shot, self.lanes, self.chunk, float(os.environ.get("QD_POST_WS_GB", "160")) * (1 << 30))
         self._side = None
         self._stage = None
         self.host_piece = max(1, _env_int("QD_HOST_PIECE_SHOTS", self.lanes * self.chunk))   # shots per staged piece (one group of the pipelined driver's lanes)
@@ -299,6 +305,19 @@ class DeviceWindowPlan:
             if span[b] is not None:
                 res[span[b][0]:span[b][1]] = out[span[b][0]:span[b][1]].numpy()
         return res
+
+
+def fit_lanes_and_chunk(per_shot_bytes, lanes, chunk, budget_bytes, min_chunk=8192):
+    """(lanes, chunk) of the pipelined driver such that lanes x chunk x per_shot_bytes (the lanes' decoder workspaces) fits the budget: a third
+    lane goes first (it is worth 2-5 %), then the chunk is halved (down to `min_chunk` shots: below that the launches are all tail)."""
+    while lanes * chunk * per_shot_bytes > budget_bytes:
+        if lanes > 2:
+            lanes -= 1
+        elif chunk // 2 >= min_chunk:
+            chunk //= 2
+        else:
+            break
+    return lanes, chunk
 
 
 def lane_groups(nchunks, lanes):

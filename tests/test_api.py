@@ -251,6 +251,17 @@ def test_lane_groups_of_the_pipelined_driver():
             assert sum(g) == n and max(g) <= lanes and max(g) - min(g) <= 1 and len(g) == -(-n // lanes) and g == sorted(g, reverse=True)
 
 
+def test_lanes_and_chunk_give_way_to_the_workspace_budget():
+    """Plans of many large windows do not get three lanes of 65 536 shots: the third lane goes first, then the chunk is halved."""
+    from quits_amd.decoder.sliding_window import fit_lanes_and_chunk
+    GB = 1 << 30
+    assert fit_lanes_and_chunk(12 * 8704, 3, 65536, 160 * GB) == (3, 65536)                 # BB144 W = 3 / F = 1: 20 GB
+    qlp = 18 * (4 * 18944 + 64)                                                            # QLP [[1020,136]] W = 3: 1.36 MB per shot and lane
+    assert fit_lanes_and_chunk(qlp, 3, 65536, 160 * GB) == (2, 32768)
+    assert fit_lanes_and_chunk(qlp, 2, 65536, 288 * GB) == (2, 65536)
+    assert fit_lanes_and_chunk(10 ** 9, 3, 65536, GB) == (2, 8192)                          # never below the floor, never fewer than two lanes
+
+
 def test_plan_cache_is_process_wide_locked_and_keyed_on_the_device(monkeypatch):
     """a cached plan is bound to the device it was built on -- the key holds the current device -- and carries
     mutable state (staging buffers, side streams, decoder workspaces): ONE cache per process under a module lock, use serialised by
