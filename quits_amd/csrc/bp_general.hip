@@ -749,7 +749,7 @@ hipError_t qd_launch_bp_general(const GenGraphDev &g, const BpGraphDev &bg, cons
     // the staged serial schedule (GenStage): launches over iterations (0, b0], (b0, b1], ... (b_last, max_iter], workspaces w / plan->w2 in turn
     int nb = (plan && schedule == QD_SCHEDULE_SERIAL) ? plan->nbounds : 0;
     if (nb > 0) {
-        if (plan->pending && hipEventQuery(plan->counts_ready) == hipSuccess) {      // what an earlier staged call packed (never waited for)
+        if (plan->pending && qd_event_done(plan->counts_ready)) {      // what an earlier staged call packed (never waited for)
             plan->pending = 0;
             const int left = plan->host_counts[plan->pending_nb - 1];                  // shots that went into its last launch
             if (plan->pending_shots >= 4096 && (double)left > 0.85 * (double)plan->pending_shots) plan->one_launch_calls = QD_GEN_PROBE;

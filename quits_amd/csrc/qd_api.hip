@@ -1488,7 +1488,7 @@ extern "C" int qd_decoder_post_head_start(qd_decoder *d, int32_t microseconds, v
     const bool always = d->lsd || d->osd_blocks_cs > 0;
     double frac = 0.75;
     if (const char *ev = std::getenv("QD_POST_HEAD_FRAC")) frac = std::atof(ev);
-    if (d->fail_pending && hipEventQuery(d->fail_ready) == hipSuccess) {
+    if (d->fail_pending && qd_event_done(d->fail_ready)) {
         d->fail_pending = false;
         if (d->fail_pending_B > 0) d->fail_frac_hint = (double)d->host_fail[0] / (double)d->fail_pending_B;
     }

@@ -142,6 +142,13 @@ struct GenWs {
 #ifndef QD_SR_PRIO
 #define QD_SR_PRIO 0
 #endif
+// hipEventQuery without side effects: "not ready" is an answer, not an error -- it must not be what a later hipGetLastError() behind a kernel launch reports
+static inline bool qd_event_done(hipEvent_t e)
+{
+    const hipError_t r = hipEventQuery(e);
+    if (r != hipSuccess) (void)hipGetLastError();
+    return r == hipSuccess;
+}
 #define QD_GEN_MAX_STAGES 12
 struct GenStagePlan;
 struct GenStage {
